@@ -1,0 +1,309 @@
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run only in the build container (needs /root/reference, which never travels
+to the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own GAN-Based-SR/basicsr/losses/loss_util.py by
+path -- with the CUDA-only `basicsr.losses.similarity.similaritywrapper`
+module stubbed in sys.modules, because the real one needs loguru + a CUDA
+device and calls sys.exit() without them (similaritywrapper.py:11-13) -- runs
+`similarity_map(..., ssl_mode='pytorch')` (the F.unfold path,
+loss_util.py:182-229) on seeded inputs and stores inputs + outputs as small
+.npz files.  L1Loss / KLDistanceLoss live in basic_loss.py, whose import pulls
+torchvision (absent here); their forward bodies are the two one-liners
+basic_loss.py:16 (F.l1_loss, 'mean') and basic_loss.py:281 (F.kl_div on
+clamped logs), restated below with torch.nn.functional exactly as written
+there.
+
+Only DATA is stored (inputs, expected outputs); no reference source text.
+"""
+import importlib.util
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/GAN-Based-SR/basicsr/losses/loss_util.py"
+
+from ssl_amd import synth  # noqa: E402
+
+
+def load_reference():
+    for name in ("basicsr", "basicsr.losses", "basicsr.losses.similarity"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    stub = types.ModuleType("basicsr.losses.similarity.similaritywrapper")
+
+    def compute_similarity(*a, **k):  # never reached in ssl_mode='pytorch'
+        raise RuntimeError("CUDA op is not available in the build container")
+
+    stub.compute_similarity = compute_similarity
+    sys.modules["basicsr.losses.similarity.similaritywrapper"] = stub
+    spec = importlib.util.spec_from_file_location("ref_loss_util", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ref = load_reference()
+
+
+def ref_ssg(img, mask, ks, kw, sigma, gen, dtype=torch.float32, requires_grad=False):
+    """similarity_map(img (1,C,H,W), mask (1,c1,H,W)).getitem() from the reference."""
+    t = torch.as_tensor(img, dtype=dtype).clone().requires_grad_(requires_grad)
+    m = torch.as_tensor(mask, dtype=dtype)
+    s = ref.similarity_map(img=t, mask=m, ssl_mode="pytorch", kernel_size_search=ks,
+                           generalization=gen, kernel_size_window=kw, sigma=sigma).getitem()
+    return t, s
+
+
+def l1_loss(a, b, w):   # basic_loss.py:66 -> :16, reduction='mean'
+    return w * F.l1_loss(a, b, reduction="mean")
+
+
+def kl_loss(a, b, w):   # basic_loss.py:281
+    return w * F.kl_div(torch.clamp(a, min=1e-10).log(), torch.clamp(b, min=1e-10), reduction="mean")
+
+
+def caller_loop(sr, gt, masks, ks, kw, sigma, gen, w1, w2, dtype):
+    """realesrganssl_model.py:379-430: per-image loop, skip empty, cat, two criteria."""
+    sr_t = torch.as_tensor(sr, dtype=dtype).clone().requires_grad_(True)
+    gt_t = torch.as_tensor(gt, dtype=dtype)
+    m_t = torch.as_tensor(masks, dtype=dtype)
+    ls, lg = [], []
+    for i in range(sr_t.shape[0]):
+        bm = m_t[i, :].unsqueeze(0)
+        if bm.sum() == 0:
+            continue
+        ls.append(ref.similarity_map(img=sr_t[i, :].unsqueeze(0).clone(), mask=bm.clone(), ssl_mode="pytorch",
+                                     kernel_size_search=ks, generalization=gen, kernel_size_window=kw,
+                                     sigma=sigma).getitem())
+        with torch.no_grad():
+            lg.append(ref.similarity_map(img=gt_t[i, :].unsqueeze(0).clone(), mask=bm.clone(), ssl_mode="pytorch",
+                                         kernel_size_search=ks, generalization=gen, kernel_size_window=kw,
+                                         sigma=sigma).getitem())
+    a = torch.cat(ls, dim=1)
+    b = torch.cat(lg, dim=1)
+    l1 = l1_loss(a, b, w1)
+    kl = kl_loss(a, b, w2)
+    (l1 + kl).backward()
+    return a.detach(), b.detach(), l1.detach(), kl.detach(), sr_t.grad.detach()
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KB")
+
+
+def smooth_cotangent(shape, seed):
+    """Fixed smooth-ish random cotangent for dSSG/dimg checks."""
+    return np.random.default_rng(seed).standard_normal(shape).astype(np.float64)
+
+
+def f1_c1():
+    """F1 (BASELINE configs[0]): 1x3x64x64 uniform noise, fixed 5 % mask incl. the
+    4 corners, k_s=11 k_w=5, sigma in {1.0, 0.05}, generalization in {F,T}."""
+    sr, gt, mask = synth.uniform_case()
+    ks, kw = 11, 5
+    out = dict(sr=sr, gt=gt, mask=mask.astype(np.uint8), ks=ks, kw=kw)
+    n = int(mask.sum())
+    cot = smooth_cotangent((1, n, ks * ks), 7).astype(np.float32).astype(np.float64)
+    out["cot"] = cot.astype(np.float32)
+    for sigma in (1.0, 0.05):
+        for gen in (False, True):
+            tag = f"s{sigma}_g{int(gen)}"
+            t, s = ref_ssg(sr, mask, ks, kw, sigma, gen, torch.float64, True)
+            (s * torch.as_tensor(cot, dtype=torch.float64)).sum().backward()
+            out[f"ssg_{tag}"] = s.detach().numpy()[0].astype(np.float32)
+            out[f"dimg_{tag}"] = t.grad.numpy()[0].astype(np.float32)
+            if gen and sigma == 1.0:   # one fp32 run of the reference, for the record
+                _, s32 = ref_ssg(sr, mask, ks, kw, sigma, gen, torch.float32)
+                out[f"ssg_{tag}_f32run"] = s32.detach().numpy()[0]
+    # full caller-loop semantics on the same pair (weights 1e3 like the YAML)
+    for dt, dn in ((torch.float32, "f32"), (torch.float64, "f64")):
+        a, b, l1, kl, g = caller_loop(sr, gt, mask, ks, kw, 1.0, True, 1e3, 1e3, dt)
+        out[f"l1_{dn}"] = l1.numpy()
+        out[f"kl_{dn}"] = kl.numpy()
+        if dn == "f64":
+            out["grad"] = g.numpy().astype(np.float32)
+    save("f1_c1_64", **out)
+
+
+def f2_paper(size, sigmas, name, rows=64):
+    """F2 (BASELINE configs[1]-shaped, ONE image): natural-like pair, Laplacian
+    mask ~8 %, k_s=25 k_w=9, generalization=True, L1+KL weights 1e3."""
+    ks, kw = 25, 9
+    gt = synth.natural_like(100, size, size)[None]
+    sr = synth.degrade(gt[0], 10_100)[None]
+    mask = synth.laplacian_edge_mask(gt[0])[None, None]
+    n = int(mask.sum())
+    # sampled rows: first/last (image corners side) + random
+    rng = np.random.default_rng(3)
+    sel = np.unique(np.concatenate([[0, 1, n - 2, n - 1], rng.choice(n, rows - 4, replace=False)]))
+    out = dict(sr=sr, gt=gt, mask=mask.astype(np.uint8), ks=ks, kw=kw, rows=sel, n_edges=n,
+               checksum=synth.checksum(sr, gt, mask.astype(np.float32)))
+    print(f"  {name}: N={n} density={n / size / size:.4f}")
+    for sigma in sigmas:
+        for dt, dn in ((torch.float32, "f32"), (torch.float64, "f64")):
+            t0 = time.time()
+            a, b, l1, kl, g = caller_loop(sr, gt, mask, ks, kw, sigma, True, 1e3, 1e3, dt)
+            out[f"l1_s{sigma}_{dn}"] = l1.numpy()
+            out[f"kl_s{sigma}_{dn}"] = kl.numpy()
+            gg = g.numpy()
+            out[f"grad_absmax_s{sigma}_{dn}"] = np.abs(gg).max()
+            out[f"grad_sum_s{sigma}_{dn}"] = gg.astype(np.float64).sum()
+            if dn == "f64":
+                out[f"ssg_sr_s{sigma}"] = a.numpy()[0][sel].astype(np.float32)
+                out[f"ssg_gt_s{sigma}"] = b.numpy()[0][sel].astype(np.float32)
+                out[f"grad_s{sigma}"] = gg.astype(np.float32)
+            print(f"    sigma={sigma} {dn}: l1={float(l1):.6g} kl={float(kl):.6g} ({time.time() - t0:.0f}s)")
+    save(name, **out)
+
+
+def f3_masks():
+    """F3: 3-channel mask (ssl_pytorch lists every edge pixel 3x, block-tiled:
+    realesrganssl_model.py:339-341 feeds (b,3,H,W) masks) and a batch of 2 with
+    one EMPTY mask (skipped, realesrganssl_model.py:387-388)."""
+    ks, kw, sigma = 11, 5, 0.5
+    rng = np.random.default_rng(11)
+    img = rng.random((2, 3, 40, 48), dtype=np.float32)
+    gt = rng.random((2, 3, 40, 48), dtype=np.float32)
+    m1 = (rng.random((40, 48)) < 0.06).astype(np.float32)
+    m1[0, 0] = m1[39, 47] = m1[0, 47] = 1
+    out = dict(sr=img, gt=gt, ks=ks, kw=kw, sigma=sigma)
+    mask3 = np.repeat(m1[None, None], 3, axis=1)
+    _, s3 = ref_ssg(img[:1], mask3, ks, kw, sigma, True)
+    _, s1 = ref_ssg(img[:1], m1[None, None], ks, kw, sigma, True)
+    out["mask1"] = m1.astype(np.uint8)
+    out["ssg_mask3_f32"] = s3.detach().numpy()[0]
+    out["ssg_mask1_f32"] = s1.detach().numpy()[0]
+    masks = np.stack([np.zeros_like(m1), m1])[:, None]  # image 0 empty
+    for dt, dn in ((torch.float32, "f32"), (torch.float64, "f64")):
+        a, b, l1, kl, g = caller_loop(img, gt, masks, ks, kw, sigma, True, 1e3, 1e3, dt)
+        out[f"b2_l1_{dn}"] = l1.numpy()
+        out[f"b2_kl_{dn}"] = kl.numpy()
+        if dn == "f64":
+            out["b2_grad"] = g.numpy().astype(np.float32)
+    out["b2_masks"] = masks.astype(np.uint8)
+    save("f3_masks", **out)
+
+
+def f4_stress():
+    """F4 (BASELINE configs[4]-shaped): 3x128x128, k_s=49 k_w=13, DENSE mask
+    evaluated by the reference in chunks of 256 mask pixels (an SSG row depends
+    only on (img, y, x)); 32 sampled rows incl. the image corners."""
+    ks, kw, sigma = 49, 13, 1.0
+    H = W = 128
+    gt = synth.natural_like(300, H, W)[None]
+    rng = np.random.default_rng(5)
+    pix = np.unique(np.concatenate([[0, W - 1, (H - 1) * W, H * W - 1, 5 * W + 7],
+                                    rng.choice(H * W, 27, replace=False)]))
+    m = np.zeros(H * W, np.float32)
+    m[pix] = 1
+    m = m.reshape(1, 1, H, W)
+    out = dict(img=gt, ks=ks, kw=kw, sigma=sigma, pix=pix)
+    _, s = ref_ssg(gt, m, ks, kw, sigma, True, torch.float64)
+    out["ssg"] = s.detach().numpy()[0].astype(np.float32)
+    save("f4_stress_ks49", **out)
+
+
+def f5_stride_f6_eps():
+    """F5: mask_stride=3 eye pattern (ddpmssl.py:47-56,445-446) applied before the
+    SSG; F6: the Diffusion fork's epsilon 1e-20 (DM loss_util.py:1250) -- obtained
+    from the reference's un-normalised output (generalization=False) by the
+    reference's own normalisation expression with that epsilon."""
+    ks, kw, sigma = 25, 9, 0.004
+    H = W = 96
+    gt = synth.natural_like(400, H, W)[None]
+    mask = synth.laplacian_edge_mask(gt[0])
+    s = 3
+    eye = torch.eye(s, s, dtype=torch.float32).repeat(int(np.ceil(H / s)), int(np.ceil(W / s)))[:H, :W]
+    ms = (eye.numpy() * mask).astype(np.float32)
+    out = dict(img=gt, mask=mask.astype(np.uint8), mask_strided=ms.astype(np.uint8), stride=s,
+               ks=ks, kw=kw, sigma=sigma)
+    n = int(ms.sum())
+    sel = np.unique(np.concatenate([[0, n - 1], np.random.default_rng(9).choice(n, 46, replace=False)]))
+    out["rows"] = sel
+    out["n_edges"] = n
+    _, a = ref_ssg(gt, ms[None, None], ks, kw, sigma, True, torch.float64)
+    out["ssg_strided"] = a.detach().numpy()[0][sel].astype(np.float32)
+    _, e = ref_ssg(gt, ms[None, None], ks, kw, sigma, False, torch.float64)
+    q = e.detach()
+    q20 = 1 / (torch.sum(q, dim=-1) + 1e-20).unsqueeze(-1) * q
+    out["e_strided"] = q.numpy()[0][sel].astype(np.float32)
+    out["ssg_eps1e-20"] = q20.numpy()[0][sel].astype(np.float32)
+    save("f5_stride_f6_eps", **out)
+
+
+def f7_mask_pil():
+    """Edge-mask fixture: a 64x64 uint8 RGB image, PIL's convert('L') of it, and
+    the mask by generate_mask.py:22-31 with cv2.Laplacian(CV_8U) replaced by its
+    documented arithmetic evaluated with scipy.ndimage (cv2 is not installed):
+    3x3 [[0,1,0],[1,-4,1],[0,1,0]], BORDER_REFLECT_101 == scipy 'mirror',
+    saturate to [0,255], > 20."""
+    from PIL import Image
+    from scipy import ndimage
+    g = synth.natural_like(500, 64, 64)
+    u8 = np.rint(g * 255).astype(np.uint8).transpose(1, 2, 0).copy()
+    L = np.array(Image.fromarray(u8).convert("L"))
+    K = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], np.int32)
+    lap = np.clip(ndimage.correlate(L.astype(np.int32), K, mode="mirror"), 0, 255).astype(np.uint8)
+    mask = np.zeros(L.shape, dtype="int")
+    mask[lap > 20.0] = 1
+    save("f7_edge_mask", rgb=u8, gray=L, lap=lap, mask=mask.astype(np.uint8))
+
+
+def cpu_reference_timing():
+    """time the reference ssl_pytorch loss step on this
+    container's cores (one 3x256x256 image of the C2 batch, like the reference's
+    per-image loop) and record it next to the fixtures."""
+    import json
+    torch.set_num_threads(os.cpu_count())
+    ks, kw, sigma = 25, 9, 1.0
+    gt = synth.natural_like(100, 256, 256)[None]
+    sr = synth.degrade(gt[0], 10_100)[None]
+    mask = synth.laplacian_edge_mask(gt[0])[None, None]
+    n = int(mask.sum())
+    times = []
+    for it in range(3):
+        t0 = time.time()
+        caller_loop(sr, gt, mask, ks, kw, sigma, True, 1e3, 1e3, torch.float32)
+        times.append(time.time() - t0)
+        print(f"    reference step {it}: {times[-1]:.1f}s")
+    med = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
+    res = dict(what="reference ssl_pytorch fwd(SR)+fwd(GT)+L1+KL+backward, 1x3x256x256, k_s=25 k_w=9 sigma=1.0, fp32",
+               n_edges=n, seconds=times, median_after_warmup_s=med, edge_px_per_s=n / med,
+               cores=os.cpu_count(), torch_threads=torch.get_num_threads(), torch=torch.__version__)
+    with open(os.path.join(HERE, "reference_cpu_timing.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("  ", res)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7"]
+    torch.manual_seed(0)
+    if "f1" in which:
+        f1_c1()
+    if "f2s" in which:
+        f2_paper(128, (1.0, 0.004), "f2_paper_128")
+    if "f2" in which:
+        f2_paper(256, (0.004,), "f2_paper_256")
+    if "f3" in which:
+        f3_masks()
+    if "f4" in which:
+        f4_stress()
+    if "f5" in which:
+        f5_stride_f6_eps()
+    if "f7" in which:
+        f7_mask_pil()
+    if "time" in which:
+        cpu_reference_timing()

@@ -1,0 +1,187 @@
+"""The CPU oracle (oracle/ssg_oracle.c) against the golden vectors captured from
+the reference's own loss_util.py (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the fixtures hold the reference's float64 results stored as
+float32 (6e-8 relative); the float64 oracle must agree to that storage
+precision, the float32 oracle to 1e-6 (fp32 accumulation of <= 507 terms).
+"""
+import numpy as np
+import pytest
+
+from oracle import ssg_oracle as orc
+
+
+def _close(a, b, atol, rtol=0.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    lim = atol + rtol * np.abs(b)
+    assert a.shape == b.shape
+    assert (err <= lim).all(), f"max err {err.max():.3e} (limit {lim.flat[err.argmax()]:.3e})"
+
+
+@pytest.mark.parametrize("dtype,atol", [(np.float64, 2e-7), (np.float32, 2e-6)])
+@pytest.mark.parametrize("sigma", [1.0, 0.05])
+@pytest.mark.parametrize("gen", [False, True])
+def test_f1_ssg_and_vjp(golden, dtype, atol, sigma, gen):
+    g = golden("f1_c1_64")
+    ks, kw = int(g["ks"]), int(g["kw"])
+    img = g["sr"][0].astype(dtype)
+    mask = g["mask"][0, 0]
+    pos = orc.mask_to_pos(mask)
+    assert pos.shape[0] == 209 and mask[0, 0] == 1 and mask[-1, -1] == 1
+    D = orc.distance(img, pos, ks, kw)
+    S = orc.ssg_epilogue(D, kw, 3, sigma, gen)
+    ref = g[f"ssg_s{sigma}_g{int(gen)}"]
+    _close(S, ref, atol)
+    # centre of every row is the largest entry (D == 0 there)
+    assert (S.argmax(1) == (ks * ks) // 2).all()
+    # vector-Jacobian product under the fixed cotangent
+    cot = g["cot"][0].astype(dtype)
+    gD = orc.ssg_epilogue_backward(S, cot, ks, kw, 3, sigma, gen)
+    gI = orc.distance_backward(img, pos, ks, kw, gD)
+    refg = g[f"dimg_s{sigma}_g{int(gen)}"]
+    _close(gI, refg, atol=3e-6 * np.abs(refg).max() if dtype == np.float32 else 2e-7 * np.abs(refg).max())
+
+
+def test_f1_fp32_reference_run_is_within_tolerance_of_fp64(golden):
+    g = golden("f1_c1_64")
+    _close(g["ssg_s1.0_g1_f32run"], g["ssg_s1.0_g1"], 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_f1_caller_loop_losses_and_grad(golden, dtype):
+    g = golden("f1_c1_64")
+    r = orc.ssg_loss(g["sr"].astype(dtype), g["gt"].astype(dtype), g["mask"][:, 0], int(g["ks"]), int(g["kw"]),
+                     1.0, 1e3, 1e3)
+    rt = 1e-9 if dtype == np.float64 else 2e-5
+    assert abs(r["l1"] - float(g["l1_f64"])) <= rt * abs(float(g["l1_f64"]))
+    assert abs(r["kl"] - float(g["kl_f64"])) <= max(rt, 1e-7) * abs(float(g["kl_f64"])) + 1e-12
+    if dtype == np.float64:
+        _close(r["grad"], g["grad"], atol=2e-7 * np.abs(g["grad"]).max())
+
+
+@pytest.mark.parametrize("size_name", ["f2_paper_128", "f2_paper_256"])
+def test_f2_paper_config(golden, size_name):
+    try:
+        g = golden(size_name)
+    except FileNotFoundError:
+        pytest.skip("fixture not generated")
+    ks, kw = int(g["ks"]), int(g["kw"])
+    sr, gt, mask = g["sr"].astype(np.float64), g["gt"].astype(np.float64), g["mask"][:, 0]
+    rows = g["rows"]
+    pos = orc.mask_to_pos(mask[0])
+    assert pos.shape[0] == int(g["n_edges"])
+    sigmas = [k[len("l1_s"):-len("_f64")] for k in g.files if k.startswith("l1_s") and k.endswith("_f64")]
+    assert sigmas
+    for sg in sigmas:
+        sigma = float(sg)
+        for img, key in ((sr[0], "ssg_sr"), (gt[0], "ssg_gt")):
+            S = orc.ssg_epilogue(orc.distance(img, pos[rows], ks, kw), kw, 3, sigma, True)
+            _close(S, g[f"{key}_s{sg}"], 2e-7)
+        if size_name.endswith("128"):   # full loss + gradient (seconds on 8 cores)
+            r = orc.ssg_loss(sr, gt, mask, ks, kw, sigma, 1e3, 1e3)
+            assert abs(r["l1"] - float(g[f"l1_s{sg}_f64"])) <= 1e-9 * abs(float(g[f"l1_s{sg}_f64"]))
+            assert abs(r["kl"] - float(g[f"kl_s{sg}_f64"])) <= 1e-8 * abs(float(g[f"kl_s{sg}_f64"]))
+            ref = g[f"grad_s{sg}"]
+            # L1's sign() makes isolated gradient entries flip on ties between fp runs: compare in L1 norm too
+            _close(r["grad"], ref[None] if ref.ndim == 3 else ref, atol=1e-6 * np.abs(ref).max())
+
+
+def test_f3_three_channel_mask_and_empty_image(golden):
+    g = golden("f3_masks")
+    ks, kw, sigma = int(g["ks"]), int(g["kw"]), float(g["sigma"])
+    S = orc.ssg_map(g["sr"][0].astype(np.float64), g["mask1"], ks, kw, sigma)
+    _close(S, g["ssg_mask1_f32"], 2e-6)
+    # ssl_pytorch with a (1,3,H,W) mask lists every edge pixel three times, block-tiled
+    _close(np.tile(S, (3, 1)), g["ssg_mask3_f32"], 2e-6)
+    r = orc.ssg_loss(g["sr"].astype(np.float64), g["gt"].astype(np.float64), g["b2_masks"][:, 0], ks, kw, sigma,
+                     1e3, 1e3)
+    assert abs(r["l1"] - float(g["b2_l1_f64"])) <= 1e-9 * float(g["b2_l1_f64"])
+    assert abs(r["kl"] - float(g["b2_kl_f64"])) <= 1e-8 * float(g["b2_kl_f64"])
+    assert np.abs(r["grad"][0]).max() == 0.0   # the empty-mask image is skipped
+    _close(r["grad"], g["b2_grad"], atol=2e-7 * np.abs(g["b2_grad"]).max())
+
+
+def test_f4_stress_kernel_sizes(golden):
+    g = golden("f4_stress_ks49")
+    ks, kw, sigma = int(g["ks"]), int(g["kw"]), float(g["sigma"])
+    H, W = g["img"].shape[-2:]
+    pix = g["pix"]
+    pos = np.stack([pix // W, pix % W], 1).astype(np.int32)
+    S = orc.ssg_epilogue(orc.distance(g["img"][0].astype(np.float64), pos, ks, kw), kw, 3, sigma, True)
+    _close(S, g["ssg"], 2e-7)
+    S32 = orc.ssg_epilogue(orc.distance(g["img"][0].astype(np.float32), pos, ks, kw), kw, 3, sigma, True)
+    _close(S32, g["ssg"], 1e-6)
+
+
+def test_f5_mask_stride_and_f6_eps(golden):
+    g = golden("f5_stride_f6_eps")
+    ks, kw, sigma, s = int(g["ks"]), int(g["kw"]), float(g["sigma"]), int(g["stride"])
+    ms = orc.mask_stride(g["mask"], s)
+    assert np.array_equal(ms, g["mask_strided"])
+    pos = orc.mask_to_pos(ms)
+    assert pos.shape[0] == int(g["n_edges"])
+    rows = g["rows"]
+    D = orc.distance(g["img"][0].astype(np.float64), pos[rows], ks, kw)
+    _close(orc.ssg_epilogue(D, kw, 3, sigma, True), g["ssg_strided"], 2e-7)
+    _close(orc.ssg_epilogue(D, kw, 3, sigma, False), g["e_strided"], 2e-7)
+    _close(orc.ssg_epilogue(D, kw, 3, sigma, True, eps=1e-20), g["ssg_eps1e-20"], 2e-7)
+
+
+def test_f7_edge_mask(golden):
+    g = golden("f7_edge_mask")
+    m, gray = orc.edge_mask_rgb8(g["rgb"], 20.0, return_gray=True)
+    assert np.array_equal(gray, g["gray"])      # PIL convert('L')
+    assert np.array_equal(m, g["mask"])
+    chw = (g["rgb"].astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1)
+    assert np.array_equal(orc.edge_mask_chw(chw), g["mask"])
+    assert 0.02 < m.mean() < 0.3
+
+
+def test_padded_operator_semantics_match_unpadded():
+    """similarity.h-style entry points (padded image + padded pos) == the reflect-by-index form."""
+    rng = np.random.default_rng(0)
+    img = rng.random((3, 20, 24))
+    ks, kw = 7, 3
+    hp = ks // 2
+    pos = np.array([[0, 0], [19, 23], [5, 7], [0, 12], [10, 0]], np.int32)
+    D = orc.distance(img, pos, ks, kw)
+    pad = np.pad(img, ((0, 0), (hp, hp), (hp, hp)), mode="reflect")
+    D2 = orc.compute_similarity_padded(pad, pos + hp, ks, kw)
+    assert np.abs(D - D2).max() < 1e-13
+    gD = rng.standard_normal(D.shape)
+    gi_pad = orc.compute_similarity_backward_padded(pad, gD, pos + hp, ks, kw)
+    # fold the reflect pad back (what autograd does for F.pad(mode='reflect'))
+    H, W = img.shape[1:]
+    fold = np.zeros_like(img)
+    for Y in range(H + 2 * hp):
+        y = abs(Y - hp)
+        y = 2 * H - 2 - y if y >= H else y
+        for X in range(W + 2 * hp):
+            x = abs(X - hp)
+            x = 2 * W - 2 - x if x >= W else x
+            fold[:, y, x] += gi_pad[:, Y, X]
+    gi = orc.distance_backward(img, pos, ks, kw, gD)
+    assert np.abs(gi - fold).max() < 1e-12
+
+
+def test_backward_matches_finite_differences():
+    rng = np.random.default_rng(1)
+    img = rng.random((2, 9, 10))
+    ks, kw, sigma = 5, 3, 0.3
+    pos = np.array([[0, 0], [4, 5], [8, 9], [3, 0]], np.int32)
+    cot = rng.standard_normal((4, ks * ks))
+
+    def f(x):
+        return (orc.ssg_epilogue(orc.distance(x, pos, ks, kw), kw, 2, sigma, True) * cot).sum()
+
+    S = orc.ssg_epilogue(orc.distance(img, pos, ks, kw), kw, 2, sigma, True)
+    g = orc.distance_backward(img, pos, ks, kw, orc.ssg_epilogue_backward(S, cot, ks, kw, 2, sigma, True))
+    num = np.zeros_like(img)
+    h = 1e-6
+    for i in np.ndindex(img.shape):
+        a = img.copy(); a[i] += h
+        b = img.copy(); b[i] -= h
+        num[i] = (f(a) - f(b)) / (2 * h)
+    assert np.abs(num - g).max() < 1e-7
