@@ -1,0 +1,169 @@
+/*
+ * ssg_hip.h -- C ABI of the MI355X (gfx950) Self-Similarity-Graph loss engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of ChrisDud0257/SSL: the
+ * SSG loss.  Everything below is `extern "C"`, takes
+ * plain DEVICE pointers and sizes, allocates nothing, never synchronises the
+ * host, and launches on the hipStream_t the caller passes (pass
+ * torch.cuda.current_stream().cuda_stream from PyTorch).  All floating point
+ * is IEEE fp32; indices are int32.
+ *
+ * Reference interface each group replaces (paths relative to
+ * /root/reference/GAN-Based-SR/):
+ *   (A) ssg_compute_similarity[_backward]   <- basicsr/losses/similarity/similarity.h:2-23
+ *                                              (kernels similarity.cu:6-54, 74-131; pybind
+ *                                              glue similaritywrapper.cpp:9-72)
+ *   (B) ssg_edge_*                          <- scripts/data_preparation/generate_mask.py:22-31,
+ *                                              torch.where / torch.nonzero in loss_util.py:196 and
+ *                                              similaritywrapper.py:64-68, mask_stride pattern
+ *                                              realesrganssl_model.py:64-72
+ *   (C) ssg_map_forward / ssg_map_backward  <- similarity_map.ssl_pytorch / ssl_cuda,
+ *                                              basicsr/losses/loss_util.py:182-244 (+ autograd)
+ *   (D) ssg_loss_*                          <- the caller loop realesrganssl_model.py:379-430
+ *                                              with L1Loss (basic_loss.py:41-66) and
+ *                                              KLDistanceLoss (basic_loss.py:269-282)
+ *
+ * Return value of every int function: 0 on success, a positive hipError_t
+ * from the launch, or a negative SSG_E_* code.  ssg_status_string() maps both.
+ */
+#ifndef SSG_HIP_H
+#define SSG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ssg_stream_t; /* hipStream_t */
+
+#define SSG_E_BADARG (-1)     /* null pointer, even / non-positive kernel size, k_w > k_s ...   */
+#define SSG_E_TOOLARGE (-2)   /* search tile does not fit the 160 KiB LDS of a CU               */
+#define SSG_E_WORKSPACE (-3)  /* caller's workspace is smaller than ssg_loss_workspace_bytes()   */
+#define SSG_E_IMAGESMALL (-4) /* H or W <= k_s/2: reflect padding undefined (torch raises too)   */
+
+int ssg_abi_version(void);
+const char *ssg_status_string(int status);
+
+/* ---------------------------------------------------------------- (A) ----
+ * Reference operator, same argument meaning as similarity.h:2-11 plus a
+ * stream and a status.  `image` is the REFLECT-PADDED (channel,height,width)
+ * fp32 image, `pos` holds mc (Y,X) int32 pairs in PADDED coordinates, `out`
+ * is (mc,psize,psize) and is ACCUMULATED into (the reference kernel does
+ * `out[...] += d*d` on a zeroed buffer).  Raw squared patch distances, no
+ * epilogue.  Asynchronous. */
+int ssg_compute_similarity(const float *image, const int *pos, float *out,
+                           int mc, int psize, int ksize, int height, int width,
+                           int channel, ssg_stream_t stream);
+
+/* similarity.h:13-23: scatter of `grads` = dL/d(out) (mc,psize,psize) into
+ * `image_grads` (channel,height,width, PADDED layout, accumulated into).  The
+ * reference uses ~2*C*ksize^2 global atomics per (edge pixel, offset); this
+ * one reduces per edge pixel on chip and issues one atomic per touched
+ * pixel. */
+int ssg_compute_similarity_backward(const float *image, const float *grads,
+                                    const int *pos, float *image_grads, int mc,
+                                    int psize, int ksize, int height, int width,
+                                    int channel, ssg_stream_t stream);
+
+/* ---------------------------------------------------------------- (B) ----
+ * Edge list of a batch, built on device without a host round trip.
+ *
+ * mask_kind: 0 = fp32 mask (B,mask_channels,H,W), an edge pixel is
+ *                `mask[b,0,y,x] == 1.0f` (loss_util.py:196 on channel 0, like
+ *                ssl_cuda's mask[0,0], loss_util.py:233);
+ *            1 = uint8 mask, same layout, `!= 0`;
+ *            2 = no mask tensor: `mask` is the fp32 GT batch (B,3,H,W) in
+ *                [0,1] and the reference's offline mask is generated on the
+ *                fly: u8 = round(255 x), L = PIL 'L' (ITU-R 601-2 16.16 fixed
+ *                point), 4-neighbour Laplacian with BORDER_REFLECT_101
+ *                saturated to uint8, `> lap_threshold` (generate_mask.py:22-31).
+ * mask_stride > 1 additionally keeps only y % s == x % s
+ * (realesrganssl_model.py:64-72).
+ *
+ * Outputs: edges  (capacity,3) int32 rows (b,y,x) in UNPADDED coordinates,
+ *                 ordered by image then row-major -- the order of
+ *                 torch.cat([...], dim=1) over torch.where;
+ *          counts (B+2) int32: counts[0] = total N (NOT clamped to capacity;
+ *                 N > capacity means overflow: re-run with a larger list),
+ *                 counts[1+b] = first row of image b, counts[1+B] = N.
+ * scratch: ssg_edge_scratch_bytes(B,H,W) bytes of device memory. */
+size_t ssg_edge_scratch_bytes(int B, int H, int W);
+int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
+                  int H, int W, int mask_stride, float lap_threshold,
+                  int *edges, int capacity, int *counts, void *scratch,
+                  ssg_stream_t stream);
+
+/* The mask itself (B,H,W) uint8 {0,1} from an fp32 GT batch (B,3,H,W):
+ * mask_kind 2 above materialised (offline tool generate_mask.py). */
+int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W,
+                            float lap_threshold, int mask_stride,
+                            uint8_t *mask_out, ssg_stream_t stream);
+
+/* ---------------------------------------------------------------- (C) ----
+ * similarity_map forward for a batch of UNPADDED images (B,C,H,W) (reflect
+ * padding is done by index mirroring, nothing is materialised):
+ *   D  = patch distances, q = D/(C*k_w^2), e = exp(-1*q/sigma),
+ *   s  = generalization ? 1/(sum_p e + eps) * e : e        (loss_util.py:224-227)
+ * `edges` as produced by ssg_edge_list; n_edges_dev (nullable) points at the
+ * device-side row count (counts[0]); at most n_rows rows are computed (the
+ * host-known bound used to size the launch and `ssg`).  ssg is (n_rows,
+ * k_s*k_s) fp32, row n <-> edges[n].  If img2/ssg2 are non-null the same
+ * edge list is evaluated on a second batch in the same launch (SR and GT). */
+int ssg_map_forward(const float *img, const float *img2, int B, int C, int H,
+                    int W, const int *edges, const int *n_edges_dev, int n_rows,
+                    int ks, int kw, float sigma, float eps, int generalization,
+                    float *ssg, float *ssg2, ssg_stream_t stream);
+
+/* Backward of the above: grad_img (B,C,H,W) += d/d img of sum(grad_ssg * ssg)
+ * (reflect fold included).  `ssg` is the forward output (saved). */
+int ssg_map_backward(const float *img, int B, int C, int H, int W,
+                     const int *edges, const int *n_edges_dev, int n_rows,
+                     int ks, int kw, float sigma, int generalization,
+                     const float *ssg, const float *grad_ssg, float *grad_img,
+                     ssg_stream_t stream);
+
+/* ---------------------------------------------------------------- (D) ----
+ * The whole loss step of the caller loop over a batch:
+ *   l1 = w_l1 * mean |s_sr - s_gt|,  kl = w_kl * mean t'(log t' - log s')
+ * with the mean over M = N * k_s^2 elements of the LOCAL batch (images with
+ * an empty mask contribute nothing; N == 0 gives 0,0 like ddpmssl.py:492),
+ * and grad_sr (B,C,H,W) += d(l1+kl)/d sr.
+ *
+ * ssg_loss_backward consumes SSGs already computed by ssg_map_forward
+ * (API-compatible mode: SSG tensors are materialised once each).  `upstream`
+ * (nullable) points at two DEVICE floats {dL/dl1, dL/dkl} that scale the two
+ * criteria's gradients (autograd's incoming gradients, read on device so the
+ * host never synchronises); null means {1,1}.
+ * loss_out: 2 floats {l1, kl} on device.  scratch: ssg_loss_scratch_bytes(n_rows). */
+size_t ssg_loss_scratch_bytes(int n_rows, int ks);
+int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
+                      const int *edges, const int *n_edges_dev, int n_rows,
+                      int ks, int kw, float sigma, int generalization,
+                      const float *ssg_sr, const float *ssg_gt, float w_l1,
+                      float w_kl, const float *upstream /* nullable */,
+                      float *loss_out, float *grad_sr /* nullable */,
+                      void *scratch, ssg_stream_t stream);
+
+/* Everything in one call: edge list (from a mask or from GT's Laplacian),
+ * SSG(sr), SSG(gt), both criteria and the gradient.  ssg_sr / ssg_gt
+ * (capacity, k_s*k_s) receive the SSG tensors; `counts` as in ssg_edge_list;
+ * workspace >= ssg_loss_workspace_bytes(B,H,W,capacity,ks). */
+size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks);
+int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask,
+                     int mask_kind, int mask_channels, int B, int C, int H,
+                     int W, int ks, int kw, float sigma, float eps,
+                     int generalization, float w_l1, float w_kl, int mask_stride,
+                     float lap_threshold, int capacity, float *ssg_sr,
+                     float *ssg_gt, int *counts, float *loss_out, float *grad_sr,
+                     void *workspace, size_t workspace_bytes, ssg_stream_t stream);
+
+/* Host helper for profiling builds: name of the HIP kernel a configuration
+ * dispatches to ("ssg_fwd<25,9,5>", "ssg_fwd_generic", ...). */
+const char *ssg_kernel_name(int ks, int kw, int backward);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSG_HIP_H */

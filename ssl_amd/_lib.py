@@ -1,0 +1,73 @@
+"""ctypes binding of libssg_hip.so (include/ssg_hip.h).
+
+The shared library is built in-tree by ``ssl_amd._lib.build()`` (hipcc,
+--offload-arch=gfx950; cross-compiles without a GPU) and travels with the
+source tree.  There is NO fallback: if the library is missing or a symbol is
+absent, importing the compute path raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libssg_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "ssg_hip.h")
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ssg_hip.h one to one
+PROTOTYPES = {
+    "ssg_abi_version": (_i, []),
+    "ssg_status_string": (ctypes.c_char_p, [_i]),
+    "ssg_compute_similarity": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ssg_compute_similarity_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ssg_edge_scratch_bytes": (_sz, [_i, _i, _i]),
+    "ssg_edge_list": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),
+    "ssg_edge_mask_laplacian": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "ssg_map_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "ssg_map_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "ssg_loss_scratch_bytes": (_sz, [_i, _i]),
+    "ssg_loss_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _f, _f, _vp, _vp, _vp,
+                               _vp, _vp]),
+    "ssg_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ssg_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssg_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
+}
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into csrc/libssg_hip.so."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode:
+        print(out.stdout)
+    if out.returncode:
+        raise RuntimeError("building libssg_hip.so failed (see output above)")
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library with typed prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C ssl_amd/csrc`).  ssl_amd has no CPU / PyTorch fallback for the SSG kernels.")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is absent: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError(f"libssg_hip: {lib().ssg_status_string(status).decode()} (status {status})")

@@ -1,0 +1,244 @@
+// C ABI of the gfx950 SSG engine: argument checking, workspace carving and
+// kernel dispatch.  See include/ssg_hip.h for the contract of every entry point
+// and the reference interface it replaces.
+#include "../../include/ssg_hip.h"
+
+#include "ssg_common.hpp"
+
+namespace ssg {
+int launch_fwd(const FwdParams &p, hipStream_t st);
+int launch_bwd(const BwdParams &p, hipStream_t st);
+unsigned bwd_grid(int ks, int kw, int n);
+int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
+                         float w_kl, float *loss_out, hipStream_t st);
+const char *fwd_kernel_name(int ks, int kw);
+const char *bwd_kernel_name(int ks, int kw);
+size_t edge_scratch_bytes(int B, int H, int W);
+int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
+                     int *edges, int capacity, int *counts, void *scratch, hipStream_t st);
+int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride, uint8_t *out, hipStream_t st);
+}  // namespace ssg
+
+using namespace ssg;
+
+static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (kw & 1); }
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" {
+
+int ssg_abi_version(void) { return 1; }
+
+const char *ssg_status_string(int status) {
+  switch (status) {
+    case 0: return "ok";
+    case SSG_E_BADARG: return "ssg: bad argument (null pointer, even/non-positive kernel size, bad kind)";
+    case SSG_E_TOOLARGE: return "ssg: search tile does not fit the 160 KiB LDS of a CU";
+    case SSG_E_WORKSPACE: return "ssg: workspace too small";
+    case SSG_E_IMAGESMALL: return "ssg: image side <= k_s/2, reflect padding undefined";
+    default: return status > 0 ? hipGetErrorString((hipError_t)status) : "ssg: unknown status";
+  }
+}
+
+int ssg_compute_similarity(const float *image, const int *pos, float *out, int mc, int psize, int ksize, int height,
+                           int width, int channel, ssg_stream_t stream) {
+  if (mc < 0 || !sizes_ok(psize, ksize) || channel <= 0 || height <= 0 || width <= 0) return SSG_E_BADARG;
+  if (mc == 0) return 0;
+  if (!image || !pos || !out) return SSG_E_BADARG;
+  FwdParams p{};
+  p.img[0] = image;
+  p.out[0] = out;
+  p.nimg = 1;
+  p.edges = pos;
+  p.estride = 2;
+  p.n_dev = nullptr;
+  p.n_host = mc;
+  p.B = 1;
+  p.C = channel;
+  p.H = height;
+  p.W = width;
+  p.sigma = 1.f;
+  p.eps = 0.f;
+  p.generalization = 0;
+  p.raw = 1;
+  p.ks = psize;
+  p.kw = ksize;
+  return launch_fwd(p, (hipStream_t)stream);
+}
+
+int ssg_compute_similarity_backward(const float *image, const float *grads, const int *pos, float *image_grads,
+                                    int mc, int psize, int ksize, int height, int width, int channel,
+                                    ssg_stream_t stream) {
+  if (mc < 0 || !sizes_ok(psize, ksize) || channel <= 0 || height <= 0 || width <= 0) return SSG_E_BADARG;
+  if (mc == 0) return 0;
+  if (!image || !grads || !pos || !image_grads) return SSG_E_BADARG;
+  BwdParams p{};
+  p.img = image;
+  p.grad = image_grads;
+  p.edges = pos;
+  p.estride = 2;
+  p.n_dev = nullptr;
+  p.n_host = mc;
+  p.B = 1;
+  p.C = channel;
+  p.H = height;
+  p.W = width;
+  p.mode = GRAD_D;
+  p.gin = grads;
+  p.sigma = 1.f;
+  p.ks = psize;
+  p.kw = ksize;
+  return launch_bwd(p, (hipStream_t)stream);
+}
+
+size_t ssg_edge_scratch_bytes(int B, int H, int W) { return edge_scratch_bytes(B, H, W); }
+
+int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
+                  float lap_threshold, int *edges, int capacity, int *counts, void *scratch, ssg_stream_t stream) {
+  if (!mask || !edges || !counts || !scratch || B <= 0 || H <= 0 || W <= 0 || capacity < 0 || mask_kind < 0 ||
+      mask_kind > 2 || mask_channels <= 0)
+    return SSG_E_BADARG;
+  return launch_edge_list(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, edges, capacity,
+                          counts, scratch, (hipStream_t)stream);
+}
+
+int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_threshold, int mask_stride,
+                            uint8_t *mask_out, ssg_stream_t stream) {
+  if (!gt || !mask_out || B <= 0 || H <= 0 || W <= 0) return SSG_E_BADARG;
+  return launch_edge_mask(gt, B, H, W, lap_threshold, mask_stride, mask_out, (hipStream_t)stream);
+}
+
+int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, int W, const int *edges,
+                    const int *n_edges_dev, int n_rows, int ks, int kw, float sigma, float eps, int generalization,
+                    float *ssg, float *ssg2, ssg_stream_t stream) {
+  if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
+  if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
+  if (n_rows == 0) return 0;
+  if (!img || !edges || !ssg || ((img2 != nullptr) != (ssg2 != nullptr))) return SSG_E_BADARG;
+  FwdParams p{};
+  p.img[0] = img;
+  p.img[1] = img2;
+  p.out[0] = ssg;
+  p.out[1] = ssg2;
+  p.nimg = img2 ? 2 : 1;
+  p.edges = edges;
+  p.estride = 3;
+  p.n_dev = n_edges_dev;
+  p.n_host = n_rows;
+  p.B = B;
+  p.C = C;
+  p.H = H;
+  p.W = W;
+  p.sigma = sigma;
+  p.eps = eps;
+  p.generalization = generalization;
+  p.raw = 0;
+  p.ks = ks;
+  p.kw = kw;
+  return launch_fwd(p, (hipStream_t)stream);
+}
+
+int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *edges, const int *n_edges_dev,
+                     int n_rows, int ks, int kw, float sigma, int generalization, const float *ssg,
+                     const float *grad_ssg, float *grad_img, ssg_stream_t stream) {
+  if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
+  if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
+  if (n_rows == 0) return 0;
+  if (!img || !edges || !ssg || !grad_ssg || !grad_img) return SSG_E_BADARG;
+  BwdParams p{};
+  p.img = img;
+  p.grad = grad_img;
+  p.edges = edges;
+  p.estride = 3;
+  p.n_dev = n_edges_dev;
+  p.n_host = n_rows;
+  p.B = B;
+  p.C = C;
+  p.H = H;
+  p.W = W;
+  p.mode = GRAD_S;
+  p.gin = grad_ssg;
+  p.ssg = ssg;
+  p.sigma = sigma;
+  p.generalization = generalization;
+  p.ks = ks;
+  p.kw = kw;
+  return launch_bwd(p, (hipStream_t)stream);
+}
+
+size_t ssg_loss_scratch_bytes(int n_rows, int ks) {
+  (void)ks;
+  return 2 * sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1) + 64;
+}
+
+int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *n_edges_dev,
+                      int n_rows, int ks, int kw, float sigma, int generalization, const float *ssg_sr,
+                      const float *ssg_gt, float w_l1, float w_kl, const float *upstream, float *loss_out,
+                      float *grad_sr, void *scratch, ssg_stream_t stream) {
+  if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
+  if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rows == 0) return (int)hipMemsetAsync(loss_out, 0, 2 * sizeof(float), st);
+  if (!sr || !edges || !ssg_sr || !ssg_gt || !scratch) return SSG_E_BADARG;
+  BwdParams p{};
+  p.img = sr;
+  p.grad = grad_sr;
+  p.edges = edges;
+  p.estride = 3;
+  p.n_dev = n_edges_dev;
+  p.n_host = n_rows;
+  p.B = B;
+  p.C = C;
+  p.H = H;
+  p.W = W;
+  p.mode = GRAD_LOSS;
+  p.ssg = ssg_sr;
+  p.ssg2 = ssg_gt;
+  p.sigma = sigma;
+  p.generalization = generalization;
+  p.w_l1 = w_l1;
+  p.w_kl = w_kl;
+  p.partials = (float *)scratch;
+  p.upstream = upstream;
+  p.ks = ks;
+  p.kw = kw;
+  int rc = launch_bwd(p, st);
+  if (rc) return rc;
+  return launch_loss_finalize(p.partials, (int)bwd_grid(ks, kw, n_rows), n_edges_dev, n_rows, ks * ks, w_l1, w_kl,
+                              loss_out, st);
+}
+
+size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
+  return align_up(sizeof(int) * 3 * (size_t)(capacity > 0 ? capacity : 1), 256) +
+         align_up(edge_scratch_bytes(B, H, W), 256) + align_up(ssg_loss_scratch_bytes(capacity, ks), 256);
+}
+
+int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,
+                     int C, int H, int W, int ks, int kw, float sigma, float eps, int generalization, float w_l1,
+                     float w_kl, int mask_stride, float lap_threshold, int capacity, float *ssg_sr, float *ssg_gt,
+                     int *counts, float *loss_out, float *grad_sr, void *workspace, size_t workspace_bytes,
+                     ssg_stream_t stream) {
+  if (!sr || !gt || !ssg_sr || !ssg_gt || !counts || !loss_out || !workspace || capacity <= 0) return SSG_E_BADARG;
+  if (mask_kind != 2 && !mask) return SSG_E_BADARG;
+  if (workspace_bytes < ssg_loss_workspace_bytes(B, H, W, capacity, ks)) return SSG_E_WORKSPACE;
+  char *ws = (char *)workspace;
+  int *edges = (int *)ws;
+  ws += align_up(sizeof(int) * 3 * (size_t)capacity, 256);
+  void *escratch = ws;
+  ws += align_up(edge_scratch_bytes(B, H, W), 256);
+  void *lscratch = ws;
+  int rc = ssg_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
+                         W, mask_stride, lap_threshold, edges, capacity, counts, escratch, stream);
+  if (rc) return rc;
+  rc = ssg_map_forward(sr, gt, B, C, H, W, edges, counts, capacity, ks, kw, sigma, eps, generalization, ssg_sr,
+                       ssg_gt, stream);
+  if (rc) return rc;
+  return ssg_loss_backward(sr, B, C, H, W, edges, counts, capacity, ks, kw, sigma, generalization, ssg_sr, ssg_gt,
+                           w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);
+}
+
+const char *ssg_kernel_name(int ks, int kw, int backward) {
+  return backward ? bwd_kernel_name(ks, kw) : fwd_kernel_name(ks, kw);
+}
+
+}  // extern "C"

@@ -1,0 +1,567 @@
+// Backward SSG kernels for gfx950: dL/dimg from G = dL/dD, per edge pixel on
+// chip, one fp32 atomic per touched image pixel (the reference issues
+// ~2*C*k_w^2 global atomics per (edge pixel, search offset), similarity.cu:123-128).
+//
+// For one edge pixel with centre window A (k_w x k_w) and search tile S (k_s x k_s)
+// the reference's scatter is algebraically
+//   gS[c,t] = -2 ( sum_k Gz[t-k] A[c,k]  -  S[c,t] * sum_k Gz[t-k] )      t in tile
+//   gA[c,k] =  2 ( A[c,k] * sum_p G[p]   -  sum_t Gz[t-k] S[c,t] )        k in window
+// (Gz = G zero-extended outside the k_s x k_s offsets; the out-of-area rule
+// "B = 0" contributes exactly the A*sum G part).  Both sums are correlations
+// of the k_s x k_s G tile with a k_w x k_w stencil and reuse the forward's
+// decomposition: a lane owns a BS x BS block of tile positions t and streams the
+// (BS+k_w-1)^2 patch of Gz it needs from LDS row by row (ssg_common.hpp).
+//   pass A: acc[t]  += Gz[t+k'] * Aflip[c,k']      (25 accumulators, A in registers)
+//   pass B: P[k']   += Gz[t+k'] * S[c,t]           (per-lane partials, reduced
+//           across the job's 25 lanes through an LDS slice in a fixed order)
+// G itself comes from one of three sources (GradMode): dL/dD directly (the
+// reference operator's backward), dL/dS + saved S (similarity_map autograd), or
+// S_sr/S_gt for the fused L1 + KL criteria, whose partial sums are also
+// produced here (L1Loss basic_loss.py:66, KLDistanceLoss basic_loss.py:281).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "ssg_common.hpp"
+
+namespace ssg {
+
+template <class G>
+__device__ __forceinline__ void load_grow(const float *tg, const float *zrow, int ry, int cx0,
+                                          const bool (&colv)[G::PW], float (&out)[G::PW]) {
+  const float *rowp = ((unsigned)ry < (unsigned)G::KS) ? (tg + ry * G::S) : zrow;
+#pragma unroll
+  for (int j = 0; j < G::PW; ++j) {
+    const float v = rowp[cx0 + j];
+    out[j] = colv[j] ? v : 0.f;
+  }
+}
+
+// dL/dS of the two criteria at one element (a = s_sr, b = s_gt), and the
+// criteria's un-normalised terms.
+__device__ __forceinline__ float criteria_elem(float a, float b, float w1m, float w2m, float &l1, float &kl) {
+  const float cl = 1e-10f;
+  const float ac = fmaxf(a, cl), bc = fmaxf(b, cl);
+  l1 += fabsf(a - b);
+  kl += bc * (logf(bc) - logf(ac));
+  float g = a > b ? w1m : (a < b ? -w1m : 0.f);
+  if (a >= cl) g -= w2m * bc / ac;
+  return g;
+}
+
+template <class G, int KHC>
+__global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
+  constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
+  constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
+  constexpr int JOBS = G::JOBS, PW = G::PW, S = G::S, CHG = G::CH;
+  constexpr int PADF = (HK + 3) & ~3;
+  constexpr int NCH = (KW + KHC - 1) / KHC;  // pass-B chunks of KHC stencil rows
+  constexpr int SL = KHC * KW;               // partials per chunk
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = p.C, H = p.H, W = p.W;
+  float *gt = smem + PADF;                    // [JOBS][KS][S]   G tiles
+  float *zero = gt + JOBS * CHG;              // zero row
+  float *red = zero + ((G::ZROW + 3) & ~3);   // [JOBS][SL][LPJ] pass-B slice
+  float *red2 = red + JOBS * SL * LPJ;        // [WG] scalar reductions
+  float *jsc = red2 + WG;                     // [JOBS][4]: dot, sumG
+  int *sh_edge = (int *)(jsc + JOBS * 4);     // [JOBS][4]
+  float *at = (float *)(sh_edge + JOBS * 4);  // [JOBS][C][KW][KW] centre windows
+
+  const int tid = threadIdx.x;
+  const int nrows = rows_to_do(p.n_dev, p.n_host);
+  const int job0 = blockIdx.x * JOBS;
+  if (job0 >= nrows) {
+    if (p.mode == GRAD_LOSS && tid == 0) {
+      p.partials[2 * blockIdx.x] = 0.f;
+      p.partials[2 * blockIdx.x + 1] = 0.f;
+    }
+    return;
+  }
+
+  if (tid < JOBS) {
+    const int q = job0 + tid;
+    const bool v = q < nrows;
+    Edge e = load_edge(p.edges, p.estride, v ? q : 0);
+    sh_edge[tid * 4 + 0] = e.b;
+    sh_edge[tid * 4 + 1] = e.y;
+    sh_edge[tid * 4 + 2] = e.x;
+    sh_edge[tid * 4 + 3] = v ? 1 : 0;
+  }
+  for (int i = tid; i < G::ZROW + 4; i += WG) zero[i] = 0.f;
+  if (tid < PADF) smem[tid] = 0.f;
+
+  int jl = tid / LPJ;
+  const int m = tid - jl * LPJ;
+  const bool lane_on = jl < JOBS;
+  if (!lane_on) jl = 0;
+  const int n = job0 + jl;
+  const bool job_on = lane_on && n < nrows;
+  __syncthreads();
+
+  // ---- stage 1: G tile of each job ----
+  float *tg = gt + jl * CHG;
+  const float kfac = 1.f / (p.sigma * (float)(C * KW * KW));
+  float l1p = 0.f, klp = 0.f;
+  {
+    const size_t base = (size_t)(job_on ? n : 0) * P;
+    float dot = 0.f;
+    if (p.mode == GRAD_D) {
+      if (lane_on)
+        for (int e = m; e < P; e += LPJ) {
+          const int py = e / KS, px = e - py * KS;
+          tg[py * S + px] = job_on ? p.gin[base + e] : 0.f;
+        }
+    } else {
+      const float invM = 1.f / ((float)nrows * (float)P);
+      const float u1 = p.upstream ? p.upstream[0] : 1.f, u2 = p.upstream ? p.upstream[1] : 1.f;
+      const float w1m = p.w_l1 * invM * u1, w2m = p.w_kl * invM * u2;
+      if (lane_on)
+        for (int e = m; e < P; e += LPJ) {
+          const int py = e / KS, px = e - py * KS;
+          float g = 0.f;
+          if (job_on) {
+            const float s = p.ssg[base + e];
+            g = p.mode == GRAD_S ? p.gin[base + e] : criteria_elem(s, p.ssg2[base + e], w1m, w2m, l1p, klp);
+            dot = __builtin_fmaf(g, s, dot);
+          }
+          tg[py * S + px] = g;
+        }
+      red2[tid] = dot;
+      __syncthreads();
+      if (tid < JOBS) {
+        float t = 0.f;
+        for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
+        jsc[tid * 4 + 0] = p.generalization ? t : 0.f;
+      }
+      __syncthreads();
+      dot = jsc[jl * 4 + 0];
+      if (lane_on)
+        for (int e = m; e < P; e += LPJ) {
+          const int py = e / KS, px = e - py * KS;
+          const float s = job_on ? p.ssg[base + e] : 0.f;
+          tg[py * S + px] = -(s * kfac) * (tg[py * S + px] - dot);
+        }
+    }
+  }
+  if (p.mode == GRAD_LOSS) {  // criteria partial sums of this workgroup
+    __syncthreads();
+    red2[tid] = l1p;
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+    if (tid == 0)
+      for (int k = 0; k < WG; ++k) t1 += red2[k];
+    __syncthreads();
+    red2[tid] = klp;
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 0; k < WG; ++k) t2 += red2[k];
+      p.partials[2 * blockIdx.x] = t1;
+      p.partials[2 * blockIdx.x + 1] = t2;
+    }
+    if (p.grad == nullptr) return;
+  }
+  // centre windows A (reflect by index mirroring)
+  for (int j = 0; j < JOBS; ++j) {
+    const int b = sh_edge[j * 4 + 0], y = sh_edge[j * 4 + 1], x = sh_edge[j * 4 + 2];
+    for (int e = tid; e < C * KW * KW; e += WG) {
+      const int c = e / (KW * KW), r = e - c * KW * KW, kh = r / KW, kx = r - kh * KW;
+      at[(j * C) * KW * KW + e] =
+          p.img[(((size_t)b * C + c) * H + reflect_idx(y - HK + kh, H)) * W + reflect_idx(x - HK + kx, W)];
+    }
+  }
+  __syncthreads();
+  {  // sum_p G per job
+    float ls = 0.f;
+    if (lane_on)
+      for (int e = m; e < P; e += LPJ) {
+        const int py = e / KS;
+        ls += tg[py * S + (e - py * KS)];
+      }
+    red2[tid] = ls;
+    __syncthreads();
+    if (tid < JOBS) {
+      float t = 0.f;
+      for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
+      jsc[tid * 4 + 1] = t;
+    }
+    __syncthreads();
+  }
+  const float sumG = jsc[jl * 4 + 1];
+
+  // ---- per-lane block of tile positions ----
+  const int by = m / NB, bx = m - by * NB;
+  const int ry0 = BS * by - HK, cx0 = BS * bx - HK;
+  bool colv[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) colv[j] = (unsigned)(cx0 + j) < (unsigned)KS;
+  const float *zrow = zero + HK;
+  const int eb = sh_edge[jl * 4 + 0], ey = sh_edge[jl * 4 + 1], ex = sh_edge[jl * 4 + 2];
+
+  // window sum of Gz around every owned t (channel independent)
+  float box[BS][BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i)
+#pragma unroll
+    for (int j = 0; j < BS; ++j) box[i][j] = 0.f;
+  {
+    float bn[PW];
+    load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
+#pragma unroll
+    for (int r = 0; r < PW; ++r) {
+      float bv[PW];
+#pragma unroll
+      for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+      if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
+      float hs[BS];  // horizontal k_w-tap sums of this patch row
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) t += bv[j + kx];
+        hs[j] = t;
+      }
+#pragma unroll
+      for (int i = 0; i < BS; ++i) {
+        const int kh = r - i;
+        if (kh < 0 || kh >= KW) continue;
+#pragma unroll
+        for (int j = 0; j < BS; ++j) box[i][j] += hs[j];
+      }
+      pin_block<BS, BS>(box);
+    }
+  }
+
+#pragma unroll 1
+  for (int c = 0; c < C; ++c) {
+    const size_t cbase = ((size_t)eb * C + c) * H * W;
+    // image offset of tile position (i,j) of the owned block, -1 when it takes no gradient
+    // (`fence` is an opaque zero: it pins the address arithmetic and the loads that use
+    // it BELOW the asm that produced it, so hipcc cannot hoist 50 VGPRs of offsets and
+    // image values above the unrolled passes)
+    auto tile_off = [&](int i, int j, int fence) -> int {
+      const int ty = BS * by + i, tx = BS * bx + j;
+      const bool in = ty < KS && tx < KS && job_on;
+      const int o = reflect_idx(ey + fence - HP + (ty < KS ? ty : 0), H) * W +
+                    reflect_idx(ex - HP + (tx < KS ? tx : 0), W);
+      return in ? o : -1;
+    };
+    const float *ac = at + (jl * C + c) * KW * KW;
+
+    // ---- pass A: acc[t] = sum_k' Gz[t+k'] * A[c,-k'] ----
+    {
+      float acc[BS][BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) acc[i][j] = 0.f;
+      if constexpr (KW <= 9) {
+        float af[KW][KW];
+#pragma unroll
+        for (int kh = 0; kh < KW; ++kh)
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) af[kh][kx] = ac[(KW - 1 - kh) * KW + (KW - 1 - kx)];
+        float bn[PW];
+        load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
+#pragma unroll
+        for (int r = 0; r < PW; ++r) {
+          float bv[PW];
+#pragma unroll
+          for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+          if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const int kh = r - i;
+            if (kh < 0 || kh >= KW) continue;
+#pragma unroll
+            for (int j = 0; j < BS; ++j)
+#pragma unroll
+              for (int kx = 0; kx < KW; ++kx) acc[i][j] = __builtin_fmaf(af[kh][kx], bv[j + kx], acc[i][j]);
+          }
+          pin_block<BS, BS>(acc);
+        }
+      } else {
+#pragma unroll 1
+        for (int r = 0; r < PW; ++r) {
+          float bv[PW];
+          load_grow<G>(tg, zrow, ry0 + r, cx0, colv, bv);
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const int kh = r - i;
+            if (kh < 0 || kh >= KW) continue;
+            const float *ar = ac + (KW - 1 - kh) * KW;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+              const float av = ar[KW - 1 - kx];
+#pragma unroll
+              for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(av, bv[j + kx], acc[i][j]);
+            }
+          }
+        }
+      }
+      int fa = 0;
+      asm volatile("" : "+v"(fa)::"memory");
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int o = tile_off(i, j, fa);
+          if (o >= 0) unsafeAtomicAdd(p.grad + cbase + o, -2.f * (acc[i][j] - p.img[cbase + o] * box[i][j]));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int fb = 0;
+    asm volatile("" : "+v"(fb)::"memory");
+    // S[c,t] of the owned block (pass B's multiplier); loaded only now to keep pass A's
+    // register footprint at acc + stencil + two patch rows + box
+    float sv[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int o = tile_off(i, j, fb);
+        sv[i][j] = o >= 0 ? p.img[cbase + o] : 0.f;
+      }
+
+    // ---- pass B: P[k'] = sum_t Gz[t+k'] * S[c,t], KHC stencil rows at a time ----
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int kh0 = ch * KHC;
+      float pp[KHC][KW];
+#pragma unroll
+      for (int a = 0; a < KHC; ++a)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) pp[a][kx] = 0.f;
+      // patch rows r = kh' + i, kh' in [kh0, kh0+KHC), i in [0,BS)
+      float bn[PW];
+      load_grow<G>(tg, zrow, ry0 + kh0, cx0, colv, bn);
+#pragma unroll
+      for (int rr = 0; rr < KHC + BS - 1; ++rr) {
+        float bv[PW];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+        if (rr + 1 < KHC + BS - 1) load_grow<G>(tg, zrow, ry0 + kh0 + rr + 1, cx0, colv, bn);
+#pragma unroll
+        for (int a = 0; a < KHC; ++a) {
+          const int i = rr - a;  // block row paired with stencil row kh0+a on this patch row
+          if (i < 0 || i >= BS) continue;
+#pragma unroll
+          for (int j = 0; j < BS; ++j)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) pp[a][kx] = __builtin_fmaf(bv[j + kx], sv[i][j], pp[a][kx]);
+        }
+        pin_block<KHC, KW>(pp);
+      }
+      // reduce the slice across the job's lanes (fixed order)
+      if (lane_on) {
+#pragma unroll
+        for (int a = 0; a < KHC; ++a)
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) red[(jl * SL + a * KW + kx) * LPJ + m] = pp[a][kx];
+      }
+      __syncthreads();
+      if (job_on)
+        for (int o = m; o < SL; o += LPJ) {
+          const int a = o / KW, kxp = o - a * KW, khp = kh0 + a;
+          if (khp < KW) {
+            const float *rp = red + (jl * SL + o) * LPJ;
+            float t = 0.f;
+            for (int k = 0; k < LPJ; ++k) t += rp[k];
+            const int kh = KW - 1 - khp, kx = KW - 1 - kxp;  // k = -k'
+            const float av = ac[kh * KW + kx];
+            const int o2 = reflect_idx(ey - HK + kh, H) * W + reflect_idx(ex - HK + kx, W);
+            unsafeAtomicAdd(p.grad + cbase + o2, 2.f * (av * sumG - t));
+          }
+        }
+      __syncthreads();
+    }
+  }
+}
+
+// Any odd (ks, kw): one 256-lane workgroup per edge pixel.
+__global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ks = p.ks, kw = p.kw, hp = ks / 2, hk = kw / 2, P = ks * ks, K2 = kw * kw;
+  const int C = p.C, H = p.H, W = p.W, tid = threadIdx.x;
+  float *gt = smem;          // [P]
+  float *tile = gt + P;      // [C][P]
+  float *red = tile + C * P; // [256]
+  const int nrows = rows_to_do(p.n_dev, p.n_host);
+  const int n = blockIdx.x;
+  if (n >= nrows) {
+    if (p.mode == GRAD_LOSS && tid == 0) {
+      p.partials[2 * n] = 0.f;
+      p.partials[2 * n + 1] = 0.f;
+    }
+    return;
+  }
+  const Edge e = load_edge(p.edges, p.estride, n);
+  const size_t base = (size_t)n * P;
+  const float kfac = 1.f / (p.sigma * (float)(C * K2));
+  float l1p = 0.f, klp = 0.f;
+  if (p.mode == GRAD_D) {
+    for (int i = tid; i < P; i += 256) gt[i] = p.gin[base + i];
+  } else {
+    const float invM = 1.f / ((float)nrows * (float)P);
+    const float u1 = p.upstream ? p.upstream[0] : 1.f, u2 = p.upstream ? p.upstream[1] : 1.f;
+    const float w1m = p.w_l1 * invM * u1, w2m = p.w_kl * invM * u2;
+    float dot = 0.f;
+    for (int i = tid; i < P; i += 256) {
+      const float s = p.ssg[base + i];
+      const float g = p.mode == GRAD_S ? p.gin[base + i] : criteria_elem(s, p.ssg2[base + i], w1m, w2m, l1p, klp);
+      dot = __builtin_fmaf(g, s, dot);
+      gt[i] = g;
+    }
+    red[tid] = dot;
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < 256; ++k) t += red[k];
+    if (!p.generalization) t = 0.f;
+    __syncthreads();
+    for (int i = tid; i < P; i += 256) gt[i] = -(p.ssg[base + i] * kfac) * (gt[i] - t);
+    if (p.mode == GRAD_LOSS) {
+      red[tid] = l1p;
+      __syncthreads();
+      float t1 = 0.f, t2 = 0.f;
+      if (tid == 0)
+        for (int k = 0; k < 256; ++k) t1 += red[k];
+      __syncthreads();
+      red[tid] = klp;
+      __syncthreads();
+      if (tid == 0) {
+        for (int k = 0; k < 256; ++k) t2 += red[k];
+        p.partials[2 * n] = t1;
+        p.partials[2 * n + 1] = t2;
+      }
+      if (p.grad == nullptr) return;
+    }
+  }
+  const size_t ibase = (size_t)e.b * C * H * W;
+  for (int i = tid; i < C * P; i += 256) {
+    const int c = i / P, r = i - c * P, ry = r / ks, rx = r - ry * ks;
+    tile[i] = p.img[ibase + ((size_t)c * H + reflect_idx(e.y - hp + ry, H)) * W + reflect_idx(e.x - hp + rx, W)];
+  }
+  __syncthreads();
+  float ls = 0.f;
+  for (int i = tid; i < P; i += 256) ls += gt[i];
+  red[tid] = ls;
+  __syncthreads();
+  float sumG = 0.f;
+  for (int k = 0; k < 256; ++k) sumG += red[k];
+  // tile positions: gS[c,t] = -2 sum_k Gz[t-k] (A[c,k] - S[c,t])
+  for (int i = tid; i < C * P; i += 256) {
+    const int c = i / P, r = i - c * P, ty = r / ks, tx = r - ty * ks;
+    const float st = tile[i];
+    float acc = 0.f;
+    for (int kh = -hk; kh <= hk; ++kh)
+      for (int kx = -hk; kx <= hk; ++kx) {
+        const int py = ty - kh, px = tx - kx;
+        if ((unsigned)py < (unsigned)ks && (unsigned)px < (unsigned)ks)
+          acc = __builtin_fmaf(gt[py * ks + px], tile[(c * ks + hp + kh) * ks + hp + kx] - st, acc);
+      }
+    unsafeAtomicAdd(p.grad + ibase + ((size_t)c * H + reflect_idx(e.y - hp + ty, H)) * W + reflect_idx(e.x - hp + tx, W),
+                    -2.f * acc);
+  }
+  // window positions: gA[c,k] = 2 ( A sum G - sum_p G[p] Sz[c,p+k] )
+  for (int i = tid; i < C * K2; i += 256) {
+    const int c = i / K2, r = i - c * K2, kh = r / kw - hk, kx = r - (r / kw) * kw - hk;
+    const float a = tile[(c * ks + hp + kh) * ks + hp + kx];
+    float acc = 0.f;
+    for (int py = 0; py < ks; ++py) {
+      const int yy = py + kh;
+      if ((unsigned)yy >= (unsigned)ks) continue;
+      for (int px = 0; px < ks; ++px) {
+        const int xx = px + kx;
+        if ((unsigned)xx < (unsigned)ks) acc = __builtin_fmaf(gt[py * ks + px], tile[(c * ks + yy) * ks + xx], acc);
+      }
+    }
+    unsafeAtomicAdd(p.grad + ibase + ((size_t)c * H + reflect_idx(e.y + kh, H)) * W + reflect_idx(e.x + kx, W),
+                    2.f * (a * sumG - acc));
+  }
+}
+
+// loss_out[0] = w_l1 * sum|a-b| / M, loss_out[1] = w_kl * sum t'(log t' - log s') / M
+__global__ void ssg_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P,
+                                  float w_l1, float w_kl, float *loss_out) {
+  __shared__ double s1[256], s2[256];
+  double a = 0, b = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    a += (double)partials[2 * i];
+    b += (double)partials[2 * i + 1];
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = b = 0;
+    for (int k = 0; k < 256; ++k) {
+      a += s1[k];
+      b += s2[k];
+    }
+    const int nrows = rows_to_do(n_dev, n_host);
+    const double M = (double)nrows * (double)P;
+    loss_out[0] = nrows > 0 ? (float)((double)w_l1 * a / M) : 0.f;
+    loss_out[1] = nrows > 0 ? (float)((double)w_kl * b / M) : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ host ----
+template <class G, int KHC>
+static size_t bwd_lds_bytes(int C) {
+  constexpr int PADF = (G::HK + 3) & ~3;
+  return sizeof(float) * (size_t)(PADF + G::JOBS * G::CH + ((G::ZROW + 3) & ~3) + G::JOBS * KHC * G::KW * G::LPJ +
+                                  G::WG + G::JOBS * 4 + G::JOBS * C * G::KW * G::KW + 8) +
+         sizeof(int) * 4 * G::JOBS;
+}
+
+template <class G, int KHC>
+static int launch_bwd_tiled(const BwdParams &p, hipStream_t st, unsigned *grid_out) {
+  const size_t lds = bwd_lds_bytes<G, KHC>(p.C);
+  if (lds > 160 * 1024) return -2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)ssg_bwd_tiled<G, KHC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)((p.n_host + G::JOBS - 1) / G::JOBS);
+  if (grid_out) *grid_out = grid;
+  if (p.n_host == 0) return 0;
+  hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(grid), dim3(G::WG), lds, st, p);
+  return (int)hipGetLastError();
+}
+
+// Number of workgroups (= rows of `partials`) launch_bwd will use for n rows.
+unsigned bwd_grid(int ks, int kw, int n) {
+  if (ks == 25 && kw == 9) return (unsigned)((n + Geo<25, 9, 5, 128>::JOBS - 1) / Geo<25, 9, 5, 128>::JOBS);
+  if (ks == 11 && kw == 5) return (unsigned)((n + Geo<11, 5, 4, 64>::JOBS - 1) / Geo<11, 5, 4, 64>::JOBS);
+  return (unsigned)n;
+}
+
+int launch_bwd(const BwdParams &p, hipStream_t st) {
+  if (p.ks == 25 && p.kw == 9) return launch_bwd_tiled<Geo<25, 9, 5, 128>, 3>(p, st, nullptr);
+  if (p.ks == 11 && p.kw == 5) return launch_bwd_tiled<Geo<11, 5, 4, 64>, 5>(p, st, nullptr);
+  const size_t lds = sizeof(float) * ((size_t)(p.C + 1) * p.ks * p.ks + 256);
+  if (lds > 160 * 1024) return -2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)ssg_bwd_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (p.n_host == 0) return 0;
+  hipLaunchKernelGGL(ssg_bwd_generic, dim3((unsigned)p.n_host), dim3(256), lds, st, p);
+  return (int)hipGetLastError();
+}
+
+int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
+                         float w_kl, float *loss_out, hipStream_t st) {
+  hipLaunchKernelGGL(ssg_loss_finalize, dim3(1), dim3(256), 0, st, partials, nparts, n_dev, n_host, P, w_l1, w_kl,
+                     loss_out);
+  return (int)hipGetLastError();
+}
+
+const char *bwd_kernel_name(int ks, int kw) {
+  if (ks == 25 && kw == 9) return "ssg_bwd_tiled<Geo<25,9,5,128>,3>";
+  if (ks == 11 && kw == 5) return "ssg_bwd_tiled<Geo<11,5,4,64>,5>";
+  return "ssg_bwd_generic";
+}
+
+}  // namespace ssg

@@ -1,0 +1,148 @@
+// Shared device/host definitions of the gfx950 SSG engine (see include/ssg_hip.h).
+//
+// Work decomposition used by every tiled kernel ("job" = one edge pixel of one
+// image): the k_s x k_s grid of search offsets is cut into NB x NB blocks of
+// BS x BS offsets; one lane owns one block, so a job occupies LPJ = NB*NB lanes
+// and a workgroup of WG lanes carries JOBS = WG / LPJ jobs.  For the paper's
+// k_s = 25 that is 5x5 blocks of 5x5 offsets: 25 lanes per edge pixel, five
+// edge pixels per 128-lane workgroup (125/128 lanes busy).  A lane walks the
+// (BS+k_w-1)^2 input patch its block needs row by row; every LDS value it
+// loads feeds up to BS*k_w FMAs, which keeps the kernel on the fp32 VALU
+// roofline instead of LDS bandwidth (MI355X: 128 lane-ops vs 32 LDS dwords per
+// clock per CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ssg {
+
+// F.pad(mode='reflect') index map (border sample not duplicated).
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * n - 2 - i : i;
+}
+
+// cv2 BORDER_REFLECT_101 (identical map; kept separate for the n == 1 corner).
+__device__ __forceinline__ int reflect101_idx(int i, int n) {
+  if (n == 1) return 0;
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * n - 2 - i : i;
+}
+
+template <int KS_, int KW_, int BS_, int WG_>
+struct Geo {
+  static constexpr int KS = KS_, KW = KW_, BS = BS_, WG = WG_;
+  static constexpr int HP = KS / 2, HK = KW / 2;
+  static constexpr int P = KS * KS;
+  static constexpr int NB = (KS + BS - 1) / BS;  // blocks per side
+  static constexpr int LPJ = NB * NB;            // lanes per job
+  static constexpr int JOBS = WG / LPJ;          // jobs per workgroup
+  static constexpr int PW = BS + KW - 1;         // input patch side per lane
+  static constexpr int S = KS + 1;               // LDS row stride of a tile (floats)
+  static constexpr int CH = KS * S;              // LDS channel stride
+  static constexpr int ZROW = NB * BS + 2 * HK;  // length of the all-zero row
+  static_assert(JOBS >= 1, "workgroup too small for one job");
+  static_assert(KW <= KS && (KS & 1) && (KW & 1), "odd sizes, k_w <= k_s");
+};
+
+// Compiler fence for the fully unrolled row-streaming loops.  hipcc otherwise sinks
+// the arithmetic of every patch row below all rows' LDS loads (sched_barrier does not
+// order pure arithmetic), which keeps the whole (BS+k_w-1)^2 patch live and spills.
+// Passing every accumulator through an empty asm with a memory clobber pins row r's
+// FMAs above it and row r+2's loads below it, at zero instruction cost.
+template <int N>
+__device__ __forceinline__ void pin_row(float (&v)[N]) {
+  if constexpr (N == 3) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
+  } else if constexpr (N == 4) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+  } else if constexpr (N == 5) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");
+  } else if constexpr (N == 7) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6])::"memory");
+  } else if constexpr (N == 9) {
+    asm volatile(""
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                   "+v"(v[8])::"memory");
+  } else if constexpr (N == 13) {
+    asm volatile(""
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12])::"memory");
+  } else {
+    static_assert(N == 3, "add a pin_row arm for this width");
+  }
+}
+
+template <int R, int N>
+__device__ __forceinline__ void pin_block(float (&v)[R][N]) {
+#pragma unroll
+  for (int i = 0; i < R; ++i) pin_row<N>(v[i]);
+}
+
+struct Edge {
+  int b, y, x;
+};
+
+// edges rows are (b,y,x) (stride 3) or the reference op's (Y,X) (stride 2, b = 0).
+__device__ __forceinline__ Edge load_edge(const int *edges, int stride, int n) {
+  const int *e = edges + (size_t)n * stride;
+  Edge r;
+  r.b = stride == 3 ? e[0] : 0;
+  r.y = e[stride - 2];
+  r.x = e[stride - 1];
+  return r;
+}
+
+// Parameters shared by the forward kernels.
+struct FwdParams {
+  const float *img[2];  // (B,C,H,W) each; img[1] may be null
+  float *out[2];        // (n, KS*KS) each
+  int nimg;
+  const int *edges;
+  int estride;       // 3: (b,y,x)   2: (Y,X)
+  const int *n_dev;  // nullable device row count
+  int n_host;        // host bound on rows
+  int B, C, H, W;
+  float sigma, eps;
+  int generalization;
+  int raw;  // 1: out += D (reference operator)   0: SSG epilogue
+  int ks, kw;  // used by the generic kernel only
+};
+
+// How the backward kernel obtains G = dL/dD for a job.
+enum GradMode : int {
+  GRAD_D = 0,    // gin = dL/dD                       (reference operator backward)
+  GRAD_S = 1,    // gin = dL/dS, ssg = S saved         (similarity_map autograd)
+  GRAD_LOSS = 2  // ssg = S_sr, ssg2 = S_gt: L1 + KL   (fused loss)
+};
+
+struct BwdParams {
+  const float *img;  // (B,C,H,W)
+  float *grad;       // (B,C,H,W), accumulated with fp32 atomics (may be null in GRAD_LOSS: loss only)
+  const int *edges;
+  int estride;
+  const int *n_dev;
+  int n_host;
+  int B, C, H, W;
+  int mode;
+  const float *gin;   // GRAD_D / GRAD_S
+  const float *ssg;   // GRAD_S / GRAD_LOSS
+  const float *ssg2;  // GRAD_LOSS
+  float sigma;
+  int generalization;
+  float w_l1, w_kl;
+  const float *upstream;  // GRAD_LOSS, nullable: device {dL/dl1, dL/dkl}
+  float *partials;  // GRAD_LOSS: (gridDim.x, 2) per-workgroup sums of |a-b| and t'(log t' - log s')
+  int ks, kw;       // generic kernel only
+};
+
+__device__ __forceinline__ int rows_to_do(const int *n_dev, int n_host) {
+  int n = n_host;
+  if (n_dev) {
+    const int d = *n_dev;
+    n = d < n ? d : n;
+  }
+  return n;
+}
+
+}  // namespace ssg

@@ -1,0 +1,179 @@
+// Edge list of a batch, built on device (no host round trip): which pixels of
+// which images take part in the SSG loss, in the reference's order
+// (image-major, then row-major == torch.where / torch.nonzero,
+// loss_util.py:196, similaritywrapper.py:67), optionally generating the
+// reference's offline Laplacian edge mask on the fly (generate_mask.py:22-31)
+// and applying the mask_stride eye pattern (realesrganssl_model.py:64-72).
+//
+// Three small HBM-bound kernels: per-1024-pixel chunk counts, an exclusive scan
+// of the chunk counts (one workgroup), and an order-preserving scatter.
+#include "ssg_common.hpp"
+
+namespace ssg {
+
+struct EdgeParams {
+  const void *mask;
+  int kind;  // 0 fp32 mask, 1 uint8 mask, 2 fp32 GT (Laplacian)
+  int mask_channels;
+  int B, H, W;
+  int stride;
+  float thr;
+  int nblk_img;  // ceil(H*W / 1024)
+};
+
+constexpr int CHUNK = 1024;  // pixels per workgroup (256 lanes x 4 consecutive pixels)
+
+// PIL convert('L') of round(255 * rgb): ITU-R 601-2 in 16.16 fixed point.
+__device__ __forceinline__ int gray_l(const float *img, size_t plane, size_t off) {
+  const float r = fminf(fmaxf(img[off] * 255.f, 0.f), 255.f);
+  const float g = fminf(fmaxf(img[off + plane] * 255.f, 0.f), 255.f);
+  const float b = fminf(fmaxf(img[off + 2 * plane] * 255.f, 0.f), 255.f);
+  const unsigned ri = (unsigned)__float2int_rn(r), gi = (unsigned)__float2int_rn(g), bi = (unsigned)__float2int_rn(b);
+  return (int)((ri * 19595u + gi * 38470u + bi * 7471u + 0x8000u) >> 16);
+}
+
+__device__ __forceinline__ bool edge_pred(const EdgeParams &p, int b, int y, int x) {
+  if (p.stride > 1 && (y % p.stride) != (x % p.stride)) return false;
+  const size_t plane = (size_t)p.H * p.W;
+  if (p.kind == 0) {
+    return ((const float *)p.mask)[(size_t)b * p.mask_channels * plane + (size_t)y * p.W + x] == 1.0f;
+  } else if (p.kind == 1) {
+    return ((const uint8_t *)p.mask)[(size_t)b * p.mask_channels * plane + (size_t)y * p.W + x] != 0;
+  }
+  // cv2.Laplacian(L, CV_8U): [[0,1,0],[1,-4,1],[0,1,0]], BORDER_REFLECT_101, saturate
+  const float *img = (const float *)p.mask + (size_t)b * 3 * plane;
+  const int ym = reflect101_idx(y - 1, p.H), yp = reflect101_idx(y + 1, p.H);
+  const int xm = reflect101_idx(x - 1, p.W), xp = reflect101_idx(x + 1, p.W);
+  int v = gray_l(img, plane, (size_t)ym * p.W + x) + gray_l(img, plane, (size_t)yp * p.W + x) +
+          gray_l(img, plane, (size_t)y * p.W + xm) + gray_l(img, plane, (size_t)y * p.W + xp) -
+          4 * gray_l(img, plane, (size_t)y * p.W + x);
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  return (float)v > p.thr;
+}
+
+// bit k of the result: pixel 4*tid+k of this chunk is an edge pixel
+__device__ __forceinline__ unsigned chunk_bits(const EdgeParams &p, int &b, int &pix0) {
+  const int blk = blockIdx.x;
+  b = blk / p.nblk_img;
+  pix0 = (blk - b * p.nblk_img) * CHUNK + 4 * threadIdx.x;
+  unsigned bits = 0;
+  const int HW = p.H * p.W;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pix = pix0 + k;
+    if (pix < HW) {
+      const int y = pix / p.W, x = pix - y * p.W;
+      if (edge_pred(p, b, y, x)) bits |= 1u << k;
+    }
+  }
+  return bits;
+}
+
+__global__ __launch_bounds__(256) void edge_count(EdgeParams p, int *blockcnt) {
+  __shared__ int wsum[4];
+  int b, pix0;
+  const unsigned bits = chunk_bits(p, b, pix0);
+  int c = __popc(bits);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of blockcnt[0..nblk) -> blockoff, plus counts (B+2):
+// counts[0] = N, counts[1+b] = first row of image b, counts[1+B] = N.
+__global__ __launch_bounds__(1024) void edge_scan(const int *blockcnt, int *blockoff, int nblk, int nblk_img, int B,
+                                                  int *counts) {
+  __shared__ int buf[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + tid;
+    const int v = i < nblk ? blockcnt[i] : 0;
+    buf[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = tid >= o ? buf[tid - o] : 0;
+      __syncthreads();
+      buf[tid] += t;
+      __syncthreads();
+    }
+    const int excl = carry + buf[tid] - v;
+    if (i < nblk) {
+      blockoff[i] = excl;
+      if (i % nblk_img == 0) counts[1 + i / nblk_img] = excl;
+    }
+    __syncthreads();
+    if (tid == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    counts[0] = carry;
+    counts[1 + B] = carry;
+  }
+}
+
+__global__ __launch_bounds__(256) void edge_scatter(EdgeParams p, const int *blockoff, int *edges, int capacity) {
+  __shared__ int buf[256];
+  int b, pix0;
+  const unsigned bits = chunk_bits(p, b, pix0);
+  const int tid = threadIdx.x;
+  const int c = __popc(bits);
+  buf[tid] = c;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int t = tid >= o ? buf[tid - o] : 0;
+    __syncthreads();
+    buf[tid] += t;
+    __syncthreads();
+  }
+  int pos = blockoff[blockIdx.x] + buf[tid] - c;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (bits & (1u << k)) {
+      if (pos < capacity) {
+        const int pix = pix0 + k, y = pix / p.W;
+        edges[3 * (size_t)pos + 0] = b;
+        edges[3 * (size_t)pos + 1] = y;
+        edges[3 * (size_t)pos + 2] = pix - y * p.W;
+      }
+      ++pos;
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_mask_write(EdgeParams p, uint8_t *out) {
+  int b, pix0;
+  const unsigned bits = chunk_bits(p, b, pix0);
+  const int HW = p.H * p.W;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (pix0 + k < HW) out[(size_t)b * HW + pix0 + k] = (bits >> k) & 1u;
+}
+
+// ------------------------------------------------------------------ host ----
+size_t edge_scratch_bytes(int B, int H, int W) {
+  const size_t nblk = (size_t)B * (((size_t)H * W + CHUNK - 1) / CHUNK);
+  return 2 * nblk * sizeof(int) + 64;
+}
+
+int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
+                     int *edges, int capacity, int *counts, void *scratch, hipStream_t st) {
+  EdgeParams p{mask, kind, mask_channels, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
+  const int nblk = B * p.nblk_img;
+  int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;
+  hipLaunchKernelGGL(edge_count, dim3(nblk), dim3(256), 0, st, p, blockcnt);
+  hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts);
+  hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity);
+  return (int)hipGetLastError();
+}
+
+int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride, uint8_t *out, hipStream_t st) {
+  EdgeParams p{gt, 2, 3, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
+  hipLaunchKernelGGL(edge_mask_write, dim3(B * p.nblk_img), dim3(256), 0, st, p, out);
+  return (int)hipGetLastError();
+}
+
+}  // namespace ssg

@@ -1,0 +1,210 @@
+"""Torch-facing front end of the gfx950 SSG engine.
+
+PyTorch is used for device memory, streams and autograd plumbing only; every
+number is produced by the hand-written HIP kernels in ssl_amd/csrc through the
+C ABI of include/ssg_hip.h.  Tensors must live on the GPU; there is no CPU
+path (a CPU tensor raises, like the reference operator refuses non-CUDA
+tensors, similaritywrapper.py:60-62 -- but with an exception instead of
+sys.exit()).
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"ssl_amd: expected a GPU tensor, got device {t.device}; the SSG engine has no CPU path")
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=None):
+    """Device-side edge list of a batch.
+
+    mask: (B,c1,H,W) float32 or uint8 (channel 0 is used) -- or None with
+    gt (B,3,H,W) float32 in [0,1] to generate the reference's Laplacian mask
+    on the fly.  Returns (edges (capacity,3) int32 [b,y,x], counts (B+2) int32
+    on device: counts[0] = N).  No host synchronisation.
+    """
+    L = _lib.lib()
+    if mask is not None:
+        _need_gpu(mask)
+        if mask.dtype == torch.uint8 or mask.dtype == torch.bool:
+            src, kind = mask.contiguous().view(torch.uint8), 1
+        else:
+            src, kind = _f32c(mask), 0
+        B, c1, H, W = src.shape
+    else:
+        _need_gpu(gt)
+        src, kind = _f32c(gt), 2
+        B, c1, H, W = src.shape
+        if c1 != 3:
+            raise ValueError("Laplacian edge mask needs a 3-channel image")
+    if capacity is None:
+        capacity = B * H * W
+    dev = src.device
+    edges = torch.empty((max(capacity, 1), 3), dtype=torch.int32, device=dev)
+    counts = torch.empty(B + 2, dtype=torch.int32, device=dev)
+    scratch = torch.empty(L.ssg_edge_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
+    _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold),
+                               _ptr(edges), capacity, _ptr(counts), _ptr(scratch), _stream()))
+    return edges, counts
+
+
+def edge_mask_laplacian(gt, lap_threshold=20.0, mask_stride=0):
+    """(B,3,H,W) float32 in [0,1] -> (B,H,W) uint8 {0,1}: generate_mask.py:22-31 on device."""
+    _need_gpu(gt)
+    g = _f32c(gt)
+    B, C, H, W = g.shape
+    if C != 3:
+        raise ValueError("Laplacian edge mask needs a 3-channel image")
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=g.device)
+    _lib.check(_lib.lib().ssg_edge_mask_laplacian(_ptr(g), B, H, W, float(lap_threshold), int(mask_stride or 0),
+                                                  _ptr(out), _stream()))
+    return out
+
+
+class _SSGMapFn(torch.autograd.Function):
+    """SSG rows of a batch for a given edge list (loss_util.py:182-244 + autograd)."""
+
+    @staticmethod
+    def forward(ctx, img, edges, counts, n_rows, ks, kw, sigma, eps, generalization):
+        x = _f32c(img)
+        B, C, H, W = x.shape
+        ssg = torch.empty((n_rows, ks * ks), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ssg_map_forward(_ptr(x), None, B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw,
+                                              float(sigma), float(eps), int(bool(generalization)), _ptr(ssg), None,
+                                              _stream()))
+        ctx.save_for_backward(x, edges, counts, ssg)
+        ctx.cfg = (n_rows, ks, kw, float(sigma), int(bool(generalization)))
+        return ssg
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_ssg):
+        x, edges, counts, ssg = ctx.saved_tensors
+        n_rows, ks, kw, sigma, gen = ctx.cfg
+        B, C, H, W = x.shape
+        g = _f32c(grad_ssg)
+        grad = torch.zeros_like(x)
+        _lib.check(_lib.lib().ssg_map_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw, sigma,
+                                               gen, _ptr(ssg), _ptr(g), _ptr(grad), _stream()))
+        return grad, None, None, None, None, None, None, None, None
+
+
+def ssg_map(img, edges, counts, n_rows, ks, kw, sigma, eps=1e-10, generalization=True):
+    """(n_rows, ks*ks) SSG rows of `img` (B,C,H,W) at `edges`; differentiable w.r.t. img."""
+    _need_gpu(img, edges, counts)
+    return _SSGMapFn.apply(img, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization)
+
+
+class _SSGLossFn(torch.autograd.Function):
+    """(l1, kl) of the caller loop realesrganssl_model.py:379-430 over a batch."""
+
+    @staticmethod
+    def forward(ctx, sr, gt, edges, counts, n_rows, ks, kw, sigma, eps, generalization, w_l1, w_kl):
+        L = _lib.lib()
+        x, y = _f32c(sr), _f32c(gt)
+        B, C, H, W = x.shape
+        dev = x.device
+        P = ks * ks
+        ssg_sr = torch.empty((max(n_rows, 1), P), dtype=torch.float32, device=dev)
+        ssg_gt = torch.empty((max(n_rows, 1), P), dtype=torch.float32, device=dev)
+        loss = torch.zeros(2, dtype=torch.float32, device=dev)
+        scratch = torch.empty(L.ssg_loss_scratch_bytes(n_rows, ks), dtype=torch.uint8, device=dev)
+        gen = int(bool(generalization))
+        _lib.check(L.ssg_map_forward(_ptr(x), _ptr(y), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw,
+                                     float(sigma), float(eps), gen, _ptr(ssg_sr), _ptr(ssg_gt), _stream()))
+        _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw, float(sigma),
+                                       gen, _ptr(ssg_sr), _ptr(ssg_gt), float(w_l1), float(w_kl), None, _ptr(loss),
+                                       None, _ptr(scratch), _stream()))
+        ctx.save_for_backward(x, edges, counts, ssg_sr, ssg_gt, scratch)
+        ctx.cfg = (n_rows, ks, kw, float(sigma), gen, float(w_l1), float(w_kl))
+        ctx.ssg = (ssg_sr, ssg_gt)
+        return loss[0], loss[1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_l1, g_kl):
+        x, edges, counts, ssg_sr, ssg_gt, scratch = ctx.saved_tensors
+        n_rows, ks, kw, sigma, gen, w_l1, w_kl = ctx.cfg
+        B, C, H, W = x.shape
+        up = torch.stack([g_l1.to(torch.float32).reshape(()), g_kl.to(torch.float32).reshape(())]).contiguous()
+        grad = torch.zeros_like(x)
+        dummy = torch.empty(2, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw, sigma,
+                                                gen, _ptr(ssg_sr), _ptr(ssg_gt), w_l1, w_kl, _ptr(up), _ptr(dummy),
+                                                _ptr(grad), _ptr(scratch), _stream()))
+        return (grad,) + (None,) * 11
+
+
+def ssg_loss(sr, gt, edges, counts, n_rows, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0,
+             w_kl=1.0):
+    """Differentiable (l1, kl) for a batch given a device edge list; n_rows bounds N."""
+    _need_gpu(sr, gt, edges, counts)
+    return _SSGLossFn.apply(sr, gt, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization, w_l1,
+                            w_kl)
+
+
+class LossStep:
+    """The whole loss step in ONE C call (ssg_loss_fwd_bwd): edge list, SSG(sr), SSG(gt),
+    L1 + KL and d(l1+kl)/d sr, with persistent buffers sized for `capacity` edge pixels.
+
+    This is the path bench.py times.  No host synchronisation happens inside; `counts[0]`
+    (device) holds the edge-pixel count N of the last step, `loss` the two scalars.
+    """
+
+    def __init__(self, B, C, H, W, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0, w_kl=1.0,
+                 mask_stride=0, lap_threshold=20.0, capacity=None, device="cuda"):
+        L = _lib.lib()
+        self.shape = (B, C, H, W)
+        self.cfg = (ks, kw, float(sigma), float(eps), int(bool(generalization)), float(w_l1), float(w_kl),
+                    int(mask_stride or 0), float(lap_threshold))
+        self.capacity = int(capacity if capacity is not None else B * H * W)
+        P = ks * ks
+        self.ssg_sr = torch.empty((self.capacity, P), dtype=torch.float32, device=device)
+        self.ssg_gt = torch.empty((self.capacity, P), dtype=torch.float32, device=device)
+        self.counts = torch.zeros(B + 2, dtype=torch.int32, device=device)
+        self.loss = torch.zeros(2, dtype=torch.float32, device=device)
+        self.grad = torch.zeros((B, C, H, W), dtype=torch.float32, device=device)
+        self.ws_bytes = L.ssg_loss_workspace_bytes(B, H, W, self.capacity, ks)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+
+    def edges(self):
+        """View of the workspace's edge list (capacity,3) int32."""
+        return self.ws[: self.capacity * 12].view(torch.int32).view(self.capacity, 3)
+
+    def __call__(self, sr, gt, mask=None):
+        """mask (B,c1,H,W) float32/uint8, or None -> Laplacian mask of gt generated on device."""
+        _need_gpu(sr, gt, mask)
+        B, C, H, W = self.shape
+        ks, kw, sigma, eps, gen, w_l1, w_kl, stride, thr = self.cfg
+        assert tuple(sr.shape) == self.shape and tuple(gt.shape) == self.shape
+        assert sr.dtype == torch.float32 and gt.dtype == torch.float32 and sr.is_contiguous() and gt.is_contiguous()
+        if mask is None:
+            kind, mc, mp = 2, 3, None
+        elif mask.dtype == torch.uint8:
+            kind, mc, mp = 1, mask.shape[1], mask
+        else:
+            kind, mc, mp = 0, mask.shape[1], mask
+            assert mask.dtype == torch.float32
+        if mp is not None:
+            assert mp.is_contiguous()
+        self.grad.zero_()
+        _lib.check(_lib.lib().ssg_loss_fwd_bwd(_ptr(sr), _ptr(gt), _ptr(mp), kind, mc, B, C, H, W, ks, kw, sigma, eps,
+                                               gen, w_l1, w_kl, stride, thr, self.capacity, _ptr(self.ssg_sr),
+                                               _ptr(self.ssg_gt), _ptr(self.counts), _ptr(self.loss), _ptr(self.grad),
+                                               _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.loss, self.grad

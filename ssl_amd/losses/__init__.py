@@ -1,0 +1,2 @@
+from .basic_loss import KLDistanceLoss, L1Loss, SSGLoss  # noqa: F401
+from .loss_util import similarity_map  # noqa: F401

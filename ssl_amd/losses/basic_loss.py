@@ -1,0 +1,92 @@
+"""The two criteria the reference applies to (SSG_sr, SSG_gt) and their fusion.
+
+L1Loss / KLDistanceLoss mirror GAN-Based-SR/basicsr/losses/basic_loss.py:41-66
+and :269-282 (same constructor arguments and semantics) for code that keeps
+the reference's per-image `similarity_map` loop.  SSGLoss is the batched
+replacement of the whole caller block realesrganssl_model.py:379-430 /
+ddpmssl.py:438-513: one module call per step, no Python loop over images, no
+host synchronisation, masks of 1 or 3 channels, optional mask_stride and
+on-device Laplacian mask.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import engine
+
+_reduction_modes = ['none', 'mean', 'sum']
+
+
+class L1Loss(nn.Module):
+    """loss_weight * L1(pred, target) with 'none' | 'mean' | 'sum' reduction and an
+    optional element-wise weight (basic_loss.py:41-66, loss_util.py:33-62)."""
+
+    def __init__(self, loss_weight=1.0, reduction='mean'):
+        super(L1Loss, self).__init__()
+        if reduction not in _reduction_modes:
+            raise ValueError(f'Unsupported reduction mode: {reduction}. Supported ones are: {_reduction_modes}')
+        self.loss_weight = loss_weight
+        self.reduction = reduction
+
+    def forward(self, pred, target, weight=None, **kwargs):
+        loss = F.l1_loss(pred, target, reduction='none')
+        if weight is not None:
+            loss = loss * weight
+        if self.reduction == 'sum':
+            loss = loss.sum()
+        elif self.reduction == 'mean':
+            if weight is None:
+                loss = loss.mean()
+            else:  # weight_reduce_loss: mean over the weighted region
+                w = weight.sum() if weight.size(1) > 1 else weight.sum() * loss.size(1)
+                loss = loss.sum() / w
+        return self.loss_weight * loss
+
+
+class KLDistanceLoss(nn.Module):
+    """loss_weight * F.kl_div(log(clamp(x,1e-10)), clamp(y,1e-10)) (basic_loss.py:269-282)."""
+
+    def __init__(self, loss_weight=0.1, reduction='mean', softmax=False):
+        super(KLDistanceLoss, self).__init__()
+        self.loss_weight = loss_weight
+        self.reduction = reduction
+        self.softmax = softmax
+
+    def forward(self, x, y):
+        if self.softmax:
+            x = x.softmax(dim=-1)
+            y = y.softmax(dim=-1)
+        return self.loss_weight * F.kl_div(torch.clamp(input=x, min=1e-10).log(), torch.clamp(input=y, min=1e-10),
+                                           reduction=self.reduction)
+
+
+class SSGLoss(nn.Module):
+    """Batched Self-Similarity-Graph loss: returns (l_selfsim, l_selfsim_kl).
+
+    forward(sr, gt, mask=None): sr, gt (B,C,H,W) on the GPU; mask (B,1|3,H,W)
+    float {0,1} / uint8, or None to generate the reference's offline Laplacian
+    edge mask of `gt` on the device (generate_mask.py:22-31).  Semantics of the
+    reference loop: images whose mask is empty are skipped, the means run over
+    sum_i N_i * k_s^2 elements of the LOCAL batch, both terms are 0 when every
+    mask is empty.  `capacity` bounds the number of edge pixels per call
+    without a host round trip (default: every pixel, B*H*W).
+    """
+
+    def __init__(self, kernel_size_search=25, kernel_size_window=9, sigma=0.004, generalization=True,
+                 loss_weight_l1=1e3, loss_weight_kl=1e3, mask_stride=0, eps=1e-10, lap_threshold=20.0,
+                 capacity=None):
+        super().__init__()
+        self.ks, self.kw = kernel_size_search, kernel_size_window
+        self.sigma, self.generalization, self.eps = sigma, generalization, eps
+        self.w_l1, self.w_kl = loss_weight_l1, loss_weight_kl
+        self.mask_stride, self.lap_threshold = mask_stride, lap_threshold
+        self.capacity = capacity
+
+    def forward(self, sr, gt, mask=None):
+        B, C, H, W = sr.shape
+        cap = self.capacity if self.capacity is not None else B * H * W
+        edges, counts = engine.edge_list(mask=mask, gt=gt if mask is None else None, mask_stride=self.mask_stride,
+                                         lap_threshold=self.lap_threshold, capacity=cap)
+        self.last_counts = counts
+        return engine.ssg_loss(sr, gt.detach(), edges, counts, cap, self.ks, self.kw, self.sigma, self.eps,
+                               self.generalization, self.w_l1, self.w_kl)
