@@ -55,6 +55,12 @@ def lib():
     """The loaded library with typed prototypes.  Raises if it is not built."""
     global _lib
     if _lib is None:
+        # torch bundles its own HIP runtime (libamdhip64 of its ROCm build).  It must be the one
+        # already mapped when libssg_hip.so resolves its libamdhip64 dependency, otherwise the
+        # process ends up with two runtimes and our launches see "no ROCm-capable device".
+        import torch  # noqa: F401
+        if torch.cuda.is_available():
+            torch.cuda.init()
         if not os.path.exists(SO_PATH):
             raise RuntimeError(
                 f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -161,7 +161,13 @@ def f2_paper(size, sigmas, name, rows=64):
             gg = g.numpy()
             out[f"grad_absmax_s{sigma}_{dn}"] = np.abs(gg).max()
             out[f"grad_sum_s{sigma}_{dn}"] = gg.astype(np.float64).sum()
+            if dn == "f32":
+                g32 = gg
             if dn == "f64":
+                # how far the reference's OWN fp32 run is from its fp64 run (max-norm, relative to
+                # max|grad|): the yardstick for fp32 gradient parity (L1's sign() and the softmax-like
+                # normalisation make tiny-sigma=1 gradients ill-conditioned in fp32)
+                out[f"grad_ref32_dev_s{sigma}"] = np.abs(g32.astype(np.float64) - gg).max() / np.abs(gg).max()
                 out[f"ssg_sr_s{sigma}"] = a.numpy()[0][sel].astype(np.float32)
                 out[f"ssg_gt_s{sigma}"] = b.numpy()[0][sel].astype(np.float32)
                 out[f"grad_s{sigma}"] = gg.astype(np.float32)

@@ -6,9 +6,13 @@ Tolerances (north star: 1e-5 fp32):
   SSG tensors      abs 1e-5 (values are in [0,1]; fixtures hold the reference's
                    float64 results)
   losses           rel 1e-5
-  gradients        1e-5 * max|grad| (+ the documented L1 sign() caveat: an
-                   element whose |s_sr - s_gt| is below fp32 resolution can take
-                   either sign; such ties do not occur in these fixtures)
+  gradients        1e-5 * max|grad| for smooth cotangents.  Through the L1/KL criteria the
+                   fp32 gradient is ill-conditioned (sign(), and g - sum g*s cancels when a
+                   row is nearly one-hot or nearly flat): the reference's OWN fp32 run is
+                   6.5e-5 (sigma=0.004) to 3.8e-4 (sigma=1.0) of max|grad| away from its fp64
+                   run on fixture F2.  Those tests therefore allow max(1e-5, 3 x the
+                   reference's fp32-vs-fp64 deviation stored in the fixture), and oracle-based
+                   ones max(1e-5, 4 x the fp32 oracle's deviation from the fp64 oracle).
   raw distances    rel 2e-6 (fp32 accumulation of <= 507 squares)
   edge masks/lists bit exact
 """
@@ -35,6 +39,14 @@ def T(a, dev, dtype=torch.float32):
 
 def maxerr(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def grad_tol_from_oracle(sr, gt, masks, ks, kw, sigma, ref64):
+    """max(1e-5, 4 x fp32-oracle deviation) * max|grad| -- see the module docstring."""
+    r32 = orc.ssg_loss(sr.astype(np.float32), gt.astype(np.float32), masks, ks, kw, sigma, 1e3, 1e3)
+    mx = np.abs(ref64["grad"]).max()
+    dev32 = np.abs(r32["grad"].astype(np.float64) - ref64["grad"]).max() / mx
+    return max(1e-5, 4.0 * dev32) * mx
 
 
 # ------------------------------------------------------------------ (A) operator
@@ -141,13 +153,14 @@ def test_f2_paper_config_rows_losses_grad(dev, golden, name):
         (l1 + kl).backward()
         rl1, rkl = float(g[f"l1_s{sg}_f64"]), float(g[f"kl_s{sg}_f64"])
         assert abs(float(l1) - rl1) <= 1e-5 * abs(rl1), (float(l1), rl1)
-        assert abs(float(kl) - rkl) <= 1e-5 * abs(rkl) + 1e-9, (float(kl), rkl)
+        # sigma = 1.0: KL is ~2e-6 after w = 1e3 and is a cancelling sum of terms ~1e-3; fp32 log
+        # round-off puts even the reference's own fp32 run 3.4e-9 away from its fp64 run
+        assert abs(float(kl) - rkl) <= 1e-5 * abs(rkl) + 2e-8, (float(kl), rkl)
         ref = g[f"grad_s{sg}"]
         got = sr.grad.cpu().numpy()[0]
         err = np.abs(got.astype(np.float64) - ref)
-        # max-norm at 1e-5 of the largest entry; the fp32 reference run itself differs from the fp64
-        # one by ~1e-6 relative here
-        assert err.max() <= 1e-5 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+        tol = max(1e-5, 3.0 * float(g[f"grad_ref32_dev_s{sg}"])) * np.abs(ref).max()
+        assert err.max() <= tol, (sigma, err.max() / np.abs(ref).max(), float(g[f"grad_ref32_dev_s{sg}"]))
 
 
 def test_f3_three_channel_mask_and_empty_image(dev, golden):
@@ -253,8 +266,8 @@ def test_loss_step_matches_oracle_small_batch(dev):
     n = int(step.counts[0])
     assert n == ref["n_edges"]
     l = loss.cpu().numpy()
-    assert abs(l[0] - ref["l1"]) <= 1e-5 * ref["l1"] and abs(l[1] - ref["kl"]) <= 1e-5 * ref["kl"]
-    assert maxerr(grad.cpu(), ref["grad"]) <= 1e-5 * np.abs(ref["grad"]).max()
+    assert abs(l[0] - ref["l1"]) <= 1e-5 * ref["l1"] and abs(l[1] - ref["kl"]) <= 1e-5 * ref["kl"] + 2e-8
+    assert maxerr(grad.cpu(), ref["grad"]) <= grad_tol_from_oracle(sr, gt, masks, ks, kw, sigma, ref)
     assert maxerr(step.ssg_sr[:n].cpu(), ref["s_sr"]) <= 1e-5
     assert maxerr(step.ssg_gt[:n].cpu(), ref["s_gt"]) <= 1e-5
 
@@ -288,7 +301,7 @@ def test_c2_full_size_properties(dev):
         kl = 1e3 * torch.nn.functional.kl_div(s_sr.clamp(min=1e-10).double().log(), s_gt.clamp(min=1e-10).double(),
                                               reduction="mean")
         assert abs(float(loss[0]) - float(l1)) <= 1e-5 * float(l1)
-        assert abs(float(loss[1]) - float(kl)) <= 1e-5 * float(kl) + 1e-9
+        assert abs(float(loss[1]) - float(kl)) <= 1e-5 * float(kl) + 2e-8
         # linearity of the backward in the upstream gradients, through autograd
         x = tsr.clone().requires_grad_(True)
         a, b = SSGLoss(ks, kw, sigma, True, 1e3, 1e3, capacity=n + 8)(x, tgt, tm)
@@ -316,5 +329,5 @@ def test_gradient_of_one_image_vs_oracle_paper_sizes(dev):
     x = T(sr, dev).requires_grad_(True)
     l1, kl = SSGLoss(ks, kw, sigma, True, 1e3, 1e3)(x, T(gt, dev), T(mask[:, None], dev))
     (l1 + kl).backward()
-    assert abs(float(l1) - ref["l1"]) <= 1e-5 * ref["l1"] and abs(float(kl) - ref["kl"]) <= 1e-5 * ref["kl"]
-    assert maxerr(x.grad.cpu(), ref["grad"]) <= 1e-5 * np.abs(ref["grad"]).max()
+    assert abs(float(l1) - ref["l1"]) <= 1e-5 * ref["l1"] and abs(float(kl) - ref["kl"]) <= 1e-5 * ref["kl"] + 2e-8
+    assert maxerr(x.grad.cpu(), ref["grad"]) <= grad_tol_from_oracle(sr, gt, mask, ks, kw, sigma, ref)
