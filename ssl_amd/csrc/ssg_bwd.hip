@@ -65,6 +65,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   float *jsc = red2 + WG;                     // [JOBS][4]: dot, sumG
   int *sh_edge = (int *)(jsc + JOBS * 4);     // [JOBS][4]
   float *at = (float *)(sh_edge + JOBS * 4);  // [JOBS][C][KW][KW] centre windows
+  float *gwin = at + JOBS * C * KW * KW;      // [JOBS][KW][KW] window gradients of the current channel
 
   const int tid = threadIdx.x;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
@@ -202,130 +203,138 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   const float *zrow = zero + HK;
   const int eb = sh_edge[jl * 4 + 0], ey = sh_edge[jl * 4 + 1], ex = sh_edge[jl * 4 + 2];
 
-  // window sum of Gz around every owned t (channel independent)
+  // window sum of Gz around every owned t (channel independent): separable k_w x k_w box filter
+  // through LDS -- horizontal k_w-tap sums of the job's G tile into its (still unused)
+  // reduction slice, then vertical k_w-tap sums into registers.
   float box[BS][BS];
-#pragma unroll
-  for (int i = 0; i < BS; ++i)
-#pragma unroll
-    for (int j = 0; j < BS; ++j) box[i][j] = 0.f;
   {
-    float bn[PW];
-    load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
-#pragma unroll
-    for (int r = 0; r < PW; ++r) {
-      float bv[PW];
-#pragma unroll
-      for (int j = 0; j < PW; ++j) bv[j] = bn[j];
-      if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
-      float hs[BS];  // horizontal k_w-tap sums of this patch row
-#pragma unroll
-      for (int j = 0; j < BS; ++j) {
+    float *hsum = red + jl * (KHC * KW) * LPJ;  // [KS][KS]
+    if (lane_on)
+      for (int e = m; e < P; e += LPJ) {
+        const int y = e / KS, x = e - y * KS;
         float t = 0.f;
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) t += bv[j + kx];
-        hs[j] = t;
-      }
-#pragma unroll
-      for (int i = 0; i < BS; ++i) {
-        const int kh = r - i;
-        if (kh < 0 || kh >= KW) continue;
-#pragma unroll
-        for (int j = 0; j < BS; ++j) box[i][j] += hs[j];
-      }
-      pin_block<BS, BS>(box);
-    }
-  }
-
-#pragma unroll 1
-  for (int c = 0; c < C; ++c) {
-    const size_t cbase = ((size_t)eb * C + c) * H * W;
-    // image offset of tile position (i,j) of the owned block, -1 when it takes no gradient
-    // (`fence` is an opaque zero: it pins the address arithmetic and the loads that use
-    // it BELOW the asm that produced it, so hipcc cannot hoist 50 VGPRs of offsets and
-    // image values above the unrolled passes)
-    auto tile_off = [&](int i, int j, int fence) -> int {
-      const int ty = BS * by + i, tx = BS * bx + j;
-      const bool in = ty < KS && tx < KS && job_on;
-      const int o = reflect_idx(ey + fence - HP + (ty < KS ? ty : 0), H) * W +
-                    reflect_idx(ex - HP + (tx < KS ? tx : 0), W);
-      return in ? o : -1;
-    };
-    const float *ac = at + (jl * C + c) * KW * KW;
-
-    // ---- pass A: acc[t] = sum_k' Gz[t+k'] * A[c,-k'] ----
-    {
-      float acc[BS][BS];
-#pragma unroll
-      for (int i = 0; i < BS; ++i)
-#pragma unroll
-        for (int j = 0; j < BS; ++j) acc[i][j] = 0.f;
-      if constexpr (KW <= 9) {
-        float af[KW][KW];
-#pragma unroll
-        for (int kh = 0; kh < KW; ++kh)
-#pragma unroll
-          for (int kx = 0; kx < KW; ++kx) af[kh][kx] = ac[(KW - 1 - kh) * KW + (KW - 1 - kx)];
-        float bn[PW];
-        load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
-#pragma unroll
-        for (int r = 0; r < PW; ++r) {
-          float bv[PW];
-#pragma unroll
-          for (int j = 0; j < PW; ++j) bv[j] = bn[j];
-          if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
-#pragma unroll
-          for (int i = 0; i < BS; ++i) {
-            const int kh = r - i;
-            if (kh < 0 || kh >= KW) continue;
-#pragma unroll
-            for (int j = 0; j < BS; ++j)
-#pragma unroll
-              for (int kx = 0; kx < KW; ++kx) acc[i][j] = __builtin_fmaf(af[kh][kx], bv[j + kx], acc[i][j]);
-          }
-          pin_block<BS, BS>(acc);
+        for (int kx = -HK; kx <= HK; ++kx) {
+          const int xx = x + kx;
+          t += (unsigned)xx < (unsigned)KS ? tg[y * S + xx] : 0.f;
         }
-      } else {
-#pragma unroll 1
-        for (int r = 0; r < PW; ++r) {
-          float bv[PW];
-          load_grow<G>(tg, zrow, ry0 + r, cx0, colv, bv);
-#pragma unroll
-          for (int i = 0; i < BS; ++i) {
-            const int kh = r - i;
-            if (kh < 0 || kh >= KW) continue;
-            const float *ar = ac + (KW - 1 - kh) * KW;
-#pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-              const float av = ar[KW - 1 - kx];
-#pragma unroll
-              for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(av, bv[j + kx], acc[i][j]);
-            }
-          }
-        }
+        hsum[e] = t;
       }
-      int fa = 0;
-      asm volatile("" : "+v"(fa)::"memory");
-#pragma unroll
-      for (int i = 0; i < BS; ++i)
-#pragma unroll
-        for (int j = 0; j < BS; ++j) {
-          const int o = tile_off(i, j, fa);
-          if (o >= 0) unsafeAtomicAdd(p.grad + cbase + o, -2.f * (acc[i][j] - p.img[cbase + o] * box[i][j]));
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    int fb = 0;
-    asm volatile("" : "+v"(fb)::"memory");
-    // S[c,t] of the owned block (pass B's multiplier); loaded only now to keep pass A's
-    // register footprint at acc + stencil + two patch rows + box
-    float sv[BS][BS];
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < BS; ++i)
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
-        const int o = tile_off(i, j, fb);
-        sv[i][j] = o >= 0 ? p.img[cbase + o] : 0.f;
+        const int ty = BS * by + i, tx = BS * bx + j;
+        float t = 0.f;
+        if (ty < KS && tx < KS) {
+#pragma unroll
+          for (int kh = -HK; kh <= HK; ++kh) {
+            const int yy = ty + kh;
+            t += (unsigned)yy < (unsigned)KS ? hsum[yy * KS + tx] : 0.f;
+          }
+        }
+        box[i][j] = t;
       }
+    __syncthreads();
+  }
+
+  // Barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global
+  // atomics (a __syncthreads() would drain vmcnt and stall every barrier behind the atomics'
+  // L2 round trip -- 73 % of wave time was spent there).
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // image offset of tile position (ty,tx) of this job; callers guard ty,tx < KS
+  auto img_off = [&](int ty, int tx) -> int {
+    return reflect_idx(ey - HP + ty, H) * W + reflect_idx(ex - HP + tx, W);
+  };
+  // (`fence` is an opaque zero produced by an asm AFTER pass A: it pins the address arithmetic
+  // and the loads below that point, so hipcc cannot keep 50 VGPRs of offsets and image values
+  // live across the unrolled pass)
+  auto load_sv = [&](int c, float (&sv)[BS][BS], int fence) {
+    const size_t cb = ((size_t)eb * C + c) * H * W;
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int ty = BS * by + i, tx = BS * bx + j;
+        const bool in = ty < KS && tx < KS;
+        sv[i][j] = in ? p.img[cb + fence + img_off(in ? ty : 0, in ? tx : 0)] : 0.f;
+      }
+  };
+
+  float *gst = red + jl * SL * LPJ;           // job's gradient staging tile [KS][KS], aliases its slice
+  static_assert(SL * LPJ >= P, "staging tile must fit the reduction slice");
+
+#pragma unroll 1
+  for (int c = 0; c < C; ++c) {
+    const size_t cbase = ((size_t)eb * C + c) * H * W;
+    const float *ac = at + (jl * C + c) * KW * KW;
+
+    // ---- pass A: acc[t] = sum_k' Gz[t+k'] * A[c,-k'] ----
+    float acc[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) acc[i][j] = 0.f;
+    if constexpr (KW <= 9) {
+      float af[KW][KW];
+#pragma unroll
+      for (int kh = 0; kh < KW; ++kh)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) af[kh][kx] = ac[(KW - 1 - kh) * KW + (KW - 1 - kx)];
+      float bn[PW];
+      load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
+#pragma unroll
+      for (int r = 0; r < PW; ++r) {
+        float bv[PW];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+        if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+          const int kh = r - i;
+          if (kh < 0 || kh >= KW) continue;
+#pragma unroll
+          for (int j = 0; j < BS; ++j)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) acc[i][j] = __builtin_fmaf(af[kh][kx], bv[j + kx], acc[i][j]);
+        }
+        pin_block<BS, BS>(acc);
+      }
+    } else {
+#pragma unroll 1
+      for (int r = 0; r < PW; ++r) {
+        float bv[PW];
+        load_grow<G>(tg, zrow, ry0 + r, cx0, colv, bv);
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+          const int kh = r - i;
+          if (kh < 0 || kh >= KW) continue;
+          const float *ar = ac + (KW - 1 - kh) * KW;
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) {
+            const float av = ar[KW - 1 - kx];
+#pragma unroll
+            for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(av, bv[j + kx], acc[i][j]);
+          }
+        }
+      }
+    }
+    // S[c,t] of the owned block: loaded only now (pass A's register footprint is acc + stencil
+    // + two patch rows + box); the previous channel's atomics were issued a whole pass ago, so
+    // the in-order vmcnt wait behind them is short
+    float sv[BS][BS];
+    {
+      int fz = 0;
+      asm volatile("" : "+v"(fz)::"memory");
+      load_sv(c, sv, fz);
+    }
+    // gS[c,t] = -2 (acc - S box), kept in registers until the staging tile is free
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) acc[i][j] = -2.f * (acc[i][j] - sv[i][j] * box[i][j]);
 
     // ---- pass B: P[k'] = sum_t Gz[t+k'] * S[c,t], KHC stencil rows at a time ----
 #pragma unroll 1
@@ -363,22 +372,45 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 #pragma unroll
           for (int kx = 0; kx < KW; ++kx) red[(jl * SL + a * KW + kx) * LPJ + m] = pp[a][kx];
       }
-      __syncthreads();
-      if (job_on)
+      lds_barrier();
+      if (lane_on)
         for (int o = m; o < SL; o += LPJ) {
-          const int a = o / KW, kxp = o - a * KW, khp = kh0 + a;
+          const int khp = kh0 + o / KW;
           if (khp < KW) {
             const float *rp = red + (jl * SL + o) * LPJ;
             float t = 0.f;
             for (int k = 0; k < LPJ; ++k) t += rp[k];
-            const int kh = KW - 1 - khp, kx = KW - 1 - kxp;  // k = -k'
-            const float av = ac[kh * KW + kx];
-            const int o2 = reflect_idx(ey - HK + kh, H) * W + reflect_idx(ex - HK + kx, W);
-            unsafeAtomicAdd(p.grad + cbase + o2, 2.f * (av * sumG - t));
+            const int kh = KW - 1 - khp, kx = KW - 1 - (o % KW);  // k = -k'
+            gwin[jl * KW * KW + kh * KW + kx] = 2.f * (ac[kh * KW + kx] * sumG - t);  // unique owner
           }
         }
-      __syncthreads();
+      lds_barrier();
     }
+
+    // ---- stage the job's C-channel gradient tile in LDS, merge the window part ----
+    if (lane_on) {
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int ty = BS * by + i, tx = BS * bx + j;
+          if (ty < KS && tx < KS) gst[ty * KS + tx] = acc[i][j];
+        }
+    }
+    lds_barrier();
+    if (lane_on)
+      for (int o = m; o < KW * KW; o += LPJ) {
+        const int kh = o / KW, kx = o - kh * KW;
+        gst[(HP - HK + kh) * KS + (HP - HK + kx)] += gwin[jl * KW * KW + o];  // unique owner per (kh,kx)
+      }
+    lds_barrier();
+    // ---- flush: row-contiguous fp32 atomics, nothing waits for them ----
+    if (job_on)
+      for (int e = m; e < P; e += LPJ) {
+        const int ty = e / KS, tx = e - ty * KS;
+        unsafeAtomicAdd(p.grad + cbase + img_off(ty, tx), gst[e]);
+      }
+    lds_barrier();  // staging tile is the next channel's reduction slice
   }
 }
 
@@ -516,7 +548,7 @@ template <class G, int KHC>
 static size_t bwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
   return sizeof(float) * (size_t)(PADF + G::JOBS * G::CH + ((G::ZROW + 3) & ~3) + G::JOBS * KHC * G::KW * G::LPJ +
-                                  G::WG + G::JOBS * 4 + G::JOBS * C * G::KW * G::KW + 8) +
+                                  G::WG + G::JOBS * 4 + G::JOBS * (C + 1) * G::KW * G::KW + 8) +
          sizeof(int) * 4 * G::JOBS;
 }
 
