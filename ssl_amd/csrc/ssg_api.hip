@@ -3,23 +3,37 @@
 // and the reference interface it replaces.
 #include "../../include/ssg_hip.h"
 
+#include <cstdlib>
+
 #include "ssg_common.hpp"
 
 namespace ssg {
 int launch_fwd(const FwdParams &p, hipStream_t st);
 int launch_bwd(const BwdParams &p, hipStream_t st);
-unsigned bwd_grid(int ks, int kw, int n);
+unsigned bwd_grid(const BwdParams &p);
+size_t bwd_max_partials(int B, int H, int W, int n_rows);
 int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
                          float w_kl, float *loss_out, hipStream_t st);
 const char *fwd_kernel_name(int ks, int kw);
 const char *bwd_kernel_name(int ks, int kw);
 size_t edge_scratch_bytes(int B, int H, int W);
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
-                     int *edges, int capacity, int *counts, void *scratch, hipStream_t st);
+                     int *edges, int capacity, int *counts, int *rank, int *order, void *scratch, hipStream_t st);
 int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride, uint8_t *out, hipStream_t st);
 }  // namespace ssg
 
 using namespace ssg;
+
+// SSG_DEBUG_SKIP=<bitmask> ablates kernel phases for profiling (results are then WRONG);
+// read once, 0 in production.
+static int dbg_mask() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SSG_DEBUG_SKIP");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
 
 static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (kw & 1); }
 
@@ -63,6 +77,7 @@ int ssg_compute_similarity(const float *image, const int *pos, float *out, int m
   p.raw = 1;
   p.ks = psize;
   p.kw = ksize;
+  p.dbg = dbg_mask() & 0xff;
   return launch_fwd(p, (hipStream_t)stream);
 }
 
@@ -88,18 +103,20 @@ int ssg_compute_similarity_backward(const float *image, const float *grads, cons
   p.sigma = 1.f;
   p.ks = psize;
   p.kw = ksize;
+  p.dbg = dbg_mask() >> 8;
   return launch_bwd(p, (hipStream_t)stream);
 }
 
 size_t ssg_edge_scratch_bytes(int B, int H, int W) { return edge_scratch_bytes(B, H, W); }
 
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
-                  float lap_threshold, int *edges, int capacity, int *counts, void *scratch, ssg_stream_t stream) {
+                  float lap_threshold, int *edges, int capacity, int *counts, int *rank_map, int *tile_order,
+                  void *scratch, ssg_stream_t stream) {
   if (!mask || !edges || !counts || !scratch || B <= 0 || H <= 0 || W <= 0 || capacity < 0 || mask_kind < 0 ||
-      mask_kind > 2 || mask_channels <= 0)
+      mask_kind > 2 || mask_channels <= 0 || (tile_order && !rank_map))
     return SSG_E_BADARG;
   return launch_edge_list(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, edges, capacity,
-                          counts, scratch, (hipStream_t)stream);
+                          counts, rank_map, tile_order, scratch, (hipStream_t)stream);
 }
 
 int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_threshold, int mask_stride,
@@ -135,12 +152,13 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
   p.raw = 0;
   p.ks = ks;
   p.kw = kw;
+  p.dbg = dbg_mask() & 0xff;
   return launch_fwd(p, (hipStream_t)stream);
 }
 
-int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *edges, const int *n_edges_dev,
-                     int n_rows, int ks, int kw, float sigma, int generalization, const float *ssg,
-                     const float *grad_ssg, float *grad_img, ssg_stream_t stream) {
+int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *edges, const int *tile_order,
+                     const int *n_edges_dev, int n_rows, int ks, int kw, float sigma, int generalization,
+                     const float *ssg, const float *grad_ssg, float *grad_img, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -156,6 +174,7 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *ed
   p.C = C;
   p.H = H;
   p.W = W;
+  p.order = tile_order;
   p.mode = GRAD_S;
   p.gin = grad_ssg;
   p.ssg = ssg;
@@ -163,18 +182,19 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *ed
   p.generalization = generalization;
   p.ks = ks;
   p.kw = kw;
+  p.dbg = dbg_mask() >> 8;
   return launch_bwd(p, (hipStream_t)stream);
 }
 
-size_t ssg_loss_scratch_bytes(int n_rows, int ks) {
+size_t ssg_loss_scratch_bytes(int B, int H, int W, int n_rows, int ks) {
   (void)ks;
-  return 2 * sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1) + 64;
+  return 2 * sizeof(float) * bwd_max_partials(B, H, W, n_rows) + 64;
 }
 
-int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *n_edges_dev,
-                      int n_rows, int ks, int kw, float sigma, int generalization, const float *ssg_sr,
-                      const float *ssg_gt, float w_l1, float w_kl, const float *upstream, float *loss_out,
-                      float *grad_sr, void *scratch, ssg_stream_t stream) {
+int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *tile_order,
+                      const int *n_edges_dev, int n_rows, int ks, int kw, float sigma, int generalization,
+                      const float *ssg_sr, const float *ssg_gt, float w_l1, float w_kl, const float *upstream,
+                      float *loss_out, float *grad_sr, void *scratch, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
@@ -191,6 +211,7 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
   p.C = C;
   p.H = H;
   p.W = W;
+  p.order = tile_order;
   p.mode = GRAD_LOSS;
   p.ssg = ssg_sr;
   p.ssg2 = ssg_gt;
@@ -202,15 +223,17 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
   p.upstream = upstream;
   p.ks = ks;
   p.kw = kw;
+  p.dbg = dbg_mask() >> 8;
   int rc = launch_bwd(p, st);
   if (rc) return rc;
-  return launch_loss_finalize(p.partials, (int)bwd_grid(ks, kw, n_rows), n_edges_dev, n_rows, ks * ks, w_l1, w_kl,
-                              loss_out, st);
+  return launch_loss_finalize(p.partials, (int)bwd_grid(p), n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
 }
 
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
   return align_up(sizeof(int) * 3 * (size_t)(capacity > 0 ? capacity : 1), 256) +
-         align_up(edge_scratch_bytes(B, H, W), 256) + align_up(ssg_loss_scratch_bytes(capacity, ks), 256);
+         align_up(sizeof(int) * (size_t)B * H * W, 256) + align_up(sizeof(int) * (size_t)(capacity > 0 ? capacity : 1), 256) +
+         align_up(edge_scratch_bytes(B, H, W), 256) +
+         align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
 }
 
 int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,
@@ -224,17 +247,21 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   char *ws = (char *)workspace;
   int *edges = (int *)ws;
   ws += align_up(sizeof(int) * 3 * (size_t)capacity, 256);
+  int *rank = (int *)ws;
+  ws += align_up(sizeof(int) * (size_t)B * H * W, 256);
+  int *order = (int *)ws;
+  ws += align_up(sizeof(int) * (size_t)capacity, 256);
   void *escratch = ws;
   ws += align_up(edge_scratch_bytes(B, H, W), 256);
   void *lscratch = ws;
   int rc = ssg_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
-                         W, mask_stride, lap_threshold, edges, capacity, counts, escratch, stream);
+                         W, mask_stride, lap_threshold, edges, capacity, counts, rank, order, escratch, stream);
   if (rc) return rc;
   rc = ssg_map_forward(sr, gt, B, C, H, W, edges, counts, capacity, ks, kw, sigma, eps, generalization, ssg_sr,
                        ssg_gt, stream);
   if (rc) return rc;
-  return ssg_loss_backward(sr, B, C, H, W, edges, counts, capacity, ks, kw, sigma, generalization, ssg_sr, ssg_gt,
-                           w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);
+  return ssg_loss_backward(sr, B, C, H, W, edges, order, counts, capacity, ks, kw, sigma, generalization, ssg_sr,
+                           ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);
 }
 
 const char *ssg_kernel_name(int ks, int kw, int backward) {

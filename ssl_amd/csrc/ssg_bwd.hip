@@ -47,6 +47,13 @@ __device__ __forceinline__ float criteria_elem(float a, float b, float w1m, floa
   return g;
 }
 
+// Workgroup w takes JOBS consecutive entries of the job order: either the caller's row order
+// (reference operator interface: arbitrary pos list) or, when `p.order` is given, the tile-major
+// permutation the edge-list builder wrote (8x8 image tiles, row-major inside a tile).  In tile
+// order a workgroup's JOBS edge pixels sit within a few pixels of each other, so their gradient
+// tiles are first summed into ONE LDS window (plain read-modify-write, one job at a time: LDS
+// fp32 atomics run at 0.4 lane-ops/clk/CU on gfx950, measured) and only that window goes to HBM
+// with fp32 atomics -- 3.5x fewer global atomics, which is what bounds this kernel.
 template <class G, int KHC>
 __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
@@ -55,6 +62,9 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   constexpr int PADF = (HK + 3) & ~3;
   constexpr int NCH = (KW + KHC - 1) / KHC;  // pass-B chunks of KHC stencil rows
   constexpr int SL = KHC * KW;               // partials per chunk
+  constexpr int EPL = (P + LPJ - 1) / LPJ;   // row elements per lane
+  constexpr int MH = KS + 7, MW = KS + 15;   // merge window: centres within 8 rows x 16 columns
+  constexpr int MS = MW + 1;                 // its LDS row stride
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = p.C, H = p.H, W = p.W;
@@ -63,9 +73,10 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   float *red = zero + ((G::ZROW + 3) & ~3);   // [JOBS][SL][LPJ] pass-B slice
   float *red2 = red + JOBS * SL * LPJ;        // [WG] scalar reductions
   float *jsc = red2 + WG;                     // [JOBS][4]: dot, sumG
-  int *sh_edge = (int *)(jsc + JOBS * 4);     // [JOBS][4]
+  int *sh_edge = (int *)(jsc + JOBS * 4);     // [JOBS][4]: b, y, x, row
   float *at = (float *)(sh_edge + JOBS * 4);  // [JOBS][C][KW][KW] centre windows
   float *gwin = at + JOBS * C * KW * KW;      // [JOBS][KW][KW] window gradients of the current channel
+  float *mwin = gwin + JOBS * KW * KW;        // [MH][MS] merge window of the current channel
 
   const int tid = threadIdx.x;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
@@ -77,341 +88,451 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
     }
     return;
   }
-
   if (tid < JOBS) {
-    const int q = job0 + tid;
-    const bool v = q < nrows;
-    Edge e = load_edge(p.edges, p.estride, v ? q : 0);
+    const int k = job0 + tid;
+    const bool v = k < nrows;
+    const int row = v ? (p.order ? p.order[k] : k) : -1;
+    const Edge e = load_edge(p.edges, p.estride, v ? row : 0);
     sh_edge[tid * 4 + 0] = e.b;
     sh_edge[tid * 4 + 1] = e.y;
     sh_edge[tid * 4 + 2] = e.x;
-    sh_edge[tid * 4 + 3] = v ? 1 : 0;
+    sh_edge[tid * 4 + 3] = row;
   }
   for (int i = tid; i < G::ZROW + 4; i += WG) zero[i] = 0.f;
+  for (int i = tid; i < MH * MS; i += WG) mwin[i] = 0.f;
   if (tid < PADF) smem[tid] = 0.f;
+  __syncthreads();
 
   int jl = tid / LPJ;
   const int m = tid - jl * LPJ;
   const bool lane_on = jl < JOBS;
   if (!lane_on) jl = 0;
-  const int n = job0 + jl;
-  const bool job_on = lane_on && n < nrows;
-  __syncthreads();
-
-  // ---- stage 1: G tile of each job ----
   float *tg = gt + jl * CHG;
   const float kfac = 1.f / (p.sigma * (float)(C * KW * KW));
-  float l1p = 0.f, klp = 0.f;
-  {
-    const size_t base = (size_t)(job_on ? n : 0) * P;
-    float dot = 0.f;
-    if (p.mode == GRAD_D) {
-      if (lane_on)
-        for (int e = m; e < P; e += LPJ) {
-          const int py = e / KS, px = e - py * KS;
-          tg[py * S + px] = job_on ? p.gin[base + e] : 0.f;
-        }
-    } else {
-      const float invM = 1.f / ((float)nrows * (float)P);
-      const float u1 = p.upstream ? p.upstream[0] : 1.f, u2 = p.upstream ? p.upstream[1] : 1.f;
-      const float w1m = p.w_l1 * invM * u1, w2m = p.w_kl * invM * u2;
-      if (lane_on)
-        for (int e = m; e < P; e += LPJ) {
-          const int py = e / KS, px = e - py * KS;
-          float g = 0.f;
-          if (job_on) {
-            const float s = p.ssg[base + e];
-            g = p.mode == GRAD_S ? p.gin[base + e] : criteria_elem(s, p.ssg2[base + e], w1m, w2m, l1p, klp);
-            dot = __builtin_fmaf(g, s, dot);
-          }
-          tg[py * S + px] = g;
-        }
-      red2[tid] = dot;
-      __syncthreads();
-      if (tid < JOBS) {
-        float t = 0.f;
-        for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
-        jsc[tid * 4 + 0] = p.generalization ? t : 0.f;
-      }
-      __syncthreads();
-      dot = jsc[jl * 4 + 0];
-      if (lane_on)
-        for (int e = m; e < P; e += LPJ) {
-          const int py = e / KS, px = e - py * KS;
-          const float s = job_on ? p.ssg[base + e] : 0.f;
-          tg[py * S + px] = -(s * kfac) * (tg[py * S + px] - dot);
-        }
-    }
-  }
-  if (p.mode == GRAD_LOSS) {  // criteria partial sums of this workgroup
-    __syncthreads();
-    red2[tid] = l1p;
-    __syncthreads();
-    float t1 = 0.f, t2 = 0.f;
-    if (tid == 0)
-      for (int k = 0; k < WG; ++k) t1 += red2[k];
-    __syncthreads();
-    red2[tid] = klp;
-    __syncthreads();
-    if (tid == 0) {
-      for (int k = 0; k < WG; ++k) t2 += red2[k];
-      p.partials[2 * blockIdx.x] = t1;
-      p.partials[2 * blockIdx.x + 1] = t2;
-    }
-    if (p.grad == nullptr) return;
-  }
-  // G at the centre offset multiplies (A - B) == 0 exactly (B is the window itself there), but
-  // it is the largest entry of the row by orders of magnitude when sigma is small; in the split
-  // sums below its two copies would cancel only to fp32 round-off (measured 2.4e-4 of max|grad|
-  // at sigma = 0.004).  Dropping it is exact.
-  __syncthreads();
-  if (tid < JOBS) gt[tid * CHG + HP * S + HP] = 0.f;
-  // centre windows A (reflect by index mirroring)
-  for (int j = 0; j < JOBS; ++j) {
-    const int b = sh_edge[j * 4 + 0], y = sh_edge[j * 4 + 1], x = sh_edge[j * 4 + 2];
-    for (int e = tid; e < C * KW * KW; e += WG) {
-      const int c = e / (KW * KW), r = e - c * KW * KW, kh = r / KW, kx = r - kh * KW;
-      at[(j * C) * KW * KW + e] =
-          p.img[(((size_t)b * C + c) * H + reflect_idx(y - HK + kh, H)) * W + reflect_idx(x - HK + kx, W)];
-    }
-  }
-  __syncthreads();
-  {  // sum_p G per job
-    float ls = 0.f;
-    if (lane_on)
-      for (int e = m; e < P; e += LPJ) {
-        const int py = e / KS;
-        ls += tg[py * S + (e - py * KS)];
-      }
-    red2[tid] = ls;
-    __syncthreads();
-    if (tid < JOBS) {
-      float t = 0.f;
-      for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
-      jsc[tid * 4 + 1] = t;
-    }
-    __syncthreads();
-  }
-  const float sumG = jsc[jl * 4 + 1];
-
-  // ---- per-lane block of tile positions ----
-  const int by = m / NB, bx = m - by * NB;
-  const int ry0 = BS * by - HK, cx0 = BS * bx - HK;
-  bool colv[PW];
-#pragma unroll
-  for (int j = 0; j < PW; ++j) colv[j] = (unsigned)(cx0 + j) < (unsigned)KS;
   const float *zrow = zero + HK;
-  const int eb = sh_edge[jl * 4 + 0], ey = sh_edge[jl * 4 + 1], ex = sh_edge[jl * 4 + 2];
-
-  // window sum of Gz around every owned t (channel independent): separable k_w x k_w box filter
-  // through LDS -- horizontal k_w-tap sums of the job's G tile into its (still unused)
-  // reduction slice, then vertical k_w-tap sums into registers.
-  float box[BS][BS];
-  {
-    float *hsum = red + jl * (KHC * KW) * LPJ;  // [KS][KS]
-    if (lane_on)
-      for (int e = m; e < P; e += LPJ) {
-        const int y = e / KS, x = e - y * KS;
-        float t = 0.f;
-#pragma unroll
-        for (int kx = -HK; kx <= HK; ++kx) {
-          const int xx = x + kx;
-          t += (unsigned)xx < (unsigned)KS ? tg[y * S + xx] : 0.f;
-        }
-        hsum[e] = t;
-      }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < BS; ++i)
-#pragma unroll
-      for (int j = 0; j < BS; ++j) {
-        const int ty = BS * by + i, tx = BS * bx + j;
-        float t = 0.f;
-        if (ty < KS && tx < KS) {
-#pragma unroll
-          for (int kh = -HK; kh <= HK; ++kh) {
-            const int yy = ty + kh;
-            t += (unsigned)yy < (unsigned)KS ? hsum[yy * KS + tx] : 0.f;
-          }
-        }
-        box[i][j] = t;
-      }
-    __syncthreads();
-  }
+  float l1p = 0.f, klp = 0.f;
+  const bool need_grad = p.grad != nullptr;
 
   // Barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global
   // atomics (a __syncthreads() would drain vmcnt and stall every barrier behind the atomics'
   // L2 round trip -- 73 % of wave time was spent there).
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  // image offset of tile position (ty,tx) of this job; callers guard ty,tx < KS
-  auto img_off = [&](int ty, int tx) -> int {
-    return reflect_idx(ey - HP + ty, H) * W + reflect_idx(ex - HP + tx, W);
-  };
-  // (`fence` is an opaque zero produced by an asm AFTER pass A: it pins the address arithmetic
-  // and the loads below that point, so hipcc cannot keep 50 VGPRs of offsets and image values
-  // live across the unrolled pass)
-  auto load_sv = [&](int c, float (&sv)[BS][BS], int fence) {
-    const size_t cb = ((size_t)eb * C + c) * H * W;
+  {
+    const int mo = m;
+    const int by = mo / NB, bx = mo - by * NB;
+    const int ry0 = BS * by - HK, cx0 = BS * bx - HK;
+    bool colv[PW];
 #pragma unroll
-    for (int i = 0; i < BS; ++i)
-#pragma unroll
-      for (int j = 0; j < BS; ++j) {
-        const int ty = BS * by + i, tx = BS * bx + j;
-        const bool in = ty < KS && tx < KS;
-        sv[i][j] = in ? p.img[cb + fence + img_off(in ? ty : 0, in ? tx : 0)] : 0.f;
-      }
-  };
+    for (int j = 0; j < PW; ++j) colv[j] = (unsigned)(cx0 + j) < (unsigned)KS;
+    const int eb = sh_edge[jl * 4 + 0], ey = sh_edge[jl * 4 + 1], ex = sh_edge[jl * 4 + 2];
+    const int n = sh_edge[jl * 4 + 3];
+    const bool job_on = lane_on && n >= 0;
 
-  float *gst = red + jl * SL * LPJ;           // job's gradient staging tile [KS][KS], aliases its slice
-  static_assert(SL * LPJ >= P, "staging tile must fit the reduction slice");
-
-#pragma unroll 1
-  for (int c = 0; c < C; ++c) {
-    const size_t cbase = ((size_t)eb * C + c) * H * W;
-    const float *ac = at + (jl * C + c) * KW * KW;
-
-    // ---- pass A: acc[t] = sum_k' Gz[t+k'] * A[c,-k'] ----
-    float acc[BS][BS];
-#pragma unroll
-    for (int i = 0; i < BS; ++i)
-#pragma unroll
-      for (int j = 0; j < BS; ++j) acc[i][j] = 0.f;
-    if constexpr (KW <= 9) {
-      float af[KW][KW];
-#pragma unroll
-      for (int kh = 0; kh < KW; ++kh)
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) af[kh][kx] = ac[(KW - 1 - kh) * KW + (KW - 1 - kx)];
-      float bn[PW];
-      load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
-#pragma unroll
-      for (int r = 0; r < PW; ++r) {
-        float bv[PW];
-#pragma unroll
-        for (int j = 0; j < PW; ++j) bv[j] = bn[j];
-        if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
-#pragma unroll
-        for (int i = 0; i < BS; ++i) {
-          const int kh = r - i;
-          if (kh < 0 || kh >= KW) continue;
-#pragma unroll
-          for (int j = 0; j < BS; ++j)
-#pragma unroll
-            for (int kx = 0; kx < KW; ++kx) acc[i][j] = __builtin_fmaf(af[kh][kx], bv[j + kx], acc[i][j]);
-        }
-        pin_block<BS, BS>(acc);
-      }
-    } else {
-#pragma unroll 1
-      for (int r = 0; r < PW; ++r) {
-        float bv[PW];
-        load_grow<G>(tg, zrow, ry0 + r, cx0, colv, bv);
-#pragma unroll
-        for (int i = 0; i < BS; ++i) {
-          const int kh = r - i;
-          if (kh < 0 || kh >= KW) continue;
-          const float *ar = ac + (KW - 1 - kh) * KW;
-#pragma unroll
-          for (int kx = 0; kx < KW; ++kx) {
-            const float av = ar[KW - 1 - kx];
-#pragma unroll
-            for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(av, bv[j + kx], acc[i][j]);
-          }
-        }
-      }
-    }
-    // S[c,t] of the owned block: loaded only now (pass A's register footprint is acc + stencil
-    // + two patch rows + box); the previous channel's atomics were issued a whole pass ago, so
-    // the in-order vmcnt wait behind them is short
-    float sv[BS][BS];
+    // ---- stage 1: G tile of each job.  Every global load of the row is issued before the first
+    // use (EPL independent loads per source; a rolled loop paid one L2 latency per element) ----
     {
-      int fz = 0;
-      asm volatile("" : "+v"(fz)::"memory");
-      load_sv(c, sv, fz);
-    }
-    // gS[c,t] = -2 (acc - S box), kept in registers until the staging tile is free
+      const size_t base = (size_t)(job_on ? n : 0) * P;
+      float va[EPL], vg[EPL];
+      const bool direct = p.mode == GRAD_D || (p.dbg & 1);
+      const float *src_a = direct ? (p.mode == GRAD_D ? p.gin : p.ssg) : p.ssg;
+      const float *src_b = p.mode == GRAD_S ? p.gin : p.ssg2;
 #pragma unroll
-    for (int i = 0; i < BS; ++i)
-#pragma unroll
-      for (int j = 0; j < BS; ++j) acc[i][j] = -2.f * (acc[i][j] - sv[i][j] * box[i][j]);
-
-    // ---- pass B: P[k'] = sum_t Gz[t+k'] * S[c,t], KHC stencil rows at a time ----
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int kh0 = ch * KHC;
-      float pp[KHC][KW];
-#pragma unroll
-      for (int a = 0; a < KHC; ++a)
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) pp[a][kx] = 0.f;
-      // patch rows r = kh' + i, kh' in [kh0, kh0+KHC), i in [0,BS)
-      float bn[PW];
-      load_grow<G>(tg, zrow, ry0 + kh0, cx0, colv, bn);
-#pragma unroll
-      for (int rr = 0; rr < KHC + BS - 1; ++rr) {
-        float bv[PW];
-#pragma unroll
-        for (int j = 0; j < PW; ++j) bv[j] = bn[j];
-        if (rr + 1 < KHC + BS - 1) load_grow<G>(tg, zrow, ry0 + kh0 + rr + 1, cx0, colv, bn);
-#pragma unroll
-        for (int a = 0; a < KHC; ++a) {
-          const int i = rr - a;  // block row paired with stencil row kh0+a on this patch row
-          if (i < 0 || i >= BS) continue;
-#pragma unroll
-          for (int j = 0; j < BS; ++j)
-#pragma unroll
-            for (int kx = 0; kx < KW; ++kx) pp[a][kx] = __builtin_fmaf(bv[j + kx], sv[i][j], pp[a][kx]);
-        }
-        pin_block<KHC, KW>(pp);
+      for (int k = 0; k < EPL; ++k) {
+        const int e = mo + k * LPJ;
+        va[k] = (job_on && e < P) ? src_a[base + e] : 0.f;
       }
-      // reduce the slice across the job's lanes (fixed order)
+      if (!direct) {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+          const int e = mo + k * LPJ;
+          vg[k] = (job_on && e < P) ? src_b[base + e] : 0.f;
+        }
+        const float invM = 1.f / ((float)nrows * (float)P);
+        const float u1 = p.upstream ? p.upstream[0] : 1.f, u2 = p.upstream ? p.upstream[1] : 1.f;
+        const float w1m = p.w_l1 * invM * u1, w2m = p.w_kl * invM * u2;
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+          const int e = mo + k * LPJ;
+          float g = 0.f;
+          if (job_on && e < P) g = p.mode == GRAD_S ? vg[k] : criteria_elem(va[k], vg[k], w1m, w2m, l1p, klp);
+          vg[k] = g;
+          dot = __builtin_fmaf(g, va[k], dot);
+        }
+        red2[tid] = dot;
+        __syncthreads();
+        if (tid < JOBS) {
+          float t = 0.f;
+          for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
+          jsc[tid * 4 + 0] = p.generalization ? t : 0.f;
+        }
+        __syncthreads();
+        dot = jsc[jl * 4 + 0];
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) va[k] = -(va[k] * kfac) * (vg[k] - dot);
+      }
       if (lane_on) {
 #pragma unroll
-        for (int a = 0; a < KHC; ++a)
-#pragma unroll
-          for (int kx = 0; kx < KW; ++kx) red[(jl * SL + a * KW + kx) * LPJ + m] = pp[a][kx];
-      }
-      lds_barrier();
-      if (lane_on)
-        for (int o = m; o < SL; o += LPJ) {
-          const int khp = kh0 + o / KW;
-          if (khp < KW) {
-            const float *rp = red + (jl * SL + o) * LPJ;
-            float t = 0.f;
-            for (int k = 0; k < LPJ; ++k) t += rp[k];
-            const int kh = KW - 1 - khp, kx = KW - 1 - (o % KW);  // k = -k'
-            gwin[jl * KW * KW + kh * KW + kx] = 2.f * (ac[kh * KW + kx] * sumG - t);  // unique owner
+        for (int k = 0; k < EPL; ++k) {
+          const int e = mo + k * LPJ;
+          if (e < P) {
+            const int py = e / KS, px = e - py * KS;
+            tg[py * S + px] = va[k];
           }
         }
-      lds_barrier();
+      }
     }
+    if (p.mode == GRAD_LOSS) {  // criteria partial sums of this workgroup
+      __syncthreads();
+      red2[tid] = l1p;
+      __syncthreads();
+      float t1 = 0.f, t2 = 0.f;
+      if (tid == 0)
+        for (int k = 0; k < WG; ++k) t1 += red2[k];
+      __syncthreads();
+      red2[tid] = klp;
+      __syncthreads();
+      if (tid == 0) {
+        for (int k = 0; k < WG; ++k) t2 += red2[k];
+        p.partials[2 * blockIdx.x] = t1;
+        p.partials[2 * blockIdx.x + 1] = t2;
+      }
+    }
+    if (need_grad) {
+    // G at the centre offset multiplies (A - B) == 0 exactly (B is the window itself there), but
+    // it is the largest entry of the row by orders of magnitude when sigma is small; in the split
+    // sums below its two copies would cancel only to fp32 round-off (measured 2.4e-4 of
+    // max|grad| at sigma = 0.004).  Dropping it is exact.
+    __syncthreads();
+    if (tid < JOBS) gt[tid * CHG + HP * S + HP] = 0.f;
+    // centre windows A (reflect by index mirroring); loads of all jobs in flight together
+    {
+      constexpr int APT = (3 * KW * KW + WG - 1) / WG;  // elements per thread per job when C <= 3
+      if (C <= 3) {
+        float v[JOBS][APT];
+#pragma unroll
+        for (int j = 0; j < JOBS; ++j) {
+          const int b = sh_edge[j * 4 + 0], y = sh_edge[j * 4 + 1], x = sh_edge[j * 4 + 2];
+#pragma unroll
+          for (int k = 0; k < APT; ++k) {
+            const int e = tid + k * WG;
+            const int ec = e < C * KW * KW ? e : 0;
+            const int c = ec / (KW * KW), r = ec - c * KW * KW, kh = r / KW, kx = r - kh * KW;
+            v[j][k] =
+                p.img[(((size_t)b * C + c) * H + reflect_idx(y - HK + kh, H)) * W + reflect_idx(x - HK + kx, W)];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < JOBS; ++j)
+#pragma unroll
+          for (int k = 0; k < APT; ++k) {
+            const int e = tid + k * WG;
+            if (e < C * KW * KW) at[(j * C) * KW * KW + e] = v[j][k];
+          }
+      } else {
+        for (int j = 0; j < JOBS; ++j) {
+          const int b = sh_edge[j * 4 + 0], y = sh_edge[j * 4 + 1], x = sh_edge[j * 4 + 2];
+          for (int e = tid; e < C * KW * KW; e += WG) {
+            const int c = e / (KW * KW), r = e - c * KW * KW, kh = r / KW, kx = r - kh * KW;
+            at[(j * C) * KW * KW + e] =
+                p.img[(((size_t)b * C + c) * H + reflect_idx(y - HK + kh, H)) * W + reflect_idx(x - HK + kx, W)];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {  // sum_p G per job
+      float ls = 0.f;
+      if (lane_on) {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+          const int e = mo + k * LPJ, py = e / KS;
+          if (e < P) ls += tg[py * S + (e - py * KS)];
+        }
+      }
+      red2[tid] = ls;
+      __syncthreads();
+      if (tid < JOBS) {
+        float t = 0.f;
+        for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
+        jsc[tid * 4 + 1] = t;
+      }
+      __syncthreads();
+    }
+    const float sumG = jsc[jl * 4 + 1];
 
-    // ---- stage the job's C-channel gradient tile in LDS, merge the window part ----
-    if (lane_on) {
+    // window sum of Gz around every owned t (channel independent): separable k_w x k_w box filter
+    // through LDS -- horizontal k_w-tap sums of the job's G tile into its (still unused)
+    // reduction slice, then vertical k_w-tap sums into registers.
+    float box[BS][BS];
+    {
+      float *hsum = red + jl * SL * LPJ;  // [KS][KS]
+      if (lane_on) {
+#pragma unroll 5
+        for (int k = 0; k < EPL; ++k) {
+          const int e = mo + k * LPJ;
+          const int ec = e < P ? e : 0;
+          const int y = ec / KS, x = ec - y * KS;
+          float t = 0.f;
+#pragma unroll
+          for (int kx = -HK; kx <= HK; ++kx) {
+            const int xx = x + kx;
+            const int xc = xx < 0 ? 0 : (xx >= KS ? KS - 1 : xx);  // clamped address, value selected
+            const float v = tg[y * S + xc];
+            t += (unsigned)xx < (unsigned)KS ? v : 0.f;
+          }
+          if (e < P) hsum[e] = t;
+        }
+      }
+      __syncthreads();
 #pragma unroll
       for (int i = 0; i < BS; ++i)
 #pragma unroll
         for (int j = 0; j < BS; ++j) {
           const int ty = BS * by + i, tx = BS * bx + j;
-          if (ty < KS && tx < KS) gst[ty * KS + tx] = acc[i][j];
+          const int tyc = ty < KS ? ty : KS - 1, txc = tx < KS ? tx : KS - 1;
+          float t = 0.f;
+#pragma unroll
+          for (int kh = -HK; kh <= HK; ++kh) {
+            const int yy = tyc + kh;
+            const int yc = yy < 0 ? 0 : (yy >= KS ? KS - 1 : yy);
+            const float v = hsum[yc * KS + txc];
+            t += (unsigned)yy < (unsigned)KS ? v : 0.f;
+          }
+          box[i][j] = t;
+          if (j == BS - 1) pin_row<BS>(box[i]);  // keep at most one block row of LDS loads in flight
         }
+      __syncthreads();
     }
-    lds_barrier();
-    if (lane_on)
-      for (int o = m; o < KW * KW; o += LPJ) {
-        const int kh = o / KW, kx = o - kh * KW;
-        gst[(HP - HK + kh) * KS + (HP - HK + kx)] += gwin[jl * KW * KW + o];  // unique owner per (kh,kx)
+
+    // image offset of tile position (ty,tx) of this job; callers guard ty,tx < KS
+    auto img_off = [&](int ty, int tx) -> int {
+      return reflect_idx(ey - HP + ty, H) * W + reflect_idx(ex - HP + tx, W);
+    };
+    // (`fence` is an opaque zero produced by an asm AFTER pass A: it pins the address arithmetic
+    // and the loads below that point, so hipcc cannot keep 50 VGPRs of offsets and image values
+    // live across the unrolled pass)
+    auto load_sv = [&](int c, float (&sv)[BS][BS], int fence) {
+      const size_t cb = ((size_t)eb * C + c) * H * W;
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int ty = BS * by + i, tx = BS * bx + j;
+          const bool in = ty < KS && tx < KS;
+          sv[i][j] = in ? p.img[cb + fence + img_off(in ? ty : 0, in ? tx : 0)] : 0.f;
+        }
+    };
+
+    float *gst = red + jl * SL * LPJ;  // job's gradient staging tile [KS][KS], aliases its slice
+    static_assert(SL * LPJ >= P, "staging tile must fit the reduction slice");
+
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+      const size_t cbase = ((size_t)eb * C + c) * H * W;
+      const float *ac = at + (jl * C + c) * KW * KW;
+
+      // ---- pass A: acc[t] = sum_k' Gz[t+k'] * A[c,-k'] ----
+      float acc[BS][BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) acc[i][j] = 0.f;
+      if (p.dbg & 2) {
+      } else if constexpr (KW <= 9) {
+        float af[KW][KW];
+#pragma unroll
+        for (int kh = 0; kh < KW; ++kh)
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) af[kh][kx] = ac[(KW - 1 - kh) * KW + (KW - 1 - kx)];
+        float bn[PW];
+        load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
+#pragma unroll
+        for (int r = 0; r < PW; ++r) {
+          float bv[PW];
+#pragma unroll
+          for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+          if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const int kh = r - i;
+            if (kh < 0 || kh >= KW) continue;
+#pragma unroll
+            for (int j = 0; j < BS; ++j)
+#pragma unroll
+              for (int kx = 0; kx < KW; ++kx) acc[i][j] = __builtin_fmaf(af[kh][kx], bv[j + kx], acc[i][j]);
+          }
+          pin_block<BS, BS>(acc);
+        }
+      } else {
+#pragma unroll 1
+        for (int r = 0; r < PW; ++r) {
+          float bv[PW];
+          load_grow<G>(tg, zrow, ry0 + r, cx0, colv, bv);
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const int kh = r - i;
+            if (kh < 0 || kh >= KW) continue;
+            const float *ar = ac + (KW - 1 - kh) * KW;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+              const float av = ar[KW - 1 - kx];
+#pragma unroll
+              for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(av, bv[j + kx], acc[i][j]);
+            }
+          }
+        }
       }
-    lds_barrier();
-    // ---- flush: row-contiguous fp32 atomics, nothing waits for them ----
-    if (job_on)
-      for (int e = m; e < P; e += LPJ) {
-        const int ty = e / KS, tx = e - ty * KS;
-        unsafeAtomicAdd(p.grad + cbase + img_off(ty, tx), gst[e]);
+      // S[c,t] of the owned block: loaded only now (pass A's register footprint is acc + stencil
+      // + two patch rows + box)
+      float sv[BS][BS];
+      {
+        int fz = 0;
+        asm volatile("" : "+v"(fz)::"memory");
+        load_sv(c, sv, fz);
       }
-    lds_barrier();  // staging tile is the next channel's reduction slice
+      // gS[c,t] = -2 (acc - S box)
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) acc[i][j] = -2.f * (acc[i][j] - sv[i][j] * box[i][j]);
+
+      // ---- pass B: P[k'] = sum_t Gz[t+k'] * S[c,t], KHC stencil rows at a time ----
+#pragma unroll 1
+      for (int ch = 0; ch < ((p.dbg & 4) ? 0 : NCH); ++ch) {
+        const int kh0 = ch * KHC;
+        float pp[KHC][KW];
+#pragma unroll
+        for (int a = 0; a < KHC; ++a)
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) pp[a][kx] = 0.f;
+        // patch rows r = kh' + i, kh' in [kh0, kh0+KHC), i in [0,BS)
+        float bn[PW];
+        load_grow<G>(tg, zrow, ry0 + kh0, cx0, colv, bn);
+#pragma unroll
+        for (int rr = 0; rr < KHC + BS - 1; ++rr) {
+          float bv[PW];
+#pragma unroll
+          for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+          if (rr + 1 < KHC + BS - 1) load_grow<G>(tg, zrow, ry0 + kh0 + rr + 1, cx0, colv, bn);
+#pragma unroll
+          for (int a = 0; a < KHC; ++a) {
+            const int i = rr - a;  // block row paired with stencil row kh0+a on this patch row
+            if (i < 0 || i >= BS) continue;
+#pragma unroll
+            for (int j = 0; j < BS; ++j)
+#pragma unroll
+              for (int kx = 0; kx < KW; ++kx) pp[a][kx] = __builtin_fmaf(bv[j + kx], sv[i][j], pp[a][kx]);
+          }
+          pin_block<KHC, KW>(pp);
+        }
+        // reduce the slice across the job's lanes (fixed order)
+        if (lane_on) {
+#pragma unroll
+          for (int a = 0; a < KHC; ++a)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) red[(jl * SL + a * KW + kx) * LPJ + m] = pp[a][kx];
+        }
+        lds_barrier();
+        if (lane_on)
+          for (int o = m; o < SL; o += LPJ) {
+            const int khp = kh0 + o / KW;
+            if (khp < KW) {
+              const float *rp = red + (jl * SL + o) * LPJ;
+              float t = 0.f;
+              for (int k = 0; k < LPJ; ++k) t += rp[k];
+              const int kh = KW - 1 - khp, kx = KW - 1 - (o % KW);  // k = -k'
+              gwin[jl * KW * KW + kh * KW + kx] = 2.f * (ac[kh * KW + kx] * sumG - t);  // unique owner
+            }
+          }
+        lds_barrier();
+      }
+
+      // ---- stage the job's gradient tile of this channel in LDS, merge the window part ----
+      if (lane_on) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            const int ty = BS * by + i, tx = BS * bx + j;
+            if (ty < KS && tx < KS) gst[ty * KS + tx] = acc[i][j];
+          }
+      }
+      lds_barrier();
+      if (lane_on)
+        for (int o = m; o < KW * KW; o += LPJ) {
+          const int kh = o / KW, kx = o - kh * KW;
+          gst[(HP - HK + kh) * KS + (HP - HK + kx)] += gwin[jl * KW * KW + o];  // unique owner per (kh,kx)
+        }
+      lds_barrier();
+      // Merge window: when the workgroup's jobs are one image's edge pixels within 8 rows x 16
+      // columns (always, up to tile seams, in tile order), their tiles are summed in LDS first.
+      int my0 = 1 << 30, mx0 = 1 << 30, my1 = -1, mx1 = -1, mb0 = -1;
+      bool merge = p.order != nullptr;
+#pragma unroll
+      for (int j = 0; j < JOBS; ++j) {
+        if (sh_edge[j * 4 + 3] >= 0) {
+          const int b = sh_edge[j * 4 + 0], y = sh_edge[j * 4 + 1], x = sh_edge[j * 4 + 2];
+          if (mb0 < 0) mb0 = b;
+          merge = merge && b == mb0;
+          my0 = y < my0 ? y : my0;
+          my1 = y > my1 ? y : my1;
+          mx0 = x < mx0 ? x : mx0;
+          mx1 = x > mx1 ? x : mx1;
+        }
+      }
+      merge = merge && (my1 - my0) <= MH - KS && (mx1 - mx0) <= MW - KS;
+      if (merge) {
+        // ---- sum the jobs' tiles into the merge window, one job at a time (plain LDS RMW) ----
+#pragma unroll 1
+        for (int j = 0; j < JOBS; ++j) {
+          if (jl == j && job_on) {
+            float *mj = mwin + (ey - my0) * MS + (ex - mx0);
+#pragma unroll 5
+            for (int k = 0; k < EPL; ++k) {
+              const int e = m + k * LPJ;
+              if (e < P) {
+                const int ty = e / KS, tx = e - ty * KS;
+                mj[ty * MS + tx] += gst[e];
+              }
+            }
+          }
+          lds_barrier();
+        }
+        // ---- flush the window: one fp32 atomic per touched pixel, row-contiguous; re-zero ----
+        if (!(p.dbg & 8)) {
+          const size_t cb0 = ((size_t)mb0 * C + c) * H * W;
+          const int wh = my1 - my0 + KS, ww = mx1 - mx0 + KS;
+          for (int i = tid; i < MH * MW; i += WG) {
+            const int ry = i / MW, rx = i - ry * MW;
+            if (ry < wh && rx < ww) {
+              const float v = mwin[ry * MS + rx];
+              mwin[ry * MS + rx] = 0.f;
+              if (v != 0.f)
+                unsafeAtomicAdd(p.grad + cb0 + (size_t)reflect_idx(my0 - HP + ry, H) * W + reflect_idx(mx0 - HP + rx, W), v);
+            }
+          }
+        }
+        lds_barrier();
+      } else {
+        // ---- flush per job: row-contiguous fp32 atomics, nothing waits for them ----
+        if (job_on && !(p.dbg & 8)) {
+#pragma unroll 5
+          for (int k = 0; k < EPL; ++k) {
+            const int e = m + k * LPJ;
+            if (e < P) {
+              const int ty = e / KS, tx = e - ty * KS;
+              unsafeAtomicAdd(p.grad + cbase + img_off(ty, tx), gst[e]);
+            }
+          }
+        }
+        lds_barrier();  // staging tile is the next channel's reduction slice
+      }
+    }
+    }  // need_grad
   }
+
 }
 
 // Any odd (ks, kw): one 256-lane workgroup per edge pixel.
@@ -431,8 +552,9 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
     }
     return;
   }
-  const Edge e = load_edge(p.edges, p.estride, n);
-  const size_t base = (size_t)n * P;
+  const int row = p.order ? p.order[n] : n;
+  const Edge e = load_edge(p.edges, p.estride, row);
+  const size_t base = (size_t)row * P;
   const float kfac = 1.f / (p.sigma * (float)(C * K2));
   float l1p = 0.f, klp = 0.f;
   if (p.mode == GRAD_D) {
@@ -547,13 +669,13 @@ __global__ void ssg_loss_finalize(const float *partials, int nparts, const int *
 template <class G, int KHC>
 static size_t bwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
+  constexpr int MH = G::KS + 7, MS = G::KS + 16;
   return sizeof(float) * (size_t)(PADF + G::JOBS * G::CH + ((G::ZROW + 3) & ~3) + G::JOBS * KHC * G::KW * G::LPJ +
-                                  G::WG + G::JOBS * 4 + G::JOBS * (C + 1) * G::KW * G::KW + 8) +
-         sizeof(int) * 4 * G::JOBS;
+                                  G::WG + G::JOBS * 4 + G::JOBS * 4 + G::JOBS * (C + 1) * G::KW * G::KW + MH * MS + 8);
 }
 
 template <class G, int KHC>
-static int launch_bwd_tiled(const BwdParams &p, hipStream_t st, unsigned *grid_out) {
+static int launch_bwd_tiled(const BwdParams &p, hipStream_t st) {
   const size_t lds = bwd_lds_bytes<G, KHC>(p.C);
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;
@@ -563,22 +685,29 @@ static int launch_bwd_tiled(const BwdParams &p, hipStream_t st, unsigned *grid_o
     attr_set = true;
   }
   const unsigned grid = (unsigned)((p.n_host + G::JOBS - 1) / G::JOBS);
-  if (grid_out) *grid_out = grid;
   if (p.n_host == 0) return 0;
   hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(grid), dim3(G::WG), lds, st, p);
   return (int)hipGetLastError();
 }
 
-// Number of workgroups (= rows of `partials`) launch_bwd will use for n rows.
-unsigned bwd_grid(int ks, int kw, int n) {
-  if (ks == 25 && kw == 9) return (unsigned)((n + Geo<25, 9, 5, 128>::JOBS - 1) / Geo<25, 9, 5, 128>::JOBS);
-  if (ks == 11 && kw == 5) return (unsigned)((n + Geo<11, 5, 4, 64>::JOBS - 1) / Geo<11, 5, 4, 64>::JOBS);
-  return (unsigned)n;
+// Number of workgroups (= rows of `partials`) launch_bwd will use.
+unsigned bwd_grid(const BwdParams &p) {
+  if (p.ks == 25 && p.kw == 9) return (unsigned)((p.n_host + Geo<25, 9, 5, 128>::JOBS - 1) / Geo<25, 9, 5, 128>::JOBS);
+  if (p.ks == 11 && p.kw == 5) return (unsigned)((p.n_host + Geo<11, 5, 4, 64>::JOBS - 1) / Geo<11, 5, 4, 64>::JOBS);
+  return (unsigned)p.n_host;
+}
+
+// Upper bound on bwd_grid() for scratch sizing.
+size_t bwd_max_partials(int B, int H, int W, int n_rows) {
+  (void)B;
+  (void)H;
+  (void)W;
+  return n_rows > 0 ? (size_t)n_rows : 1;
 }
 
 int launch_bwd(const BwdParams &p, hipStream_t st) {
-  if (p.ks == 25 && p.kw == 9) return launch_bwd_tiled<Geo<25, 9, 5, 128>, 3>(p, st, nullptr);
-  if (p.ks == 11 && p.kw == 5) return launch_bwd_tiled<Geo<11, 5, 4, 64>, 5>(p, st, nullptr);
+  if (p.ks == 25 && p.kw == 9) return launch_bwd_tiled<Geo<25, 9, 5, 128>, 3>(p, st);
+  if (p.ks == 11 && p.kw == 5) return launch_bwd_tiled<Geo<11, 5, 4, 64>, 5>(p, st);
   const size_t lds = sizeof(float) * ((size_t)(p.C + 1) * p.ks * p.ks + 256);
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;

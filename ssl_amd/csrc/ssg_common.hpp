@@ -107,6 +107,7 @@ struct FwdParams {
   int generalization;
   int raw;  // 1: out += D (reference operator)   0: SSG epilogue
   int ks, kw;  // used by the generic kernel only
+  int dbg;     // profiling ablations (0 in production): bit0 skip fill, bit1 skip compute, bit2 skip epilogue/store
 };
 
 // How the backward kernel obtains G = dL/dD for a job.
@@ -121,6 +122,7 @@ struct BwdParams {
   float *grad;       // (B,C,H,W), accumulated with fp32 atomics (may be null in GRAD_LOSS: loss only)
   const int *edges;
   int estride;
+  const int *order;  // nullable (n) int32: job k works on row order[k] (tile-major permutation of the rows)
   const int *n_dev;
   int n_host;
   int B, C, H, W;
@@ -134,6 +136,7 @@ struct BwdParams {
   const float *upstream;  // GRAD_LOSS, nullable: device {dL/dl1, dL/dkl}
   float *partials;  // GRAD_LOSS: (gridDim.x, 2) per-workgroup sums of |a-b| and t'(log t' - log s')
   int ks, kw;       // generic kernel only
+  int dbg;          // profiling ablations (0 in production): bit0 skip prologue math, bit1 skip pass A, bit2 skip pass B, bit3 skip atomics
 };
 
 __device__ __forceinline__ int rows_to_do(const int *n_dev, int n_host) {

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(1024) void edge_scan(const int *blockcnt, int *bloc
   }
 }
 
-__global__ __launch_bounds__(256) void edge_scatter(EdgeParams p, const int *blockoff, int *edges, int capacity) {
+__global__ __launch_bounds__(256) void edge_scatter(EdgeParams p, const int *blockoff, int *edges, int capacity,
+                                                    int *rank) {
   __shared__ int buf[256];
   int b, pix0;
   const unsigned bits = chunk_bits(p, b, pix0);
@@ -131,17 +132,21 @@ __global__ __launch_bounds__(256) void edge_scatter(EdgeParams p, const int *blo
     __syncthreads();
   }
   int pos = blockoff[blockIdx.x] + buf[tid] - c;
+  const int HW = p.H * p.W;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (bits & (1u << k)) {
-      if (pos < capacity) {
-        const int pix = pix0 + k, y = pix / p.W;
-        edges[3 * (size_t)pos + 0] = b;
-        edges[3 * (size_t)pos + 1] = y;
-        edges[3 * (size_t)pos + 2] = pix - y * p.W;
-      }
-      ++pos;
+  for (int k = 0; k < 4; ++k) {
+    const int pix = pix0 + k;
+    const bool on = bits & (1u << k);
+    if (on && pos < capacity) {
+      const int y = pix / p.W;
+      edges[3 * (size_t)pos + 0] = b;
+      edges[3 * (size_t)pos + 1] = y;
+      edges[3 * (size_t)pos + 2] = pix - y * p.W;
     }
+    // rank map: row index of every pixel (-1: not an edge pixel / beyond capacity)
+    if (rank && pix < HW) rank[(size_t)b * HW + pix] = (on && pos < capacity) ? pos : -1;
+    if (on) ++pos;
+  }
 }
 
 __global__ __launch_bounds__(256) void edge_mask_write(EdgeParams p, uint8_t *out) {
@@ -153,20 +158,90 @@ __global__ __launch_bounds__(256) void edge_mask_write(EdgeParams p, uint8_t *ou
     if (pix0 + k < HW) out[(size_t)b * HW + pix0 + k] = (bits >> k) & 1u;
 }
 
+// ---- tile-major job order for the backward kernel ----
+// order[k] = row of `edges` that job k works on: rows grouped by 8x8 image tile (tiles in
+// image-major, row-major order; row-major inside a tile), so consecutive jobs are spatial
+// neighbours.  Built from the rank map: one wave per tile.
+constexpr int OT = 8;
+
+__device__ __forceinline__ int tile_rank(const int *rank, int B, int H, int W, int tile, int lane, int &n_valid) {
+  const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT;
+  const int b = tile / (tx_n * ty_n), t = tile - b * tx_n * ty_n;
+  const int y = (t / tx_n) * OT + lane / OT, x = (t % tx_n) * OT + lane % OT;
+  (void)B;
+  n_valid = 0;
+  return (y < H && x < W) ? rank[((size_t)b * H + y) * W + x] : -1;
+}
+
+__global__ __launch_bounds__(256) void tile_count(const int *rank, int B, int H, int W, int ntiles, int *cnt) {
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (tile >= ntiles) return;
+  int nv;
+  const int r = tile_rank(rank, B, H, W, tile, lane, nv);
+  const unsigned long long bal = __ballot(r >= 0);
+  if (lane == 0) cnt[tile] = __popcll(bal);
+}
+
+__global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int n) {
+  __shared__ int buf[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n ? cnt[i] : 0;
+    buf[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = tid >= o ? buf[tid - o] : 0;
+      __syncthreads();
+      buf[tid] += t;
+      __syncthreads();
+    }
+    if (i < n) off[i] = carry + buf[tid] - v;
+    __syncthreads();
+    if (tid == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void tile_scatter(const int *rank, int B, int H, int W, int ntiles, const int *off,
+                                                    int *order, int capacity) {
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (tile >= ntiles) return;
+  int nv;
+  const int r = tile_rank(rank, B, H, W, tile, lane, nv);
+  const unsigned long long bal = __ballot(r >= 0);
+  if (r >= 0) {
+    const int pos = off[tile] + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pos < capacity) order[pos] = r;
+  }
+}
+
 // ------------------------------------------------------------------ host ----
+static size_t n_order_tiles(int B, int H, int W) { return (size_t)B * ((H + OT - 1) / OT) * ((W + OT - 1) / OT); }
+
 size_t edge_scratch_bytes(int B, int H, int W) {
   const size_t nblk = (size_t)B * (((size_t)H * W + CHUNK - 1) / CHUNK);
-  return 2 * nblk * sizeof(int) + 64;
+  return (2 * nblk + 2 * n_order_tiles(B, H, W)) * sizeof(int) + 64;
 }
 
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
-                     int *edges, int capacity, int *counts, void *scratch, hipStream_t st) {
+                     int *edges, int capacity, int *counts, int *rank, int *order, void *scratch, hipStream_t st) {
   EdgeParams p{mask, kind, mask_channels, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
   const int nblk = B * p.nblk_img;
   int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;
   hipLaunchKernelGGL(edge_count, dim3(nblk), dim3(256), 0, st, p, blockcnt);
   hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts);
-  hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity);
+  hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank);
+  if (order) {
+    const int nt = (int)n_order_tiles(B, H, W);
+    int *tcnt = blockoff + nblk, *toff = tcnt + nt;
+    hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt);
+    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt);
+    hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity);
+  }
   return (int)hipGetLastError();
 }
 

@@ -67,18 +67,45 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   if (tid < PADF) smem[tid] = 0.f;
   __syncthreads();
 
-  // ---- fill: JOBS x C x KS x KS floats, reflect by index mirroring ----
-  for (int j = 0; j < JOBS; ++j) {
+  // ---- fill: JOBS x C x KS x KS floats, reflect by index mirroring.  All global loads of a
+  // job are issued before the first LDS store (a plain loop pays the full L2 latency per
+  // element: the fill was 29 % of the kernel) ----
+  constexpr int EPT = (P + WG - 1) / WG;  // tile elements per thread per channel
+  for (int j = 0; j < ((p.dbg & 1) ? 0 : JOBS); ++j) {
     const int q = job0 + j;
     const int which = q < njobs ? q % p.nimg : 0;
     const float *src = p.img[which];
     const int b = sh_edge[j * 4 + 0], y = sh_edge[j * 4 + 1], x = sh_edge[j * 4 + 2];
-    for (int e = tid; e < P; e += WG) {
-      const int ry = e / KS, rx = e - ry * KS;
-      const int gy = reflect_idx(y - HP + ry, H), gx = reflect_idx(x - HP + rx, W);
-      const float *s0 = src + ((size_t)b * C * H + gy) * W + gx;
-      float *d0 = tiles + (j * C) * CH + ry * S + rx;
-      for (int c = 0; c < C; ++c) d0[c * CH] = s0[(size_t)c * H * W];
+    const float *s0[EPT];
+    int d0[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * WG;
+      const int ec = e < P ? e : P - 1;
+      const int ry = ec / KS, rx = ec - ry * KS;
+      s0[k] = src + ((size_t)b * C * H + reflect_idx(y - HP + ry, H)) * W + reflect_idx(x - HP + rx, W);
+      d0[k] = e < P ? (j * C) * CH + ry * S + rx : -1;
+    }
+    if (C == 3) {
+      float v[EPT][3];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[k][c] = s0[k][(size_t)c * H * W];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          if (d0[k] >= 0) tiles[d0[k] + c * CH] = v[k][c];
+    } else {
+      for (int c = 0; c < C; ++c) {
+        float v[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) v[k] = s0[k][(size_t)c * H * W];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+          if (d0[k] >= 0) tiles[d0[k] + c * CH] = v[k];
+      }
     }
   }
   __syncthreads();
@@ -102,7 +129,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
 
   const float *zrow = zero + HK;
 #pragma unroll 1
-  for (int c = 0; c < C; ++c) {
+  for (int c = 0; c < ((p.dbg & 2) ? 0 : C); ++c) {
     const float *tc = tiles + (jl * C + c) * CH;
     if constexpr (KW <= 9) {
       float a[KW][KW];  // centre window of this channel (uniform across the job's lanes)
@@ -186,16 +213,21 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
     return;
   }
 
+  if (p.dbg & 4) {
+    if (acc[0][0] == 123.456f) p.out[0][0] = acc[1][1];
+    return;
+  }
   // ---- epilogue: e = exp(-(D/den)/sigma), row sum, normalise ----
-  const float den = (float)(C * KW * KW);
+  // -(D/(C k_w^2))/sigma as one multiply by a host-rounded constant: |x| differs from the
+  // reference's two divisions by <= 1.5 ulp, i.e. e by < 1e-5 relative even at e ~ 1e-38
+  const float nk = -1.f / ((float)(C * KW * KW) * p.sigma);
   float lsum = 0.f;
 #pragma unroll
   for (int i = 0; i < BS; ++i)
 #pragma unroll
     for (int j = 0; j < BS; ++j) {
       const int py = BS * by + i, px = BS * bx + j;
-      const float qv = acc[i][j] / den;
-      const float e = (py < KS && px < KS) ? expf(-1.f * qv / p.sigma) : 0.f;
+      const float e = (py < KS && px < KS) ? expf(acc[i][j] * nk) : 0.f;
       acc[i][j] = e;
       lsum += e;
     }

@@ -30,6 +30,17 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+class EdgeList(tuple):
+    """(edges, counts) -- unpacks like the pair it always was -- plus `.rank`, the (B,H,W) int32
+    rank map (row of `edges` holding each pixel, -1 elsewhere), and `.order`, the tile-major
+    permutation of the rows that the backward kernels use as their job order."""
+
+    def __new__(cls, edges, counts, rank, order):
+        self = super().__new__(cls, (edges, counts))
+        self.edges, self.counts, self.rank, self.order = edges, counts, rank, order
+        return self
+
+
 def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=None):
     """Device-side edge list of a batch.
 
@@ -57,10 +68,13 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     dev = src.device
     edges = torch.empty((max(capacity, 1), 3), dtype=torch.int32, device=dev)
     counts = torch.empty(B + 2, dtype=torch.int32, device=dev)
+    rank = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    order = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
     scratch = torch.empty(L.ssg_edge_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
     _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold),
-                               _ptr(edges), capacity, _ptr(counts), _ptr(scratch), _stream()))
-    return edges, counts
+                               _ptr(edges), capacity, _ptr(counts), _ptr(rank), _ptr(order), _ptr(scratch),
+                               _stream()))
+    return EdgeList(edges, counts, rank, order)
 
 
 def edge_mask_laplacian(gt, lap_threshold=20.0, mask_stride=0):
@@ -80,7 +94,7 @@ class _SSGMapFn(torch.autograd.Function):
     """SSG rows of a batch for a given edge list (loss_util.py:182-244 + autograd)."""
 
     @staticmethod
-    def forward(ctx, img, edges, counts, n_rows, ks, kw, sigma, eps, generalization):
+    def forward(ctx, img, edges, counts, n_rows, ks, kw, sigma, eps, generalization, order):
         x = _f32c(img)
         B, C, H, W = x.shape
         ssg = torch.empty((n_rows, ks * ks), dtype=torch.float32, device=x.device)
@@ -88,6 +102,7 @@ class _SSGMapFn(torch.autograd.Function):
                                               float(sigma), float(eps), int(bool(generalization)), _ptr(ssg), None,
                                               _stream()))
         ctx.save_for_backward(x, edges, counts, ssg)
+        ctx.order = order
         ctx.cfg = (n_rows, ks, kw, float(sigma), int(bool(generalization)))
         return ssg
 
@@ -99,22 +114,23 @@ class _SSGMapFn(torch.autograd.Function):
         B, C, H, W = x.shape
         g = _f32c(grad_ssg)
         grad = torch.zeros_like(x)
-        _lib.check(_lib.lib().ssg_map_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw, sigma,
-                                               gen, _ptr(ssg), _ptr(g), _ptr(grad), _stream()))
-        return grad, None, None, None, None, None, None, None, None
+        _lib.check(_lib.lib().ssg_map_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(ctx.order), _ptr(counts), n_rows,
+                                               ks, kw, sigma, gen, _ptr(ssg), _ptr(g), _ptr(grad), _stream()))
+        return grad, None, None, None, None, None, None, None, None, None
 
 
-def ssg_map(img, edges, counts, n_rows, ks, kw, sigma, eps=1e-10, generalization=True):
-    """(n_rows, ks*ks) SSG rows of `img` (B,C,H,W) at `edges`; differentiable w.r.t. img."""
-    _need_gpu(img, edges, counts)
-    return _SSGMapFn.apply(img, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization)
+def ssg_map(img, edges, counts, n_rows, ks, kw, sigma, eps=1e-10, generalization=True, order=None):
+    """(n_rows, ks*ks) SSG rows of `img` (B,C,H,W) at `edges`; differentiable w.r.t. img.
+    `order` (EdgeList.order) is the backward kernel's tile-major job order."""
+    _need_gpu(img, edges, counts, order)
+    return _SSGMapFn.apply(img, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization, order)
 
 
 class _SSGLossFn(torch.autograd.Function):
     """(l1, kl) of the caller loop realesrganssl_model.py:379-430 over a batch."""
 
     @staticmethod
-    def forward(ctx, sr, gt, edges, counts, n_rows, ks, kw, sigma, eps, generalization, w_l1, w_kl):
+    def forward(ctx, sr, gt, edges, counts, n_rows, ks, kw, sigma, eps, generalization, w_l1, w_kl, order):
         L = _lib.lib()
         x, y = _f32c(sr), _f32c(gt)
         B, C, H, W = x.shape
@@ -123,13 +139,14 @@ class _SSGLossFn(torch.autograd.Function):
         ssg_sr = torch.empty((max(n_rows, 1), P), dtype=torch.float32, device=dev)
         ssg_gt = torch.empty((max(n_rows, 1), P), dtype=torch.float32, device=dev)
         loss = torch.zeros(2, dtype=torch.float32, device=dev)
-        scratch = torch.empty(L.ssg_loss_scratch_bytes(n_rows, ks), dtype=torch.uint8, device=dev)
+        scratch = torch.empty(L.ssg_loss_scratch_bytes(B, H, W, n_rows, ks), dtype=torch.uint8, device=dev)
         gen = int(bool(generalization))
         _lib.check(L.ssg_map_forward(_ptr(x), _ptr(y), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw,
                                      float(sigma), float(eps), gen, _ptr(ssg_sr), _ptr(ssg_gt), _stream()))
-        _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw, float(sigma),
-                                       gen, _ptr(ssg_sr), _ptr(ssg_gt), float(w_l1), float(w_kl), None, _ptr(loss),
-                                       None, _ptr(scratch), _stream()))
+        _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(order), _ptr(counts), n_rows, ks, kw,
+                                       float(sigma), gen, _ptr(ssg_sr), _ptr(ssg_gt), float(w_l1), float(w_kl), None,
+                                       _ptr(loss), None, _ptr(scratch), _stream()))
+        ctx.order = order
         ctx.save_for_backward(x, edges, counts, ssg_sr, ssg_gt, scratch)
         ctx.cfg = (n_rows, ks, kw, float(sigma), gen, float(w_l1), float(w_kl))
         ctx.ssg = (ssg_sr, ssg_gt)
@@ -144,18 +161,18 @@ class _SSGLossFn(torch.autograd.Function):
         up = torch.stack([g_l1.to(torch.float32).reshape(()), g_kl.to(torch.float32).reshape(())]).contiguous()
         grad = torch.zeros_like(x)
         dummy = torch.empty(2, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw, sigma,
-                                                gen, _ptr(ssg_sr), _ptr(ssg_gt), w_l1, w_kl, _ptr(up), _ptr(dummy),
-                                                _ptr(grad), _ptr(scratch), _stream()))
-        return (grad,) + (None,) * 11
+        _lib.check(_lib.lib().ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(ctx.order), _ptr(counts), n_rows,
+                                                ks, kw, sigma, gen, _ptr(ssg_sr), _ptr(ssg_gt), w_l1, w_kl, _ptr(up),
+                                                _ptr(dummy), _ptr(grad), _ptr(scratch), _stream()))
+        return (grad,) + (None,) * 12
 
 
 def ssg_loss(sr, gt, edges, counts, n_rows, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0,
-             w_kl=1.0):
+             w_kl=1.0, order=None):
     """Differentiable (l1, kl) for a batch given a device edge list; n_rows bounds N."""
-    _need_gpu(sr, gt, edges, counts)
+    _need_gpu(sr, gt, edges, counts, order)
     return _SSGLossFn.apply(sr, gt, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization, w_l1,
-                            w_kl)
+                            w_kl, order)
 
 
 class LossStep:

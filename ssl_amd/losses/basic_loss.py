@@ -85,8 +85,8 @@ class SSGLoss(nn.Module):
     def forward(self, sr, gt, mask=None):
         B, C, H, W = sr.shape
         cap = self.capacity if self.capacity is not None else B * H * W
-        edges, counts = engine.edge_list(mask=mask, gt=gt if mask is None else None, mask_stride=self.mask_stride,
-                                         lap_threshold=self.lap_threshold, capacity=cap)
-        self.last_counts = counts
-        return engine.ssg_loss(sr, gt.detach(), edges, counts, cap, self.ks, self.kw, self.sigma, self.eps,
-                               self.generalization, self.w_l1, self.w_kl)
+        el = engine.edge_list(mask=mask, gt=gt if mask is None else None, mask_stride=self.mask_stride,
+                              lap_threshold=self.lap_threshold, capacity=cap)
+        self.last_counts = el.counts
+        return engine.ssg_loss(sr, gt.detach(), el.edges, el.counts, cap, self.ks, self.kw, self.sigma, self.eps,
+                               self.generalization, self.w_l1, self.w_kl, order=el.order)

@@ -331,3 +331,48 @@ def test_gradient_of_one_image_vs_oracle_paper_sizes(dev):
     (l1 + kl).backward()
     assert abs(float(l1) - ref["l1"]) <= 1e-5 * ref["l1"] and abs(float(kl) - ref["kl"]) <= 1e-5 * ref["kl"] + 2e-8
     assert maxerr(x.grad.cpu(), ref["grad"]) <= grad_tol_from_oracle(sr, gt, mask, ks, kw, sigma, ref)
+
+
+def test_region_and_list_backward_agree_odd_sizes(dev):
+    """Tile-major job order + on-chip merge of neighbouring gradient tiles vs the plain row-order
+    backward: two schedules of the same sums; they must agree to fp32 summation-order noise, also
+    when H, W are not multiples of the 8-pixel tile and search areas hang over every border."""
+    from ssl_amd import engine, synth
+    ks, kw, sigma = 25, 9, 0.05
+    B, H, W = 2, 45, 51
+    gt = np.stack([synth.natural_like(950 + i, H, W, 0.12, 0.04) for i in range(B)])
+    sr = np.stack([synth.degrade(gt[i], 960 + i, 0.05) for i in range(B)])
+    masks = np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(B)])
+    masks[:, 0, 0] = masks[:, -1, -1] = masks[:, 0, -1] = masks[:, -1, 0] = 1
+    tgt, tm = T(gt, dev), T(masks[:, None], dev)
+    el = engine.edge_list(mask=tm)
+    n = int(el.counts[0])
+    assert n == int(masks.sum())
+    rk = el.rank.cpu().numpy()
+    assert np.array_equal(rk >= 0, masks.astype(bool)) and np.array_equal(np.sort(rk[rk >= 0]), np.arange(n))
+    od = el.order[:n].cpu().numpy()
+    assert np.array_equal(np.sort(od), np.arange(n))          # a permutation of the rows ...
+    e_np = el.edges[:n].cpu().numpy()[od]
+    tkey = (e_np[:, 0] * 1000 + e_np[:, 1] // 8) * 1000 + e_np[:, 2] // 8
+    assert (np.diff(tkey) >= 0).all()                            # ... grouped by 8x8 tile, tiles ascending
+    grads = []
+    for order in (None, el.order):
+        x = T(sr, dev).requires_grad_(True)
+        l1, kl = engine.ssg_loss(x, tgt, el.edges, el.counts, n, ks, kw, sigma, 1e-10, True, 1e3, 1e3, order=order)
+        (l1 + 0.5 * kl).backward()
+        grads.append((float(l1), float(kl), x.grad.clone()))
+    assert grads[0][0] == grads[1][0] or abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[0][0])
+    assert abs(grads[0][1] - grads[1][1]) <= 1e-6 * abs(grads[0][1]) + 1e-9
+    gmax = float(grads[0][2].abs().max())
+    assert float((grads[0][2] - grads[1][2]).abs().max()) <= 2e-6 * gmax
+    ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), masks, ks, kw, sigma, 1e3, 0.5e3)
+    assert maxerr(grads[1][2].cpu(), ref["grad"]) <= grad_tol_from_oracle(sr, gt, masks, ks, kw, sigma, ref)
+    # similarity_map-style autograd (dL/dS given) through both schedules
+    cot = torch.randn(n, ks * ks, device=dev)
+    gm = []
+    for order in (None, el.order):
+        x = T(sr, dev).requires_grad_(True)
+        s = engine.ssg_map(x, el.edges, el.counts, n, ks, kw, sigma, 1e-10, True, order=order)
+        (s * cot).sum().backward()
+        gm.append(x.grad.clone())
+    assert float((gm[0] - gm[1]).abs().max()) <= 2e-6 * float(gm[0].abs().max())
