@@ -97,26 +97,41 @@ def stage_times(step, sr, gt, mask, n_edges, iters):
     return out
 
 
-def cpu_baseline(sr, gt, mask, budget_s=15.0):
-    """Oracle (C + OpenMP) timed on the host cores over a bounded sample of the batch."""
+def cpu_baseline(sr, gt, mask, budget_s=20.0):
+    """Oracle (C + OpenMP) timed on the host cores over a bounded sample of the batch
+    (about budget_s seconds of wall time: whole images, as many as fit)."""
     from oracle import ssg_oracle as orc
     cores = os.cpu_count() or 1
-    m0 = mask[:1, 0].copy()
-    ys, xs = np.nonzero(m0[0])
-    keep = np.zeros_like(m0)
-    keep[0, ys[:256], xs[:256]] = 1        # calibration: 256 edge pixels of image 0
+    orc.ssg_loss(sr[:1, :, :64, :64], gt[:1, :, :64, :64], mask[:1, 0, :64, :64], KS, KW, SIGMA, W_L1, W_KL)  # warm up
     t0 = time.time()
-    orc.ssg_loss(sr[:1], gt[:1], keep, KS, KW, SIGMA, W_L1, W_KL)
-    per_px = (time.time() - t0) / max(int(keep.sum()), 1)
-    per_img = per_px * float(mask[0].sum())
-    nimg = int(min(sr.shape[0], max(1, budget_s // max(per_img, 1e-3))))
-    t0 = time.time()
-    r = orc.ssg_loss(sr[:nimg], gt[:nimg], mask[:nimg, 0], KS, KW, SIGMA, W_L1, W_KL)
-    dt = time.time() - t0
+    r = orc.ssg_loss(sr[:1], gt[:1], mask[:1, 0], KS, KW, SIGMA, W_L1, W_KL)     # calibrate on image 0
+    per_img = max(time.time() - t0, 1e-3)
+    nimg = int(min(sr.shape[0], max(1, round(budget_s / per_img))))
+    if nimg > 1:
+        t0 = time.time()
+        r = orc.ssg_loss(sr[:nimg], gt[:nimg], mask[:nimg, 0], KS, KW, SIGMA, W_L1, W_KL)
+        dt = time.time() - t0
+    else:
+        dt = per_img
     return {"value": r["n_edges"] / dt, "unit": "edge-px/s", "cores": cores, "kind": "port",
-            "sample": f"first {nimg} of {sr.shape[0]} images ({r['n_edges']} edge px), fp32 C oracle with OpenMP "
-                      f"over edge pixels, {dt:.1f} s",
+            "sample": f"first {nimg} of {sr.shape[0]} images ({r['n_edges']} edge px), fp32 C oracle, OpenMP over "
+                      f"edge pixels on all {cores} host cores, {dt:.1f} s",
             "l1": r["l1"], "kl": r["kl"]}
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/pmc_traffic.json,
+    produced by tools/prof_pmc.sh + tools/pmc_to_json.py with the guide's unit / gfx950 corrections);
+    None if there is no entry for this kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        for k, v in t.get("kernels", {}).items():
+            if k.split("<")[0] in kernel_name and ("bwd" in k) == ("bwd" in kernel_name):
+                return v.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def main():
@@ -193,7 +208,7 @@ def main():
                        "input_checksum": synth.checksum(sr_np, gt_np, mask_np), "parallelism": f"images sharded x{world}",
                        "l1": float(loss[0]), "kl": float(loss[1])},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
                          "alg_bytes_per_edge_px": b_alg, "kernel_ms": stages,
                          "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS},
                          "valu": {"achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -64,7 +64,6 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   constexpr int SL = KHC * KW;               // partials per chunk
   constexpr int EPL = (P + LPJ - 1) / LPJ;   // row elements per lane
   constexpr int MH = KS + 7, MW = KS + 15;   // merge window: centres within 8 rows x 16 columns
-  constexpr int MS = MW + 1;                 // its LDS row stride
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = p.C, H = p.H, W = p.W;
@@ -76,7 +75,6 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   int *sh_edge = (int *)(jsc + JOBS * 4);     // [JOBS][4]: b, y, x, row
   float *at = (float *)(sh_edge + JOBS * 4);  // [JOBS][C][KW][KW] centre windows
   float *gwin = at + JOBS * C * KW * KW;      // [JOBS][KW][KW] window gradients of the current channel
-  float *mwin = gwin + JOBS * KW * KW;        // [MH][MS] merge window of the current channel
 
   const int tid = threadIdx.x;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
@@ -99,7 +97,6 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
     sh_edge[tid * 4 + 3] = row;
   }
   for (int i = tid; i < G::ZROW + 4; i += WG) zero[i] = 0.f;
-  for (int i = tid; i < MH * MS; i += WG) mwin[i] = 0.f;
   if (tid < PADF) smem[tid] = 0.f;
   __syncthreads();
 
@@ -262,48 +259,39 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
     }
     const float sumG = jsc[jl * 4 + 1];
 
-    // window sum of Gz around every owned t (channel independent): separable k_w x k_w box filter
-    // through LDS -- horizontal k_w-tap sums of the job's G tile into its (still unused)
-    // reduction slice, then vertical k_w-tap sums into registers.
+    // window sum of Gz around every owned t (channel independent), streamed like pass A: per
+    // patch row the k_w-tap horizontal sums, added to every block row the patch row pairs with
     float box[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) box[i][j] = 0.f;
     {
-      float *hsum = red + jl * SL * LPJ;  // [KS][KS]
-      if (lane_on) {
-#pragma unroll 5
-        for (int k = 0; k < EPL; ++k) {
-          const int e = mo + k * LPJ;
-          const int ec = e < P ? e : 0;
-          const int y = ec / KS, x = ec - y * KS;
-          float t = 0.f;
+      float bn[PW];
+      load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
 #pragma unroll
-          for (int kx = -HK; kx <= HK; ++kx) {
-            const int xx = x + kx;
-            const int xc = xx < 0 ? 0 : (xx >= KS ? KS - 1 : xx);  // clamped address, value selected
-            const float v = tg[y * S + xc];
-            t += (unsigned)xx < (unsigned)KS ? v : 0.f;
-          }
-          if (e < P) hsum[e] = t;
-        }
-      }
-      __syncthreads();
+      for (int r = 0; r < PW; ++r) {
+        float bv[PW];
 #pragma unroll
-      for (int i = 0; i < BS; ++i)
+        for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+        if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
+        float hs[BS];
 #pragma unroll
         for (int j = 0; j < BS; ++j) {
-          const int ty = BS * by + i, tx = BS * bx + j;
-          const int tyc = ty < KS ? ty : KS - 1, txc = tx < KS ? tx : KS - 1;
-          float t = 0.f;
+          float t = bv[j];
 #pragma unroll
-          for (int kh = -HK; kh <= HK; ++kh) {
-            const int yy = tyc + kh;
-            const int yc = yy < 0 ? 0 : (yy >= KS ? KS - 1 : yy);
-            const float v = hsum[yc * KS + txc];
-            t += (unsigned)yy < (unsigned)KS ? v : 0.f;
-          }
-          box[i][j] = t;
-          if (j == BS - 1) pin_row<BS>(box[i]);  // keep at most one block row of LDS loads in flight
+          for (int kx = 1; kx < KW; ++kx) t += bv[j + kx];
+          hs[j] = t;
         }
-      __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+          const int kh = r - i;
+          if (kh < 0 || kh >= KW) continue;
+#pragma unroll
+          for (int j = 0; j < BS; ++j) box[i][j] += hs[j];
+        }
+        pin_block<BS, BS>(box);
+      }
     }
 
     // image offset of tile position (ty,tx) of this job; callers guard ty,tx < KS
@@ -484,34 +472,31 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
       }
       merge = merge && (my1 - my0) <= MH - KS && (mx1 - mx0) <= MW - KS;
       if (merge) {
-        // ---- sum the jobs' tiles into the merge window, one job at a time (plain LDS RMW) ----
-#pragma unroll 1
-        for (int j = 0; j < JOBS; ++j) {
-          if (jl == j && job_on) {
-            float *mj = mwin + (ey - my0) * MS + (ex - mx0);
-#pragma unroll 5
-            for (int k = 0; k < EPL; ++k) {
-              const int e = m + k * LPJ;
-              if (e < P) {
-                const int ty = e / KS, tx = e - ty * KS;
-                mj[ty * MS + tx] += gst[e];
-              }
-            }
-          }
-          lds_barrier();
-        }
-        // ---- flush the window: one fp32 atomic per touched pixel, row-contiguous; re-zero ----
+        // ---- gather-merge: every lane owns pixels of the jobs' common window and sums the
+        // staged tiles that cover them (no LDS atomics, no per-job rounds), then issues ONE
+        // fp32 atomic per touched pixel, row-contiguous ----
         if (!(p.dbg & 8)) {
           const size_t cb0 = ((size_t)mb0 * C + c) * H * W;
           const int wh = my1 - my0 + KS, ww = mx1 - mx0 + KS;
-          for (int i = tid; i < MH * MW; i += WG) {
-            const int ry = i / MW, rx = i - ry * MW;
-            if (ry < wh && rx < ww) {
-              const float v = mwin[ry * MS + rx];
-              mwin[ry * MS + rx] = 0.f;
-              if (v != 0.f)
-                unsafeAtomicAdd(p.grad + cb0 + (size_t)reflect_idx(my0 - HP + ry, H) * W + reflect_idx(mx0 - HP + rx, W), v);
+          int dy[JOBS], dx[JOBS];
+#pragma unroll
+          for (int j = 0; j < JOBS; ++j) {
+            const bool on = sh_edge[j * 4 + 3] >= 0;
+            dy[j] = on ? sh_edge[j * 4 + 1] - my0 : -(1 << 20);
+            dx[j] = on ? sh_edge[j * 4 + 2] - mx0 : -(1 << 20);
+          }
+          for (int i = tid; i < wh * ww; i += WG) {
+            const int ry = i / ww, rx = i - ry * ww;
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < JOBS; ++j) {
+              const int ty = ry - dy[j], tx = rx - dx[j];
+              const bool in = (unsigned)ty < (unsigned)KS && (unsigned)tx < (unsigned)KS;
+              const float g = red[j * SL * LPJ + (in ? ty * KS + tx : 0)];
+              v += in ? g : 0.f;
             }
+            if (v != 0.f)
+              unsafeAtomicAdd(p.grad + cb0 + (size_t)reflect_idx(my0 - HP + ry, H) * W + reflect_idx(mx0 - HP + rx, W), v);
           }
         }
         lds_barrier();
@@ -669,9 +654,8 @@ __global__ void ssg_loss_finalize(const float *partials, int nparts, const int *
 template <class G, int KHC>
 static size_t bwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
-  constexpr int MH = G::KS + 7, MS = G::KS + 16;
   return sizeof(float) * (size_t)(PADF + G::JOBS * G::CH + ((G::ZROW + 3) & ~3) + G::JOBS * KHC * G::KW * G::LPJ +
-                                  G::WG + G::JOBS * 4 + G::JOBS * 4 + G::JOBS * (C + 1) * G::KW * G::KW + MH * MS + 8);
+                                  G::WG + G::JOBS * 4 + G::JOBS * 4 + G::JOBS * (C + 1) * G::KW * G::KW + 8);
 }
 
 template <class G, int KHC>

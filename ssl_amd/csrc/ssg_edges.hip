@@ -182,27 +182,28 @@ __global__ __launch_bounds__(256) void tile_count(const int *rank, int B, int H,
   if (lane == 0) cnt[tile] = __popcll(bal);
 }
 
+// exclusive scan of cnt[0..n): each of the 1024 lanes first sums a contiguous run of
+// ceil(n/1024) entries, one Hillis-Steele pass scans the 1024 run totals, then the runs are
+// re-walked to write the offsets (one workgroup, a handful of barriers).
 __global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int n) {
   __shared__ int buf[1024];
-  __shared__ int carry;
   const int tid = threadIdx.x;
-  if (tid == 0) carry = 0;
+  const int run = (n + 1023) / 1024;
+  const int lo = tid * run, hi = lo + run < n ? lo + run : n;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[i];
+  buf[tid] = s;
   __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const int v = i < n ? cnt[i] : 0;
-    buf[tid] = v;
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int t = tid >= o ? buf[tid - o] : 0;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int t = tid >= o ? buf[tid - o] : 0;
-      __syncthreads();
-      buf[tid] += t;
-      __syncthreads();
-    }
-    if (i < n) off[i] = carry + buf[tid] - v;
+    buf[tid] += t;
     __syncthreads();
-    if (tid == 1023) carry += buf[1023];
-    __syncthreads();
+  }
+  int acc = buf[tid] - s;
+  for (int i = lo; i < hi; ++i) {
+    off[i] = acc;
+    acc += cnt[i];
   }
 }
 
