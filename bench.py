@@ -149,7 +149,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ    # launched by torch.distributed.run (also with 1 rank)
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL on ROCm
 
@@ -163,7 +164,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -178,7 +179,7 @@ def main():
 
     tot_edges = torch.tensor([float(n_edges)], device=dev, dtype=torch.float64)
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tot_edges, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax)
@@ -220,7 +221,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(sr_np, gt_np, mask_np)
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

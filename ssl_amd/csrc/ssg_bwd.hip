@@ -347,9 +347,9 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
             const int kh = r - i;
             if (kh < 0 || kh >= KW) continue;
 #pragma unroll
-            for (int j = 0; j < BS; ++j)
+            for (int kx = 0; kx < KW; ++kx)  // tap-major: BS independent FMAs back to back
 #pragma unroll
-              for (int kx = 0; kx < KW; ++kx) acc[i][j] = __builtin_fmaf(af[kh][kx], bv[j + kx], acc[i][j]);
+              for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(af[kh][kx], bv[j + kx], acc[i][j]);
           }
           pin_block<BS, BS>(acc);
         }

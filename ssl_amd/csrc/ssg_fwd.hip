@@ -152,13 +152,17 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
         for (int i = 0; i < BS; ++i) {
           const int kh = r - i;
           if (kh < 0 || kh >= KW) continue;
+          // tap-major order: BS independent (sub, fma) pairs back to back, so consecutive
+          // instructions never wait on each other (accumulator-major order serialised every
+          // FMA behind the previous one on the same accumulator)
 #pragma unroll
-          for (int j = 0; j < BS; ++j)
+          for (int kx = 0; kx < KW; ++kx) {
+            float d[BS];
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-              const float d = a[kh][kx] - bv[j + kx];
-              acc[i][j] = __builtin_fmaf(d, d, acc[i][j]);
-            }
+            for (int j = 0; j < BS; ++j) d[j] = a[kh][kx] - bv[j + kx];
+#pragma unroll
+            for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(d[j], d[j], acc[i][j]);
+          }
         }
         pin_block<BS, BS>(acc);
       }
