@@ -424,3 +424,39 @@ def test_drop_in_training_step(dev):
         hist.append(float(l_selfsim) + float(l_selfsim_kl))
     assert int(crit.last_counts[0]) > 100
     assert hist[-1] < hist[0], hist
+
+
+def test_stress_kernel_sizes_loss_and_dense_mask(dev):
+    """BASELINE configs[4] kernel sizes (k_s=49, k_w=13): full loss + gradient vs the oracle on a sparse
+    mask, then a DENSE mask (every pixel an edge pixel) at 3x128x128 -- size-independent properties plus
+    oracle rows; the reference cannot materialise this case (its second unfold would be 1.28 TB at 512^2)."""
+    from ssl_amd import SSGLoss, engine, synth
+    ks, kw, sigma = 49, 13, 0.02
+    gt = synth.natural_like(1300, 72, 80)[None]
+    sr = synth.degrade(gt[0], 1301, 0.04)[None]
+    rng = np.random.default_rng(4)
+    mask = (rng.random((1, 72, 80)) < 0.02).astype(np.uint8)
+    mask[0, 0, 0] = mask[0, -1, -1] = 1
+    ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask, ks, kw, sigma, 1e3, 1e3)
+    x = T(sr, dev).requires_grad_(True)
+    l1, kl = SSGLoss(ks, kw, sigma, True, 1e3, 1e3)(x, T(gt, dev), T(mask[:, None], dev))
+    (l1 + kl).backward()
+    assert abs(float(l1) - ref["l1"]) <= 1e-5 * ref["l1"] and abs(float(kl) - ref["kl"]) <= 1e-5 * ref["kl"] + 2e-8
+    assert maxerr(x.grad.cpu(), ref["grad"]) <= grad_tol_from_oracle(sr, gt, mask, ks, kw, sigma, ref)
+    # dense mask
+    H = W = 128
+    gt = synth.natural_like(1400, H, W)[None]
+    sr = synth.degrade(gt[0], 1401)[None]
+    dense = torch.ones((1, 1, H, W), device=dev)
+    step = engine.LossStep(1, 3, H, W, ks, kw, 1.0, 1e-10, True, 1e3, 1e3, device=dev)
+    loss, grad = step(T(sr, dev), T(gt, dev), dense)
+    n = int(step.counts[0])
+    assert n == H * W
+    assert float((step.ssg_sr[:n].sum(1) - 1).abs().max()) < 1e-5
+    assert bool((step.ssg_sr[:n].argmax(1) == (ks * ks) // 2).all())
+    assert bool(torch.isfinite(grad).all()) and float(grad.abs().max()) > 0
+    pix = np.array([0, W - 1, 77 * W + 5, H * W - 1, 64 * W + 64])
+    pos = np.stack([pix // W, pix % W], 1).astype(np.int32)
+    for img, s in ((sr, step.ssg_sr), (gt, step.ssg_gt)):
+        r = orc.ssg_epilogue(orc.distance(img[0].astype(np.float64), pos, ks, kw), kw, 3, 1.0, True)
+        assert maxerr(s[torch.as_tensor(pix, device=dev)].cpu(), r) <= 1e-5
