@@ -625,28 +625,39 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
   }
 }
 
-// loss_out[0] = w_l1 * sum|a-b| / M, loss_out[1] = w_kl * sum t'(log t' - log s') / M
-__global__ void ssg_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P,
-                                  float w_l1, float w_kl, float *loss_out) {
-  __shared__ double s1[256], s2[256];
+// loss_out[0] = w_l1 * sum|a-b| / M, loss_out[1] = w_kl * sum t'(log t' - log s') / M.
+// One workgroup, fp64, fixed summation order (lane-strided partial sums, then lane order).
+__global__ __launch_bounds__(1024) void ssg_loss_finalize(const float *partials, int nparts, const int *n_dev,
+                                                          int n_host, int P, float w_l1, float w_kl, float *loss_out) {
+  __shared__ double s1[1024], s2[1024];
+  const float2 *pp = (const float2 *)partials;
   double a = 0, b = 0;
-  for (int i = threadIdx.x; i < nparts; i += 256) {
-    a += (double)partials[2 * i];
-    b += (double)partials[2 * i + 1];
+  int i = threadIdx.x;
+  for (; i + 3 * 1024 < nparts; i += 4 * 1024) {  // four independent loads in flight
+    const float2 v0 = pp[i], v1 = pp[i + 1024], v2 = pp[i + 2048], v3 = pp[i + 3072];
+    a += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
+    b += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
+  }
+  for (; i < nparts; i += 1024) {
+    const float2 v = pp[i];
+    a += (double)v.x;
+    b += (double)v.y;
   }
   s1[threadIdx.x] = a;
   s2[threadIdx.x] = b;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    a = b = 0;
-    for (int k = 0; k < 256; ++k) {
-      a += s1[k];
-      b += s2[k];
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s1[threadIdx.x] += s1[threadIdx.x + o];
+      s2[threadIdx.x] += s2[threadIdx.x + o];
     }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
     const int nrows = rows_to_do(n_dev, n_host);
     const double M = (double)nrows * (double)P;
-    loss_out[0] = nrows > 0 ? (float)((double)w_l1 * a / M) : 0.f;
-    loss_out[1] = nrows > 0 ? (float)((double)w_kl * b / M) : 0.f;
+    loss_out[0] = nrows > 0 ? (float)((double)w_l1 * s1[0] / M) : 0.f;
+    loss_out[1] = nrows > 0 ? (float)((double)w_kl * s2[0] / M) : 0.f;
   }
 }
 
@@ -710,7 +721,7 @@ int launch_bwd(const BwdParams &p, hipStream_t st) {
 
 int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
                          float w_kl, float *loss_out, hipStream_t st) {
-  hipLaunchKernelGGL(ssg_loss_finalize, dim3(1), dim3(256), 0, st, partials, nparts, n_dev, n_host, P, w_l1, w_kl,
+  hipLaunchKernelGGL(ssg_loss_finalize, dim3(1), dim3(1024), 0, st, partials, nparts, n_dev, n_host, P, w_l1, w_kl,
                      loss_out);
   return (int)hipGetLastError();
 }

@@ -182,28 +182,45 @@ __global__ __launch_bounds__(256) void tile_count(const int *rank, int B, int H,
   if (lane == 0) cnt[tile] = __popcll(bal);
 }
 
-// exclusive scan of cnt[0..n): each of the 1024 lanes first sums a contiguous run of
-// ceil(n/1024) entries, one Hillis-Steele pass scans the 1024 run totals, then the runs are
-// re-walked to write the offsets (one workgroup, a handful of barriers).
+// exclusive scan of cnt[0..n) by one workgroup: the counts are staged in LDS with coalesced
+// loads (up to SCAN_LDS entries per round), each of the 1024 lanes sums a contiguous run from
+// LDS, one Hillis-Steele pass scans the run totals, the runs are re-walked in LDS and the
+// offsets leave with coalesced stores.
+constexpr int SCAN_LDS = 16384;
+
 __global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int n) {
-  __shared__ int buf[1024];
+  extern __shared__ int stage[];  // [SCAN_LDS] + [1024] + carry
+  int *buf = stage + SCAN_LDS;
+  int &carry = stage[SCAN_LDS + 1024];
   const int tid = threadIdx.x;
-  const int run = (n + 1023) / 1024;
-  const int lo = tid * run, hi = lo + run < n ? lo + run : n;
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += cnt[i];
-  buf[tid] = s;
+  if (tid == 0) carry = 0;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int t = tid >= o ? buf[tid - o] : 0;
+  for (int base = 0; base < n; base += SCAN_LDS) {
+    const int m = n - base < SCAN_LDS ? n - base : SCAN_LDS;
+    for (int i = tid; i < m; i += 1024) stage[i] = cnt[base + i];
     __syncthreads();
-    buf[tid] += t;
+    const int run = (m + 1023) / 1024;
+    const int lo = tid * run, hi = lo + run < m ? lo + run : m;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += stage[i];
+    buf[tid] = s;
     __syncthreads();
-  }
-  int acc = buf[tid] - s;
-  for (int i = lo; i < hi; ++i) {
-    off[i] = acc;
-    acc += cnt[i];
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = tid >= o ? buf[tid - o] : 0;
+      __syncthreads();
+      buf[tid] += t;
+      __syncthreads();
+    }
+    int acc = carry + buf[tid] - s;
+    for (int i = lo; i < hi; ++i) {
+      const int v = stage[i];
+      stage[i] = acc;
+      acc += v;
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += 1024) off[base + i] = stage[i];
+    if (tid == 1023) carry += buf[1023];
+    __syncthreads();
   }
 }
 
@@ -237,10 +254,16 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts);
   hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank);
   if (order) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(int) * (SCAN_LDS + 1024 + 4)));
+      attr_set = true;
+    }
     const int nt = (int)n_order_tiles(B, H, W);
     int *tcnt = blockoff + nblk, *toff = tcnt + nt;
     hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt);
-    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt);
+    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), sizeof(int) * (SCAN_LDS + 1024 + 4), st, tcnt, toff, nt);
     hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity);
   }
   return (int)hipGetLastError();
