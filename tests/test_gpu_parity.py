@@ -460,3 +460,39 @@ def test_stress_kernel_sizes_loss_and_dense_mask(dev):
     for img, s in ((sr, step.ssg_sr), (gt, step.ssg_gt)):
         r = orc.ssg_epilogue(orc.distance(img[0].astype(np.float64), pos, ks, kw), kw, 3, 1.0, True)
         assert maxerr(s[torch.as_tensor(pix, device=dev)].cpu(), r) <= 1e-5
+
+
+@pytest.mark.parametrize("strategy", ["areaarea_mask_nonlocal_cuda_v1", "areaarea_mask_nonlocal_cuda_v2",
+                                      "areaarea_mask_nonlocalavg_cuda_v1", "areaarea_mask_nonlocalavg_cuda_v2",
+                                      "areaarea_mask_nonlocal"])
+def test_diffusion_fork_strategies(dev, strategy):
+    """Diffusion-Based-SR fork's similarity_map constructor (DM loss_util.py:242-363): the operator-based
+    strategies vs their formulas evaluated on the oracle's distances."""
+    from ssl_amd.losses.dm_loss_util import similarity_map as dm_similarity_map
+    from ssl_amd import synth
+    ks, kc, sigma = 25, 9, 0.05
+    img = synth.natural_like(1500, 56, 60)[None]
+    mask = synth.laplacian_edge_mask(img[0]).astype(np.float32)
+    pos = orc.mask_to_pos(mask)
+    D = orc.distance(img[0].astype(np.float64), pos, ks, kc).reshape(len(pos), -1)
+    avg = "avg" in strategy
+    q = D / (3 * kc * kc) if avg else D
+    if strategy.endswith("nonlocal_cuda_v2"):
+        q = np.sqrt(q + 1e-8)
+    sig = sigma if avg else sigma * 3 * kc * kc        # keep exp() in range for the un-averaged variants
+    e = np.exp(-q / sig)
+    if strategy == "areaarea_mask_nonlocalavg_cuda_v2":
+        e = np.delete(e, ks * ks // 2, axis=1)
+    eps = 1e-20 if strategy == "areaarea_mask_nonlocalavg_cuda_v1" else 1e-6
+    ref = e / (e.sum(1, keepdims=True) + eps)
+    x = T(img, dev).requires_grad_(True)
+    s = dm_similarity_map(x, T(mask[None, None], dev), simself_strategy=strategy, kernel_size=ks, scaling_factor=sig,
+                          softmax=True, kernel_size_center=kc, dh=16, dw=16, temperature=0, crossentropy=False,
+                          rearrange_back=True, stride=1, pix_num=1, index=None, mean=False, var=False,
+                          gene_type="sum", largest_k=0).getitem()
+    assert s.shape == (1,) + ref.shape
+    assert maxerr(s.detach().cpu()[0], ref) <= 1e-5
+    s.square().sum().backward()
+    assert bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        dm_similarity_map(x, T(mask[None, None], dev), simself_strategy="imgimg")
