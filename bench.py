@@ -80,8 +80,8 @@ def stage_times(step, sr, gt, mask, n_edges, iters):
                                    p(rank), p(order), p(scratch), st))
 
     def f_fwd():
-        _lib.check(L.ssg_map_forward(p(sr), p(gt), B, C, H, W, p(edges), p(step.counts), n_edges, KS, KW, SIGMA, EPS,
-                                     1, p(step.ssg_sr), p(step.ssg_gt), st))
+        _lib.check(L.ssg_map_forward(p(sr), p(gt), B, C, H, W, p(edges), p(order), p(step.counts), n_edges, KS, KW,
+                                     SIGMA, EPS, 1, p(step.ssg_sr), p(step.ssg_gt), st))
 
     def f_bwd():
         _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(step.counts), n_edges, KS, KW, SIGMA, 1,

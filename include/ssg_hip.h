@@ -96,7 +96,10 @@ int ssg_compute_similarity_backward(const float *image, const float *grads,
  *                 makes consecutive jobs spatial neighbours, whose gradient
  *                 tiles are then summed on chip before touching HBM (3.5x
  *                 fewer global atomics).  Rows of the SSG tensors keep the
- *                 reference's order either way.
+ *                 reference's order either way.  Entries hold the row in bits
+ *                 0..29; bit 30 of every 5th entry (first of a group of five
+ *                 jobs) marks groups whose edge pixels share one image and an
+ *                 8 x 16 pixel window (the kernels' on-chip sharing test).
  * scratch: ssg_edge_scratch_bytes(B,H,W) bytes of device memory. */
 size_t ssg_edge_scratch_bytes(int B, int H, int W);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
@@ -120,9 +123,12 @@ int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W,
  * device-side row count (counts[0]); at most n_rows rows are computed (the
  * host-known bound used to size the launch and `ssg`).  ssg is (n_rows,
  * k_s*k_s) fp32, row n <-> edges[n].  If img2/ssg2 are non-null the same
- * edge list is evaluated on a second batch in the same launch (SR and GT). */
+ * edge list is evaluated on a second batch in the same launch (SR and GT).
+ * tile_order (from ssg_edge_list) only changes which workgroup computes which
+ * row: neighbouring edge pixels then share one LDS search region. */
 int ssg_map_forward(const float *img, const float *img2, int B, int C, int H,
-                    int W, const int *edges, const int *n_edges_dev, int n_rows,
+                    int W, const int *edges, const int *tile_order /* nullable */,
+                    const int *n_edges_dev, int n_rows,
                     int ks, int kw, float sigma, float eps, int generalization,
                     float *ssg, float *ssg2, ssg_stream_t stream);
 

@@ -126,8 +126,8 @@ int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_thre
 }
 
 int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, int W, const int *edges,
-                    const int *n_edges_dev, int n_rows, int ks, int kw, float sigma, float eps, int generalization,
-                    float *ssg, float *ssg2, ssg_stream_t stream) {
+                    const int *tile_order, const int *n_edges_dev, int n_rows, int ks, int kw, float sigma, float eps,
+                    int generalization, float *ssg, float *ssg2, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -140,6 +140,7 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
   p.nimg = img2 ? 2 : 1;
   p.edges = edges;
   p.estride = 3;
+  p.order = tile_order;
   p.n_dev = n_edges_dev;
   p.n_host = n_rows;
   p.B = B;
@@ -257,8 +258,8 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   int rc = ssg_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
                          W, mask_stride, lap_threshold, edges, capacity, counts, rank, order, escratch, stream);
   if (rc) return rc;
-  rc = ssg_map_forward(sr, gt, B, C, H, W, edges, counts, capacity, ks, kw, sigma, eps, generalization, ssg_sr,
-                       ssg_gt, stream);
+  rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, counts, capacity, ks, kw, sigma, eps, generalization,
+                       ssg_sr, ssg_gt, stream);
   if (rc) return rc;
   return ssg_loss_backward(sr, B, C, H, W, edges, order, counts, capacity, ks, kw, sigma, generalization, ssg_sr,
                            ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);

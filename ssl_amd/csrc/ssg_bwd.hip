@@ -89,7 +89,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   if (tid < JOBS) {
     const int k = job0 + tid;
     const bool v = k < nrows;
-    const int row = v ? (p.order ? p.order[k] : k) : -1;
+    const int row = v ? (p.order ? (p.order[k] & ORDER_MASK) : k) : -1;
     const Edge e = load_edge(p.edges, p.estride, v ? row : 0);
     sh_edge[tid * 4 + 0] = e.b;
     sh_edge[tid * 4 + 1] = e.y;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
     }
     return;
   }
-  const int row = p.order ? p.order[n] : n;
+  const int row = p.order ? (p.order[n] & ORDER_MASK) : n;
   const Edge e = load_edge(p.edges, p.estride, row);
   const size_t base = (size_t)row * P;
   const float kfac = 1.f / (p.sigma * (float)(C * K2));

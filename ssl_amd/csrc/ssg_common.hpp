@@ -79,6 +79,12 @@ __device__ __forceinline__ void pin_block(float (&v)[R][N]) {
   for (int i = 0; i < R; ++i) pin_row<N>(v[i]);
 }
 
+// `order` entries: bits 0..29 = row; bit 30 of the FIRST entry of every group of ORDER_GROUP
+// consecutive entries = "these jobs are one image's edge pixels within 8 rows x 16 columns".
+constexpr int ORDER_GROUP = 5;
+constexpr int ORDER_FLAG = 1 << 30;
+constexpr int ORDER_MASK = ORDER_FLAG - 1;
+
 struct Edge {
   int b, y, x;
 };
@@ -100,6 +106,7 @@ struct FwdParams {
   int nimg;
   const int *edges;
   int estride;       // 3: (b,y,x)   2: (Y,X)
+  const int *order;  // nullable (n): tile-major permutation of the rows -> image-major job order
   const int *n_dev;  // nullable device row count
   int n_host;        // host bound on rows
   int B, C, H, W;

@@ -237,6 +237,33 @@ __global__ __launch_bounds__(256) void tile_scatter(const int *rank, int B, int 
   }
 }
 
+// Marks the groups of ORDER_GROUP consecutive jobs whose edge pixels are one image's and lie within
+// 8 rows x 16 columns (bit ORDER_FLAG of the group's first entry): the forward kernel variants pick
+// their groups from this flag with a single load.
+__global__ __launch_bounds__(256) void tile_group_flags(int *order, const int *edges, const int *counts, int capacity) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  int n = counts[0];
+  n = n < capacity ? n : capacity;
+  const int k0 = g * ORDER_GROUP;
+  if (k0 >= n) return;
+  int y0 = 1 << 30, x0 = 1 << 30, y1 = -1, x1 = -1, b0 = -1;
+  bool ok = true;
+  int first = 0;
+  for (int j = 0; j < ORDER_GROUP && k0 + j < n; ++j) {
+    const int row = order[k0 + j] & ORDER_MASK;
+    if (j == 0) first = row;
+    const int b = edges[3 * (size_t)row], y = edges[3 * (size_t)row + 1], x = edges[3 * (size_t)row + 2];
+    if (b0 < 0) b0 = b;
+    ok = ok && b == b0;
+    y0 = y < y0 ? y : y0;
+    y1 = y > y1 ? y : y1;
+    x0 = x < x0 ? x : x0;
+    x1 = x > x1 ? x : x1;
+  }
+  ok = ok && (y1 - y0) <= 7 && (x1 - x0) <= 15;
+  order[k0] = first | (ok ? ORDER_FLAG : 0);
+}
+
 // ------------------------------------------------------------------ host ----
 static size_t n_order_tiles(int B, int H, int W) { return (size_t)B * ((H + OT - 1) / OT) * ((W + OT - 1) / OT); }
 
@@ -265,6 +292,9 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
     hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt);
     hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), sizeof(int) * (SCAN_LDS + 1024 + 4), st, tcnt, toff, nt);
     hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity);
+    const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
+    if (ngroups > 0)
+      hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256), dim3(256), 0, st, order, edges, counts, capacity);
   }
   return (int)hipGetLastError();
 }

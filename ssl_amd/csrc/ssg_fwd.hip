@@ -23,9 +23,9 @@ namespace ssg {
 // One patch row (PW floats) of a lane's block from the LDS tile: rows outside the
 // search area read the all-zero row, columns outside it are predicated to 0.
 template <class G>
-__device__ __forceinline__ void load_row(const float *tc, const float *zrow, int ry, int cx0,
+__device__ __forceinline__ void load_row(const float *tc, int rs, const float *zrow, int ry, int cx0,
                                          const bool (&colv)[G::PW], float (&out)[G::PW]) {
-  const float *rowp = ((unsigned)ry < (unsigned)G::KS) ? (tc + ry * G::S) : zrow;
+  const float *rowp = ((unsigned)ry < (unsigned)G::KS) ? (tc + ry * rs) : zrow;
 #pragma unroll
   for (int j = 0; j < G::PW; ++j) {
     const float v = rowp[cx0 + j];
@@ -33,49 +33,124 @@ __device__ __forceinline__ void load_row(const float *tc, const float *zrow, int
   }
 }
 
-template <class G>
+// MERGED = false: every job stages its own C x k_s x k_s search tile in LDS.
+// MERGED = true : the workgroup's jobs are edge pixels of ONE image within 8 rows x 16 columns
+//                 (the usual case in the tile-major job order): their search areas are read from
+//                 one shared LDS region of at most 32 x 40 pixels per channel -- 2.4x fewer fill
+//                 loads and 17 KB instead of 40 KB of LDS per workgroup (3 instead of 2 waves per
+//                 SIMD).  Both variants are launched over the same job groups; a group runs in the
+//                 variant its geometry selects and exits at once in the other.
+template <class G, bool MERGED>
 __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
   constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
   constexpr int JOBS = G::JOBS, PW = G::PW, S = G::S, CH = G::CH;
   constexpr int PADF = (HK + 3) & ~3;
+  constexpr int MH = KS + 7, MW = KS + 15, MS = MW + 1;  // merged region: rows, cols, row stride
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = p.C, H = p.H, W = p.W;
-  float *tiles = smem + PADF;                  // [JOBS][C][KS][S]
-  float *zero = tiles + JOBS * C * CH;         // ZROW zeros (also absorbs tail over-reads)
-  float *red = zero + ((G::ZROW + 3) & ~3);    // [WG] row-sum scratch
-  int *sh_edge = (int *)(red + WG);            // [JOBS][4]: b, y, x, valid
+  float *tiles = smem + PADF;                                      // [JOBS][C][KS][S] or [C][MH][MS]
+  float *zero = tiles + (MERGED ? C * MH * MS : JOBS * C * CH);    // ZROW zeros (also absorbs tail over-reads)
+  float *red = zero + ((G::ZROW + 3) & ~3);                        // [WG] row-sum scratch
+  int *sh_edge = (int *)(red + WG);                                // [JOBS][6]: b, y, x, row, which, pad
 
   const int tid = threadIdx.x;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
-  const int njobs = nrows * p.nimg;
+  // job numbering: row order -> q = row * nimg + image; tile order -> image-major, every image's
+  // jobs padded to a multiple of JOBS so that groups coincide with the ORDER_GROUP groups
+  const int npad = p.order ? (nrows + JOBS - 1) / JOBS * JOBS : nrows;
+  const int njobs = npad * p.nimg;
   const int job0 = blockIdx.x * JOBS;
   if (job0 >= njobs) return;
+  int which0 = 0, k0 = 0;
+  bool mergeable = false;
+  if (p.order) {
+    static_assert(!MERGED || JOBS == ORDER_GROUP, "order flags are computed for groups of ORDER_GROUP jobs");
+    which0 = job0 / npad;
+    k0 = job0 - which0 * npad;
+    if (k0 >= nrows) return;                             // padding-only group
+    mergeable = (p.order[k0] & ORDER_FLAG) != 0;         // one wave-uniform load decides the variant
+  }
+  if (mergeable != MERGED) return;
 
   if (tid < JOBS) {
-    const int q = job0 + tid;
-    const bool v = q < njobs;
-    const int n = v ? q / p.nimg : 0;
-    Edge e = load_edge(p.edges, p.estride, n);
-    sh_edge[tid * 4 + 0] = e.b;
-    sh_edge[tid * 4 + 1] = e.y;
-    sh_edge[tid * 4 + 2] = e.x;
-    sh_edge[tid * 4 + 3] = v ? 1 : 0;
+    int row = -1, which = 0;
+    if (p.order) {
+      which = which0;
+      if (k0 + tid < nrows) row = p.order[k0 + tid] & ORDER_MASK;
+    } else if (job0 + tid < njobs) {
+      row = (job0 + tid) / p.nimg;
+      which = (job0 + tid) - row * p.nimg;
+    }
+    const Edge e = load_edge(p.edges, p.estride, row < 0 ? 0 : row);
+    sh_edge[tid * 6 + 0] = e.b;
+    sh_edge[tid * 6 + 1] = e.y;
+    sh_edge[tid * 6 + 2] = e.x;
+    sh_edge[tid * 6 + 3] = row;
+    sh_edge[tid * 6 + 4] = which;
   }
   for (int i = tid; i < G::ZROW + 4; i += WG) zero[i] = 0.f;
   if (tid < PADF) smem[tid] = 0.f;
   __syncthreads();
 
+  // common window of the group's jobs (uniform across the workgroup; merged variant only)
+  int my0 = 1 << 30, mx0 = 1 << 30, my1 = -1, mx1 = -1, mb0 = 0, mw0 = 0;
+  if constexpr (MERGED) {
+#pragma unroll
+    for (int j = 0; j < JOBS; ++j)
+      if (sh_edge[j * 6 + 3] >= 0) {
+        const int y = sh_edge[j * 6 + 1], x = sh_edge[j * 6 + 2];
+        mb0 = sh_edge[j * 6 + 0];
+        mw0 = sh_edge[j * 6 + 4];
+        my0 = y < my0 ? y : my0;
+        my1 = y > my1 ? y : my1;
+        mx0 = x < mx0 ? x : mx0;
+        mx1 = x > mx1 ? x : mx1;
+      }
+  }
+
+  if constexpr (MERGED) {
+    // ---- fill the shared region: rows of up to 40 contiguous pixels, reflect by mirroring ----
+    const int wh = my1 - my0 + KS, ww = mx1 - mx0 + KS;
+    const float *src = p.img[mw0] + (size_t)mb0 * C * H * W;
+    // 8 lanes per region row (5 columns each, stride 8), WG/8 rows per pass, two passes in flight
+    constexpr int LPR = 8, CPL = (MW + LPR - 1) / LPR, RPP = WG / LPR;
+    const int rows = (p.dbg & 1) ? 0 : C * wh;
+    const int lx = tid % LPR, lr = tid / LPR;
+    for (int r0 = 0; r0 < rows; r0 += 2 * RPP) {
+      float v[2][CPL];
+      int d[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int R = r0 + h * RPP + lr;
+        const bool on = R < rows;
+        const int Rc = on ? R : 0;
+        const int c = Rc / wh, ry = Rc - c * wh;
+        const float *srow = src + ((size_t)c * H + reflect_idx(my0 - HP + ry, H)) * W;
+        d[h] = on ? (c * MH + ry) * MS : -1;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int rx = lx + k * LPR;
+          v[h][k] = srow[reflect_idx(mx0 - HP + (rx < ww ? rx : 0), W)];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int rx = lx + k * LPR;
+          if (d[h] >= 0 && rx < ww) tiles[d[h] + rx] = v[h][k];
+        }
+    }
+  } else {
   // ---- fill: JOBS x C x KS x KS floats, reflect by index mirroring.  All global loads of a
   // job are issued before the first LDS store (a plain loop pays the full L2 latency per
   // element: the fill was 29 % of the kernel) ----
   constexpr int EPT = (P + WG - 1) / WG;  // tile elements per thread per channel
   for (int j = 0; j < ((p.dbg & 1) ? 0 : JOBS); ++j) {
-    const int q = job0 + j;
-    const int which = q < njobs ? q % p.nimg : 0;
-    const float *src = p.img[which];
-    const int b = sh_edge[j * 4 + 0], y = sh_edge[j * 4 + 1], x = sh_edge[j * 4 + 2];
+    const float *src = p.img[sh_edge[j * 6 + 4]];
+    const int b = sh_edge[j * 6 + 0], y = sh_edge[j * 6 + 1], x = sh_edge[j * 6 + 2];
     const float *s0[EPT];
     int d0[EPT];
 #pragma unroll
@@ -108,6 +183,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
       }
     }
   }
+  }
   __syncthreads();
 
   // ---- per-lane block ----
@@ -128,26 +204,30 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
     for (int j = 0; j < BS; ++j) acc[i][j] = 0.f;
 
   const float *zrow = zero + HK;
+  // per-job tile origin, row stride and channel stride inside LDS
+  const int rs = MERGED ? MS : S, chs = MERGED ? MH * MS : CH;
+  const float *tjob = MERGED ? tiles + (sh_edge[jl * 6 + 1] - my0) * MS + (sh_edge[jl * 6 + 2] - mx0)
+                             : tiles + (jl * C) * CH;
 #pragma unroll 1
   for (int c = 0; c < ((p.dbg & 2) ? 0 : C); ++c) {
-    const float *tc = tiles + (jl * C + c) * CH;
+    const float *tc = tjob + c * chs;
     if constexpr (KW <= 9) {
       float a[KW][KW];  // centre window of this channel (uniform across the job's lanes)
 #pragma unroll
       for (int kh = 0; kh < KW; ++kh)
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) a[kh][kx] = tc[(HP - HK + kh) * S + (HP - HK + kx)];
+        for (int kx = 0; kx < KW; ++kx) a[kh][kx] = tc[(HP - HK + kh) * rs + (HP - HK + kx)];
       // software pipeline: patch row r+1 is in flight while row r is consumed;
       // pin_block keeps hipcc from hoisting every row's loads to the top (which blew
       // the VGPR budget and spilled ~380 dwords per lane).
       float bn[PW];
-      load_row<G>(tc, zrow, ry0, cx0, colv, bn);
+      load_row<G>(tc, rs, zrow, ry0, cx0, colv, bn);
 #pragma unroll
       for (int r = 0; r < PW; ++r) {
         float bv[PW];
 #pragma unroll
         for (int j = 0; j < PW; ++j) bv[j] = bn[j];
-        if (r + 1 < PW) load_row<G>(tc, zrow, ry0 + r + 1, cx0, colv, bn);
+        if (r + 1 < PW) load_row<G>(tc, rs, zrow, ry0 + r + 1, cx0, colv, bn);
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
           const int kh = r - i;
@@ -171,7 +251,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
 #pragma unroll 1
       for (int r = 0; r < PW; ++r) {
         const int ry = ry0 + r;
-        const float *rowp = ((unsigned)ry < (unsigned)KS) ? (tc + ry * S) : zrow;
+        const float *rowp = ((unsigned)ry < (unsigned)KS) ? (tc + ry * rs) : zrow;
         float bv[PW];
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
@@ -182,7 +262,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
         for (int i = 0; i < BS; ++i) {
           const int kh = r - i;
           if (kh < 0 || kh >= KW) continue;  // runtime r: predicated
-          const float *ar = tc + (HP - HK + kh) * S + (HP - HK);
+          const float *ar = tc + (HP - HK + kh) * rs + (HP - HK);
 #pragma unroll
           for (int kx = 0; kx < KW; ++kx) {
             const float av = ar[kx];
@@ -197,10 +277,9 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
     }
   }
 
-  const int q = job0 + jl;
-  const bool job_on = lane_on && q < njobs;
-  const int n = job_on ? q / p.nimg : 0;
-  const int which = job_on ? q % p.nimg : 0;
+  const bool job_on = lane_on && sh_edge[jl * 6 + 3] >= 0;
+  const int n = job_on ? sh_edge[jl * 6 + 3] : 0;
+  const int which = job_on ? sh_edge[jl * 6 + 4] : 0;
 
   if (p.raw) {
     // reference operator: out[n,py,px] += D   (similarity.cu:49)
@@ -243,7 +322,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
     for (int k = 0; k < LPJ; ++k) tot += red[jl * LPJ + k];
     scale = 1.f / (tot + p.eps);
   }
-  float *stage = tiles + (jl * C) * CH;  // >= P floats per job
+  float *stage = tiles + (MERGED ? jl * P : (jl * C) * CH);  // >= P floats per job
   if (lane_on) {
 #pragma unroll
     for (int i = 0; i < BS; ++i)
@@ -255,10 +334,10 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   }
   __syncthreads();
   for (int j = 0; j < JOBS; ++j) {
-    const int qq = job0 + j;
-    if (qq >= njobs) break;
-    float *o = p.out[qq % p.nimg] + (size_t)(qq / p.nimg) * P;
-    const float *sj = tiles + (j * C) * CH;
+    const int row = sh_edge[j * 6 + 3];
+    if (row < 0) continue;
+    float *o = p.out[sh_edge[j * 6 + 4]] + (size_t)row * P;
+    const float *sj = tiles + (MERGED ? j * P : (j * C) * CH);
     for (int e = tid; e < P; e += WG) o[e] = sj[e];
   }
 }
@@ -314,35 +393,50 @@ __global__ __launch_bounds__(256) void ssg_fwd_generic(FwdParams p) {
 }
 
 // ------------------------------------------------------------------ host ----
-template <class G>
+template <class G, bool MERGED>
 static size_t fwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
-  return sizeof(float) * (size_t)(PADF + G::JOBS * C * G::CH + ((G::ZROW + 3) & ~3) + 4 + G::WG) +
-         sizeof(int) * 4 * G::JOBS;
+  constexpr int MH = G::KS + 7, MS = G::KS + 16;
+  const size_t tiles = MERGED ? (size_t)C * MH * MS : (size_t)G::JOBS * C * G::CH;
+  return sizeof(float) * (size_t)(PADF + tiles + ((G::ZROW + 3) & ~3) + 4 + G::WG) + sizeof(int) * 6 * G::JOBS;
 }
 
-template <class G>
+template <class G, bool MERGED>
 static int launch_fwd_tiled(const FwdParams &p, hipStream_t st) {
-  const size_t lds = fwd_lds_bytes<G>(p.C);
+  const size_t lds = fwd_lds_bytes<G, MERGED>(p.C);
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)ssg_fwd_tiled<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)ssg_fwd_tiled<G, MERGED>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
-  const long njobs = (long)p.n_host * p.nimg;
+  // tile order pads every image's jobs to a multiple of JOBS
+  const long per_img = p.order ? ((long)p.n_host + G::JOBS - 1) / G::JOBS * G::JOBS : (long)p.n_host;
+  const long njobs = per_img * p.nimg;
   if (njobs == 0) return 0;
   const unsigned grid = (unsigned)((njobs + G::JOBS - 1) / G::JOBS);
-  hipLaunchKernelGGL(ssg_fwd_tiled<G>, dim3(grid), dim3(G::WG), lds, st, p);
+  hipLaunchKernelGGL((ssg_fwd_tiled<G, MERGED>), dim3(grid), dim3(G::WG), lds, st, p);
   return (int)hipGetLastError();
 }
 
-int launch_fwd(const FwdParams &p, hipStream_t st) {
-  if (p.ks == 25 && p.kw == 9) return launch_fwd_tiled<Geo<25, 9, 5, 128>>(p, st);
-  if (p.ks == 11 && p.kw == 5) return launch_fwd_tiled<Geo<11, 5, 4, 64>>(p, st);
-  if (p.ks == 49 && p.kw == 13 && fwd_lds_bytes<Geo<49, 13, 7, 128>>(p.C) <= 160 * 1024)
-    return launch_fwd_tiled<Geo<49, 13, 7, 128>>(p, st);
+int launch_fwd(const FwdParams &p_in, hipStream_t st) {
+  FwdParams p = p_in;
+  if (p.ks == 25 && p.kw == 9) {
+    using G = Geo<25, 9, 5, 128>;
+    // the merged variant stages its JOBS output rows in the shared region: needs C*(k_s+7)*(k_s+16) >= JOBS*k_s^2
+    const bool can_merge = p.order && !p.raw && (size_t)p.C * (G::KS + 7) * (G::KS + 16) >= (size_t)G::JOBS * G::P;
+    if (!can_merge) p.order = nullptr;
+    if (can_merge) {
+      const int rc = launch_fwd_tiled<G, true>(p, st);
+      if (rc) return rc;
+    }
+    return launch_fwd_tiled<G, false>(p, st);
+  }
+  p.order = nullptr;  // the other geometries run in row order
+  if (p.ks == 11 && p.kw == 5) return launch_fwd_tiled<Geo<11, 5, 4, 64>, false>(p, st);
+  if (p.ks == 49 && p.kw == 13 && fwd_lds_bytes<Geo<49, 13, 7, 128>, false>(p.C) <= 160 * 1024)
+    return launch_fwd_tiled<Geo<49, 13, 7, 128>, false>(p, st);
   const size_t lds = sizeof(float) * ((size_t)p.C * p.ks * p.ks + 256);
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;
@@ -357,9 +451,9 @@ int launch_fwd(const FwdParams &p, hipStream_t st) {
 }
 
 const char *fwd_kernel_name(int ks, int kw) {
-  if (ks == 25 && kw == 9) return "ssg_fwd_tiled<Geo<25,9,5,128>>";
-  if (ks == 11 && kw == 5) return "ssg_fwd_tiled<Geo<11,5,4,64>>";
-  if (ks == 49 && kw == 13) return "ssg_fwd_tiled<Geo<49,13,7,128>>";
+  if (ks == 25 && kw == 9) return "ssg_fwd_tiled<Geo<25,9,5,128>,merged|single>";
+  if (ks == 11 && kw == 5) return "ssg_fwd_tiled<Geo<11,5,4,64>,single>";
+  if (ks == 49 && kw == 13) return "ssg_fwd_tiled<Geo<49,13,7,128>,single>";
   return "ssg_fwd_generic";
 }
 

@@ -98,9 +98,9 @@ class _SSGMapFn(torch.autograd.Function):
         x = _f32c(img)
         B, C, H, W = x.shape
         ssg = torch.empty((n_rows, ks * ks), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().ssg_map_forward(_ptr(x), None, B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw,
-                                              float(sigma), float(eps), int(bool(generalization)), _ptr(ssg), None,
-                                              _stream()))
+        _lib.check(_lib.lib().ssg_map_forward(_ptr(x), None, B, C, H, W, _ptr(edges), _ptr(order), _ptr(counts), n_rows,
+                                              ks, kw, float(sigma), float(eps), int(bool(generalization)), _ptr(ssg),
+                                              None, _stream()))
         ctx.save_for_backward(x, edges, counts, ssg)
         ctx.order = order
         ctx.cfg = (n_rows, ks, kw, float(sigma), int(bool(generalization)))
@@ -141,8 +141,8 @@ class _SSGLossFn(torch.autograd.Function):
         loss = torch.zeros(2, dtype=torch.float32, device=dev)
         scratch = torch.empty(L.ssg_loss_scratch_bytes(B, H, W, n_rows, ks), dtype=torch.uint8, device=dev)
         gen = int(bool(generalization))
-        _lib.check(L.ssg_map_forward(_ptr(x), _ptr(y), B, C, H, W, _ptr(edges), _ptr(counts), n_rows, ks, kw,
-                                     float(sigma), float(eps), gen, _ptr(ssg_sr), _ptr(ssg_gt), _stream()))
+        _lib.check(L.ssg_map_forward(_ptr(x), _ptr(y), B, C, H, W, _ptr(edges), _ptr(order), _ptr(counts), n_rows, ks,
+                                     kw, float(sigma), float(eps), gen, _ptr(ssg_sr), _ptr(ssg_gt), _stream()))
         _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(order), _ptr(counts), n_rows, ks, kw,
                                        float(sigma), gen, _ptr(ssg_sr), _ptr(ssg_gt), float(w_l1), float(w_kl), None,
                                        _ptr(loss), None, _ptr(scratch), _stream()))

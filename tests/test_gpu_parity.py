@@ -350,7 +350,9 @@ def test_region_and_list_backward_agree_odd_sizes(dev):
     assert n == int(masks.sum())
     rk = el.rank.cpu().numpy()
     assert np.array_equal(rk >= 0, masks.astype(bool)) and np.array_equal(np.sort(rk[rk >= 0]), np.arange(n))
-    od = el.order[:n].cpu().numpy()
+    od_raw = el.order[:n].cpu().numpy()
+    od = od_raw & 0x3FFFFFFF                                   # bit 30 = group flag (first entry of 5)
+    assert (od_raw[np.arange(n) % 5 != 0] == od[np.arange(n) % 5 != 0]).all()
     assert np.array_equal(np.sort(od), np.arange(n))          # a permutation of the rows ...
     e_np = el.edges[:n].cpu().numpy()[od]
     tkey = (e_np[:, 0] * 1000 + e_np[:, 1] // 8) * 1000 + e_np[:, 2] // 8
