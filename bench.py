@@ -73,15 +73,16 @@ def stage_times(step, sr, gt, mask, n_edges, iters):
     lscratch = torch.empty(L.ssg_loss_scratch_bytes(B, H, W, step.capacity, KS), dtype=torch.uint8, device=sr.device)
     rank = torch.empty((B, H, W), dtype=torch.int32, device=sr.device)
     order = torch.empty(step.capacity, dtype=torch.int32, device=sr.device)
+    plan = torch.empty(L.ssg_forward_plan_bytes(B, H, W, step.capacity) // 4, dtype=torch.int32, device=sr.device)
     p = engine._ptr
 
     def f_edges():
         _lib.check(L.ssg_edge_list(p(mask), 0, 1, B, H, W, 0, 20.0, p(edges), step.capacity, p(step.counts),
-                                   p(rank), p(order), p(scratch), st))
+                                   p(rank), p(order), p(plan), p(scratch), st))
 
     def f_fwd():
-        _lib.check(L.ssg_map_forward(p(sr), p(gt), B, C, H, W, p(edges), p(order), p(step.counts), n_edges, KS, KW,
-                                     SIGMA, EPS, 1, p(step.ssg_sr), p(step.ssg_gt), st))
+        _lib.check(L.ssg_map_forward(p(sr), p(gt), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts),
+                                     n_edges, KS, KW, SIGMA, EPS, 1, p(step.ssg_sr), p(step.ssg_gt), st))
 
     def f_bwd():
         _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(step.counts), n_edges, KS, KW, SIGMA, 1,
@@ -89,7 +90,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters):
                                        p(lscratch), st))
 
     out = {}
-    for name, f in (("edge_list(6 kernels)", f_edges), (L.ssg_kernel_name(KS, KW, 0).decode(), f_fwd),
+    for name, f in (("edge_list+plan(13 kernels)", f_edges), (L.ssg_kernel_name(KS, KW, 0).decode(), f_fwd),
                     (L.ssg_kernel_name(KS, KW, 1).decode() + "+finalize", f_bwd)):
         f()
         torch.cuda.synchronize()

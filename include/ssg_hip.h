@@ -100,13 +100,19 @@ int ssg_compute_similarity_backward(const float *image, const float *grads,
  *                 0..29; bit 30 of every 5th entry (first of a group of five
  *                 jobs) marks groups whose edge pixels share one image and an
  *                 8 x 16 pixel window (the kernels' on-chip sharing test).
+ *          fwd_plan (nullable, needs rank_map) ssg_forward_plan_bytes() bytes:
+ *                 the forward's work split -- 8x32-pixel tiles holding many
+ *                 edge pixels go to the shared-term ("dense") kernel, the
+ *                 remaining rows, tile-major, to the direct kernels.
  * scratch: ssg_edge_scratch_bytes(B,H,W) bytes of device memory. */
 size_t ssg_edge_scratch_bytes(int B, int H, int W);
+size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int H, int W, int mask_stride, float lap_threshold,
                   int *edges, int capacity, int *counts,
                   int *rank_map /* nullable */, int *tile_order /* nullable */,
-                  void *scratch, ssg_stream_t stream);
+                  int *fwd_plan /* nullable */, void *scratch,
+                  ssg_stream_t stream);
 
 /* The mask itself (B,H,W) uint8 {0,1} from an fp32 GT batch (B,3,H,W):
  * mask_kind 2 above materialised (offline tool generate_mask.py). */
@@ -128,6 +134,8 @@ int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W,
  * row: neighbouring edge pixels then share one LDS search region. */
 int ssg_map_forward(const float *img, const float *img2, int B, int C, int H,
                     int W, const int *edges, const int *tile_order /* nullable */,
+                    const int *rank_map /* nullable */,
+                    const int *fwd_plan /* nullable */,
                     const int *n_edges_dev, int n_rows,
                     int ks, int kw, float sigma, float eps, int generalization,
                     float *ssg, float *ssg2, ssg_stream_t stream);

@@ -23,9 +23,11 @@ PROTOTYPES = {
     "ssg_compute_similarity": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssg_compute_similarity_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssg_edge_scratch_bytes": (_sz, [_i, _i, _i]),
-    "ssg_edge_list": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ssg_forward_plan_bytes": (_sz, [_i, _i, _i, _i]),
+    "ssg_edge_list": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssg_edge_mask_laplacian": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp]),
-    "ssg_map_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "ssg_map_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp,
+                             _vp]),
     "ssg_map_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "ssg_loss_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ssg_loss_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _f, _f, _vp, _vp,

@@ -18,7 +18,28 @@ const char *fwd_kernel_name(int ks, int kw);
 const char *bwd_kernel_name(int ks, int kw);
 size_t edge_scratch_bytes(int B, int H, int W);
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
-                     int *edges, int capacity, int *counts, int *rank, int *order, void *scratch, hipStream_t st);
+                     int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
+                     void *scratch, hipStream_t st);
+size_t fwd_plan_bytes(int B, int H, int W, int capacity);
+int fwd_plan_order_offset(int B, int H, int W);
+struct DenseParams {
+  const float *img[2];
+  float *out[2];
+  int nimg;
+  const int *rank;
+  const int *n_dense;
+  const int *tiles;
+  int max_tiles;
+  const int *n_dev;
+  int n_host;
+  int B, H, W;
+  float sigma, eps;
+  int generalization;
+  int dbg;
+};
+bool dense_supported(int ks, int kw, int C);
+int dense_max_tiles(int B, int H, int W);
+int launch_fwd_dense(const DenseParams &p, int ks, int kw, int C, hipStream_t st);
 int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride, uint8_t *out, hipStream_t st);
 }  // namespace ssg
 
@@ -26,6 +47,20 @@ using namespace ssg;
 
 // SSG_DEBUG_SKIP=<bitmask> ablates kernel phases for profiling (results are then WRONG);
 // read once, 0 in production.
+// Edge pixels per 8 x 32 tile from which the dense ("shared-term") forward kernel takes the tile.
+// EXPERIMENTAL and OFF by default (0): the kernel is correct (the whole GPU suite passes with
+// SSG_DENSE_THR=1) but at 1-2 waves/SIMD and two LDS hand-offs per offset it is still slower than
+// the direct kernels at every density measured (profiles/r1_dense_forward_experiment.txt), so the
+// product path neither builds a forward plan nor launches it unless SSG_DENSE_THR > 0.
+static int dense_threshold() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SSG_DENSE_THR");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 static int dbg_mask() {
   static int v = -1;
   if (v < 0) {
@@ -109,14 +144,17 @@ int ssg_compute_similarity_backward(const float *image, const float *grads, cons
 
 size_t ssg_edge_scratch_bytes(int B, int H, int W) { return edge_scratch_bytes(B, H, W); }
 
+size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity) { return fwd_plan_bytes(B, H, W, capacity); }
+
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
                   float lap_threshold, int *edges, int capacity, int *counts, int *rank_map, int *tile_order,
-                  void *scratch, ssg_stream_t stream) {
+                  int *fwd_plan, void *scratch, ssg_stream_t stream) {
   if (!mask || !edges || !counts || !scratch || B <= 0 || H <= 0 || W <= 0 || capacity < 0 || mask_kind < 0 ||
-      mask_kind > 2 || mask_channels <= 0 || (tile_order && !rank_map))
+      mask_kind > 2 || mask_channels <= 0 || ((tile_order || fwd_plan) && !rank_map))
     return SSG_E_BADARG;
   return launch_edge_list(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, edges, capacity,
-                          counts, rank_map, tile_order, scratch, (hipStream_t)stream);
+                          counts, rank_map, tile_order, dense_threshold() > 0 ? fwd_plan : nullptr, dense_threshold(),
+                          scratch, (hipStream_t)stream);
 }
 
 int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_threshold, int mask_stride,
@@ -126,8 +164,9 @@ int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_thre
 }
 
 int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, int W, const int *edges,
-                    const int *tile_order, const int *n_edges_dev, int n_rows, int ks, int kw, float sigma, float eps,
-                    int generalization, float *ssg, float *ssg2, ssg_stream_t stream) {
+                    const int *tile_order, const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows,
+                    int ks, int kw, float sigma, float eps, int generalization, float *ssg, float *ssg2,
+                    ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -154,6 +193,32 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
   p.ks = ks;
   p.kw = kw;
   p.dbg = dbg_mask() & 0xff;
+  if (dense_threshold() > 0 && fwd_plan && rank_map && dense_supported(ks, kw, C)) {
+    // dense tiles -> shared-term kernel; the rest (plan's own tile-major order) -> direct kernels
+    DenseParams d{};
+    d.img[0] = img;
+    d.img[1] = img2;
+    d.out[0] = ssg;
+    d.out[1] = ssg2;
+    d.nimg = p.nimg;
+    d.rank = rank_map;
+    d.n_dense = fwd_plan + 1;
+    d.tiles = fwd_plan + 4;
+    d.max_tiles = dense_max_tiles(B, H, W);
+    d.n_dev = n_edges_dev;
+    d.n_host = n_rows;
+    d.B = B;
+    d.H = H;
+    d.W = W;
+    d.sigma = sigma;
+    d.eps = eps;
+    d.generalization = generalization;
+    d.dbg = (dbg_mask() >> 16) & 0xff;
+    const int rc = launch_fwd_dense(d, ks, kw, C, (hipStream_t)stream);
+    if (rc) return rc;
+    p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
+    p.n_dev = fwd_plan;  // n_sparse
+  }
   return launch_fwd(p, (hipStream_t)stream);
 }
 
@@ -233,7 +298,7 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
   return align_up(sizeof(int) * 3 * (size_t)(capacity > 0 ? capacity : 1), 256) +
          align_up(sizeof(int) * (size_t)B * H * W, 256) + align_up(sizeof(int) * (size_t)(capacity > 0 ? capacity : 1), 256) +
-         align_up(edge_scratch_bytes(B, H, W), 256) +
+         align_up(fwd_plan_bytes(B, H, W, capacity), 256) + align_up(edge_scratch_bytes(B, H, W), 256) +
          align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
 }
 
@@ -252,14 +317,16 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   ws += align_up(sizeof(int) * (size_t)B * H * W, 256);
   int *order = (int *)ws;
   ws += align_up(sizeof(int) * (size_t)capacity, 256);
+  int *plan = (int *)ws;
+  ws += align_up(fwd_plan_bytes(B, H, W, capacity), 256);
   void *escratch = ws;
   ws += align_up(edge_scratch_bytes(B, H, W), 256);
   void *lscratch = ws;
   int rc = ssg_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
-                         W, mask_stride, lap_threshold, edges, capacity, counts, rank, order, escratch, stream);
+                         W, mask_stride, lap_threshold, edges, capacity, counts, rank, order, plan, escratch, stream);
   if (rc) return rc;
-  rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, counts, capacity, ks, kw, sigma, eps, generalization,
-                       ssg_sr, ssg_gt, stream);
+  rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
+                       generalization, ssg_sr, ssg_gt, stream);
   if (rc) return rc;
   return ssg_loss_backward(sr, B, C, H, W, edges, order, counts, capacity, ks, kw, sigma, generalization, ssg_sr,
                            ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);

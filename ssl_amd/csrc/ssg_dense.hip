@@ -1,0 +1,321 @@
+// Dense-tile ("shared-term") forward SSG kernel for gfx950.
+//
+// The direct kernels (ssg_fwd.hip) spend 2*C*k_w^2 VALU ops per (edge pixel, search offset).
+// Where edge pixels are dense, most of that work is shared: for an offset q the per-pixel term
+//     E_q[u] = sum_c ( I[c,u] - I[c,u+q] )^2
+// is the same for every edge pixel whose k_w x k_w window covers u, and
+//     D[n,q] = sum_{k in K(q)} E_q[x_n + k]  +  sum_{k in win \ K(q)} |I[x_n + k]|^2
+// where K(q) = { k : |k + q|_inf <= k_s/2 } is the part of the window whose partner stays inside
+// the search area (the reference's "B = 0 outside the area" rule, similarity.cu:43-47 ==
+// F.unfold zero padding, loss_util.py:208); K(q) is a sub-rectangle [ylo,yhi] x [xlo,xhi] of the
+// window that depends on q only.  Both parts are separable box sums of non-negative fields, so
+// everything here is plain additions of non-negative numbers: no sliding subtraction, no prefix
+// sums (both break the 1e-5 budget at sigma = 0.004).
+//
+// One workgroup (4 waves) owns a tile of 8 x 32 candidate centres.  Its (8+2*16) x (32+2*16) x C
+// image region sits in LDS.  Wave w walks the offset rows q_y = w, w+4, ...; inside a row the 25
+// (k_s) offsets q_x are fully unrolled: lane (r, g) keeps its own 16 pixels of U-row r (U = tile
+// grown by the window halo) in registers, slides the 16-pixel window of I[u+q] by one pixel per
+// step (3 LDS dwords), forms E, then the horizontal box sums of its 8 centre columns with
+// compile-time truncation [xlo,xhi], and writes them to the wave's H buffer.  The tile's edge
+// pixels (census from the rank map) then add the vertical taps [ylo,yhi], the |I|^2 complement,
+// apply exp and store e[n,q]; the row sums are accumulated on the fly and the rows are rescaled
+// by 1/(sum + eps) at the end (L2-resident re-read of what the workgroup just wrote).
+//
+// Cost: ~235 wave-instructions per (tile, offset) regardless of the number of edge pixels, against
+// 25 * 12.6 k lane-instructions per edge pixel for the direct kernels: break-even at ~27 edge
+// pixels per 256-pixel tile; the edge-list builder routes tiles above the threshold here.
+#include "ssg_common.hpp"
+
+namespace ssg {
+
+struct DenseParams {
+  const float *img[2];
+  float *out[2];
+  int nimg;
+  const int *rank;      // (B,H,W) row of every pixel, -1 if not an edge pixel
+  const int *n_dense;   // device count of dense tiles
+  const int *tiles;     // dense tile ids
+  int max_tiles;        // launch bound per image slot
+  const int *n_dev;     // rows computed at all (capacity clamp), nullable
+  int n_host;
+  int B, H, W;
+  float sigma, eps;
+  int generalization;
+  int dbg;  // profiling ablations: bit0 no stores, bit1 no edge stage, bit2 no E/H stage, bit3 no rescale
+};
+
+constexpr int DT_Y = 8, DT_X = 32;  // centres per tile
+
+template <int KS, int KW, int C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void ssg_fwd_dense(DenseParams p) {
+  constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK;
+  constexpr int RH = DT_Y + 2 * HALO, RWD = DT_X + 2 * HALO, RS = RWD + 1;  // image region
+  constexpr int UH = DT_Y + 2 * HK, UW = DT_X + 2 * HK;                      // window halo U
+  constexpr int LW = 8 + KW - 1;                                             // U columns per lane
+  constexpr int NE_MAX = DT_Y * DT_X, NCHUNK = NE_MAX / 64;
+  static_assert(UH == 16 && DT_X == 32, "lane map: 16 U-rows x 4 column groups of 8 centres");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *reg = smem;                       // [C][RH][RS]
+  float *F = reg + C * RH * RS;            // [UH][UW]   sum_c I^2 on U
+  float *HF = F + UH * UW;                 // [UH][DT_X] full-window horizontal sums of F
+  float *Hb = HF + UH * DT_X;              // [4][UH][DT_X] per-wave horizontal sums of E_q
+  float *rsum = Hb + 4 * UH * DT_X;        // [4][NE_MAX] per-wave partial row sums
+  int *elist = (int *)(rsum + 4 * NE_MAX); // [NE_MAX][3] (ey, ex, row)
+  int *misc = elist + NE_MAX * 3;          // [8]: wave counts, n_e
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int which = blockIdx.x / p.max_tiles, tslot = blockIdx.x - which * p.max_tiles;
+  if (tslot >= *p.n_dense) return;
+  const int H = p.H, W = p.W;
+  const int tx_n = (W + DT_X - 1) / DT_X, ty_n = (H + DT_Y - 1) / DT_Y;
+  const int tile = p.tiles[tslot];
+  const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
+  const int ty0 = (tr / tx_n) * DT_Y, tx0 = (tr % tx_n) * DT_X;
+  const int nrows = rows_to_do(p.n_dev, p.n_host);
+
+  // ---- census of the tile's edge pixels (row-major inside the tile) ----
+  {
+    const int ey = tid / DT_X, ex = tid % DT_X;
+    const int y = ty0 + ey, x = tx0 + ex;
+    int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+    if (r >= nrows) r = -1;
+    const unsigned long long bal = __ballot(r >= 0);
+    if (lane == 0) misc[wv] = __popcll(bal);
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; ++k) base += misc[k];
+    if (r >= 0) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      elist[3 * pos + 0] = ey;
+      elist[3 * pos + 1] = ex;
+      elist[3 * pos + 2] = r;
+    }
+    if (tid == 0) misc[4] = misc[0] + misc[1] + misc[2] + misc[3];
+  }
+  // ---- image region: C x RH x RWD, reflect by index mirroring (clamped: far corners of
+  // tiles that overhang a small image are never used, but must stay in bounds) ----
+  {
+    const float *src = p.img[which] + (size_t)b * C * H * W;
+    const int lx = tid % 16, lr = tid / 16;  // 16 lanes per row, 4 pixels each
+    for (int R0 = 0; R0 < C * RH; R0 += 16) {
+      const int R = R0 + lr;
+      if (R < C * RH) {
+        const int c = R / RH, ry = R - c * RH;
+        int gy = reflect_idx(ty0 - HALO + ry, H);
+        gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+        const float *srow = src + ((size_t)c * H + gy) * W;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int gx = reflect_idx(tx0 - HALO + lx * 4 + k, W);
+          gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+          v[k] = srow[gx];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reg[(c * RH + ry) * RS + lx * 4 + k] = v[k];
+      }
+    }
+  }
+  __syncthreads();
+  const int n_e = misc[4];
+  for (int i = tid; i < UH * UW; i += 256) {
+    const int ur = i / UW, uc = i - ur * UW;
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float v = reg[(c * RH + ur + HP) * RS + uc + HP];
+      t = __builtin_fmaf(v, v, t);
+    }
+    F[i] = t;
+  }
+  for (int i = tid; i < 4 * NE_MAX; i += 256) rsum[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < UH * DT_X; i += 256) {
+    const int ur = i / DT_X, tc = i - ur * DT_X;
+    float t = 0.f;
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) t += F[ur * UW + tc + kx];
+    HF[i] = t;
+  }
+  __syncthreads();
+
+  // ---- main loop: wave wv takes offset rows qyi = wv, wv+4, ... ----
+  const int r = lane >> 2, g = lane & 3;
+  float iu[C][LW];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int i = 0; i < LW; ++i) iu[c][i] = reg[(c * RH + r + HP) * RS + 8 * g + HP + i];
+  float *hb = Hb + wv * UH * DT_X;
+  float *hrow = hb + r * DT_X + 8 * g;
+  const float nk = -1.f / ((float)(C * KW * KW) * p.sigma);
+  float rs[NCHUNK];
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k) rs[k] = 0.f;
+  float *outp = p.out[which];
+  // this lane's edge pixels (one per chunk of 64 list entries), hoisted out of the offset loops
+  int hoff[NCHUNK], foff[NCHUNK];
+  size_t orow[NCHUNK];
+  bool eon[NCHUNK];
+#pragma unroll
+  for (int ck = 0; ck < NCHUNK; ++ck) {
+    const int e = ck * 64 + lane;
+    eon[ck] = e < n_e;
+    const int ec = eon[ck] ? e : 0;
+    const int ey = elist[3 * ec], ex = elist[3 * ec + 1];
+    hoff[ck] = (ey + HK) * DT_X + ex;
+    foff[ck] = (ey + HK) * UW + ex + HK;
+    orow[ck] = (size_t)elist[3 * ec + 2] * P;
+  }
+
+#pragma unroll 1
+  for (int qyi = wv; qyi < ((p.dbg & 64) ? 0 : KS); qyi += 4) {
+    const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
+    const float *rq = reg + (r + qyi) * RS + 8 * g;  // + c*RH*RS + column (i + qxi)
+    float w[C][LW];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int i = 0; i < LW; ++i) w[c][i] = rq[c * RH * RS + i];
+#pragma unroll
+    for (int qxi = 0; qxi < KS; ++qxi) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;  // folds: qxi is unrolled
+      // E_q on the lane's LW pixels
+      float E[LW];
+#pragma unroll
+      for (int i = 0; i < LW; ++i) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < ((p.dbg & 4) ? 0 : C); ++c) {
+          const float d = iu[c][i] - w[c][i];
+          t = __builtin_fmaf(d, d, t);
+        }
+        E[i] = t;
+      }
+      // horizontal box sums over taps [xlo, xhi] for the 8 centre columns
+      float Hs[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = E[j + HK + xlo];
+#pragma unroll
+        for (int kx = xlo + 1; kx <= xhi; ++kx) t += E[j + HK + kx];
+        Hs[j] = t;
+      }
+      if (!(p.dbg & 16)) {
+        *(float4 *)(hrow) = make_float4(Hs[0], Hs[1], Hs[2], Hs[3]);
+        *(float4 *)(hrow + 4) = make_float4(Hs[4], Hs[5], Hs[6], Hs[7]);
+      } else {
+        asm volatile("" ::"v"(Hs[0]), "v"(Hs[3]), "v"(Hs[7]));
+      }
+      // slide the window of I[u+q] (next q_x) while the H rows land
+      if (qxi + 1 < KS && !(p.dbg & 32)) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int i = 0; i + 1 < LW; ++i) w[c][i] = w[c][i + 1];
+          w[c][LW - 1] = rq[c * RH * RS + LW + qxi];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private buffer: lockstep hand-off
+      // ---- the tile's edge pixels: vertical taps, |I|^2 complement, exp, store ----
+      const int pofs = qyi * KS + qxi;
+#pragma unroll
+      for (int ck = 0; ck < NCHUNK; ++ck) {
+        if (ck * 64 < n_e && !(p.dbg & 2)) {
+          if (eon[ck]) {
+            // every tap is loaded unconditionally (all loads of the step in flight together) and
+            // selected by the wave-uniform row range [ylo,yhi]: a rolled `for kh` pays one LDS
+            // latency per tap (measured 10x slower)
+            const float *hc = hb + hoff[ck];
+            const float *fc = HF + hoff[ck];
+            float hv[KW], fv[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+              hv[k] = hc[(k - HK) * DT_X];   // horizontal sums of E_q, window row k
+              fv[k] = fc[(k - HK) * DT_X];   // whole-row |I|^2, used where the partner row leaves the area
+            }
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+              const bool in = (k - HK) >= ylo && (k - HK) <= yhi;
+              d += in ? hv[k] : fv[k];
+            }
+            // rows that stay, columns that leave (one-sided, compile-time set of <= HK columns)
+            if (xlo > -HK || xhi < HK) {
+              const float *f0 = F + foff[ck];
+              float cs[KW];
+#pragma unroll
+              for (int k = 0; k < KW; ++k) {
+                float t = 0.f;
+#pragma unroll
+                for (int kx = -HK; kx < xlo; ++kx) t += f0[(k - HK) * UW + kx];
+#pragma unroll
+                for (int kx = xhi + 1; kx <= HK; ++kx) t += f0[(k - HK) * UW + kx];
+                cs[k] = t;
+              }
+#pragma unroll
+              for (int k = 0; k < KW; ++k) {
+                const bool in = (k - HK) >= ylo && (k - HK) <= yhi;
+                d += in ? cs[k] : 0.f;
+              }
+            }
+            const float ev = expf(d * nk);
+            rs[ck] += ev;
+            if (!(p.dbg & 1)) outp[orow[ck] + pofs] = ev;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // H rows are overwritten by the next step
+    }
+  }
+
+  // ---- row sums over the four waves, then rescale the rows this workgroup wrote ----
+#pragma unroll
+  for (int ck = 0; ck < NCHUNK; ++ck)
+    if (ck * 64 + lane < n_e) rsum[wv * NE_MAX + ck * 64 + lane] = rs[ck];
+  __threadfence_block();
+  __syncthreads();
+  if (!p.generalization || (p.dbg & 8)) return;
+  // global stores of this workgroup must be visible to its own later loads: same CU, L1 is
+  // write-through, the loads below are issued after the barrier + vmcnt drain
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int e = wv; e < n_e; e += 4) {
+    const float tot = rsum[e] + rsum[NE_MAX + e] + rsum[2 * NE_MAX + e] + rsum[3 * NE_MAX + e];
+    const float scale = 1.f / (tot + p.eps);
+    float *o = outp + (size_t)elist[3 * e + 2] * P;
+    for (int q = lane; q < P; q += 64) o[q] = scale * __builtin_nontemporal_load(o + q);
+  }
+}
+
+// ------------------------------------------------------------------ host ----
+template <int KS, int KW, int C>
+static size_t dense_lds_bytes() {
+  constexpr int HALO = KS / 2 + KW / 2, RH = DT_Y + 2 * HALO, RS = DT_X + 2 * HALO + 1;
+  constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X;
+  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_X + 4 * UH * DT_X + 4 * NE) + sizeof(int) * (NE * 3 + 8);
+}
+
+bool dense_supported(int ks, int kw, int C) { return ks == 25 && kw == 9 && C == 3; }
+
+int dense_max_tiles(int B, int H, int W) { return B * ((H + DT_Y - 1) / DT_Y) * ((W + DT_X - 1) / DT_X); }
+
+int launch_fwd_dense(const DenseParams &p, int ks, int kw, int C, hipStream_t st) {
+  if (!dense_supported(ks, kw, C)) return -1;
+  const size_t lds = dense_lds_bytes<25, 9, 3>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)ssg_fwd_dense<25, 9, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  if (p.max_tiles == 0) return 0;
+  hipLaunchKernelGGL((ssg_fwd_dense<25, 9, 3>), dim3((unsigned)p.max_tiles * p.nimg), dim3(256), lds, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace ssg

@@ -173,13 +173,43 @@ __device__ __forceinline__ int tile_rank(const int *rank, int B, int H, int W, i
   return (y < H && x < W) ? rank[((size_t)b * H + y) * W + x] : -1;
 }
 
-__global__ __launch_bounds__(256) void tile_count(const int *rank, int B, int H, int W, int ntiles, int *cnt) {
+// super-tile (8 x 32 centres, the dense forward kernel's tile) that contains 8x8 tile `tile`
+__device__ __forceinline__ int super_tile_of(int tile, int H, int W) {
+  const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT, sx_n = (W + 31) / 32;
+  const int b = tile / (tx_n * ty_n), t = tile - b * tx_n * ty_n;
+  return (b * ty_n + t / tx_n) * sx_n + (t % tx_n) / 4;
+}
+
+// `skip` (nullable): per super-tile flag; tiles of flagged super-tiles contribute no rows (they are
+// the dense forward kernel's)
+__global__ __launch_bounds__(256) void tile_count(const int *rank, int B, int H, int W, int ntiles, int *cnt,
+                                                  const int *skip) {
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (tile >= ntiles) return;
   int nv;
   const int r = tile_rank(rank, B, H, W, tile, lane, nv);
   const unsigned long long bal = __ballot(r >= 0);
-  if (lane == 0) cnt[tile] = __popcll(bal);
+  if (lane == 0) cnt[tile] = (skip && skip[super_tile_of(tile, H, W)]) ? 0 : __popcll(bal);
+}
+
+// one workgroup per 8 x 32 super-tile: count its edge pixels, flag it dense at >= thr and append it
+// to the dense list (plan[1] = count, zeroed by the caller)
+__global__ __launch_bounds__(256) void plan_classify(const int *rank, int H, int W, int thr, int *dflag, int *plan,
+                                                     int *dense_ids) {
+  __shared__ int wc[4];
+  const int sx_n = (W + 31) / 32, ty_n = (H + OT - 1) / OT;
+  const int st = blockIdx.x, b = st / (sx_n * ty_n), t = st - b * sx_n * ty_n;
+  const int y = (t / sx_n) * OT + threadIdx.x / 32, x = (t % sx_n) * 32 + threadIdx.x % 32;
+  const int r = (y < H && x < W) ? rank[((size_t)b * H + y) * W + x] : -1;
+  const unsigned long long bal = __ballot(r >= 0);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = wc[0] + wc[1] + wc[2] + wc[3];
+    const int dense = thr > 0 && n >= thr;
+    dflag[st] = dense;
+    if (dense) dense_ids[atomicAdd(&plan[1], 1)] = st;
+  }
 }
 
 // exclusive scan of cnt[0..n) by one workgroup: the counts are staged in LDS with coalesced
@@ -188,7 +218,7 @@ __global__ __launch_bounds__(256) void tile_count(const int *rank, int B, int H,
 // offsets leave with coalesced stores.
 constexpr int SCAN_LDS = 16384;
 
-__global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int n) {
+__global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int n, int *total_out) {
   extern __shared__ int stage[];  // [SCAN_LDS] + [1024] + carry
   int *buf = stage + SCAN_LDS;
   int &carry = stage[SCAN_LDS + 1024];
@@ -222,12 +252,14 @@ __global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int 
     if (tid == 1023) carry += buf[1023];
     __syncthreads();
   }
+  if (total_out && tid == 0) *total_out = carry;
 }
 
 __global__ __launch_bounds__(256) void tile_scatter(const int *rank, int B, int H, int W, int ntiles, const int *off,
-                                                    int *order, int capacity) {
+                                                    int *order, int capacity, const int *skip) {
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (tile >= ntiles) return;
+  if (skip && skip[super_tile_of(tile, H, W)]) return;
   int nv;
   const int r = tile_rank(rank, B, H, W, tile, lane, nv);
   const unsigned long long bal = __ballot(r >= 0);
@@ -240,9 +272,9 @@ __global__ __launch_bounds__(256) void tile_scatter(const int *rank, int B, int 
 // Marks the groups of ORDER_GROUP consecutive jobs whose edge pixels are one image's and lie within
 // 8 rows x 16 columns (bit ORDER_FLAG of the group's first entry): the forward kernel variants pick
 // their groups from this flag with a single load.
-__global__ __launch_bounds__(256) void tile_group_flags(int *order, const int *edges, const int *counts, int capacity) {
+__global__ __launch_bounds__(256) void tile_group_flags(int *order, const int *edges, const int *n_ptr, int capacity) {
   const int g = blockIdx.x * 256 + threadIdx.x;
-  int n = counts[0];
+  int n = n_ptr[0];
   n = n < capacity ? n : capacity;
   const int k0 = g * ORDER_GROUP;
   if (k0 >= n) return;
@@ -266,35 +298,56 @@ __global__ __launch_bounds__(256) void tile_group_flags(int *order, const int *e
 
 // ------------------------------------------------------------------ host ----
 static size_t n_order_tiles(int B, int H, int W) { return (size_t)B * ((H + OT - 1) / OT) * ((W + OT - 1) / OT); }
+static size_t n_super_tiles(int B, int H, int W) { return (size_t)B * ((H + OT - 1) / OT) * ((W + 31) / 32); }
 
 size_t edge_scratch_bytes(int B, int H, int W) {
   const size_t nblk = (size_t)B * (((size_t)H * W + CHUNK - 1) / CHUNK);
-  return (2 * nblk + 2 * n_order_tiles(B, H, W)) * sizeof(int) + 64;
+  return (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64;
+}
+
+// forward plan: [0] n_sparse, [1] n_dense, [2..3] -, [4, 4+n_super_tiles) the dense kernel's super-tile
+// ids, then (capacity) the tile-major order of the rows the direct kernels compute
+int fwd_plan_order_offset(int B, int H, int W) { return 4 + (int)n_super_tiles(B, H, W); }
+
+size_t fwd_plan_bytes(int B, int H, int W, int capacity) {
+  return sizeof(int) * (4 + (size_t)(capacity > 0 ? capacity : 1) + n_super_tiles(B, H, W));
+}
+
+static void build_order(const int *rank, int B, int H, int W, int *order, int capacity, const int *edges,
+                        const int *n_ptr, int *total_out, const int *skip, int *tcnt, int *toff, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(int) * (SCAN_LDS + 1024 + 4)));
+    attr_set = true;
+  }
+  const int nt = (int)n_order_tiles(B, H, W);
+  hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, skip);
+  hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), sizeof(int) * (SCAN_LDS + 1024 + 4), st, tcnt, toff, nt, total_out);
+  hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity, skip);
+  const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
+  if (ngroups > 0)
+    hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256), dim3(256), 0, st, order, edges,
+                       total_out ? total_out : n_ptr, capacity);
 }
 
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
-                     int *edges, int capacity, int *counts, int *rank, int *order, void *scratch, hipStream_t st) {
+                     int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
+                     void *scratch, hipStream_t st) {
   EdgeParams p{mask, kind, mask_channels, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
   const int nblk = B * p.nblk_img;
   int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;
   hipLaunchKernelGGL(edge_count, dim3(nblk), dim3(256), 0, st, p, blockcnt);
   hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts);
   hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank);
-  if (order) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void *)tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(int) * (SCAN_LDS + 1024 + 4)));
-      attr_set = true;
-    }
-    const int nt = (int)n_order_tiles(B, H, W);
-    int *tcnt = blockoff + nblk, *toff = tcnt + nt;
-    hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt);
-    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), sizeof(int) * (SCAN_LDS + 1024 + 4), st, tcnt, toff, nt);
-    hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity);
-    const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
-    if (ngroups > 0)
-      hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256), dim3(256), 0, st, order, edges, counts, capacity);
+  const int nt = (int)n_order_tiles(B, H, W);
+  int *tcnt = blockoff + nblk, *toff = tcnt + nt, *dflag = toff + nt;
+  if (order) build_order(rank, B, H, W, order, capacity, edges, counts, nullptr, nullptr, tcnt, toff, st);
+  if (plan) {
+    const int ns = (int)n_super_tiles(B, H, W);
+    (void)hipMemsetAsync(plan, 0, 4 * sizeof(int), st);
+    hipLaunchKernelGGL(plan_classify, dim3(ns), dim3(256), 0, st, rank, H, W, dense_thr, dflag, plan, plan + 4);
+    build_order(rank, B, H, W, plan + 4 + ns, capacity, edges, nullptr, plan, dflag, tcnt, toff, st);
   }
   return (int)hipGetLastError();
 }

@@ -33,11 +33,14 @@ def _f32c(t):
 class EdgeList(tuple):
     """(edges, counts) -- unpacks like the pair it always was -- plus `.rank`, the (B,H,W) int32
     rank map (row of `edges` holding each pixel, -1 elsewhere), and `.order`, the tile-major
-    permutation of the rows that the backward kernels use as their job order."""
+    permutation of the rows that the backward kernels use as their job order, and `.plan`, the
+    forward's work split between the dense-tile kernel and the direct kernels.  `.fwd` bundles
+    what the forward entry points take."""
 
-    def __new__(cls, edges, counts, rank, order):
+    def __new__(cls, edges, counts, rank, order, plan):
         self = super().__new__(cls, (edges, counts))
-        self.edges, self.counts, self.rank, self.order = edges, counts, rank, order
+        self.edges, self.counts, self.rank, self.order, self.plan = edges, counts, rank, order, plan
+        self.fwd = (order, rank, plan)
         return self
 
 
@@ -70,11 +73,12 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     counts = torch.empty(B + 2, dtype=torch.int32, device=dev)
     rank = torch.empty((B, H, W), dtype=torch.int32, device=dev)
     order = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    plan = torch.empty(L.ssg_forward_plan_bytes(B, H, W, capacity) // 4, dtype=torch.int32, device=dev)
     scratch = torch.empty(L.ssg_edge_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
     _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold),
-                               _ptr(edges), capacity, _ptr(counts), _ptr(rank), _ptr(order), _ptr(scratch),
-                               _stream()))
-    return EdgeList(edges, counts, rank, order)
+                               _ptr(edges), capacity, _ptr(counts), _ptr(rank), _ptr(order), _ptr(plan),
+                               _ptr(scratch), _stream()))
+    return EdgeList(edges, counts, rank, order, plan)
 
 
 def edge_mask_laplacian(gt, lap_threshold=20.0, mask_stride=0):
@@ -94,13 +98,14 @@ class _SSGMapFn(torch.autograd.Function):
     """SSG rows of a batch for a given edge list (loss_util.py:182-244 + autograd)."""
 
     @staticmethod
-    def forward(ctx, img, edges, counts, n_rows, ks, kw, sigma, eps, generalization, order):
+    def forward(ctx, img, edges, counts, n_rows, ks, kw, sigma, eps, generalization, order, fwd):
         x = _f32c(img)
+        f_order, f_rank, f_plan = fwd if fwd is not None else (order, None, None)
         B, C, H, W = x.shape
         ssg = torch.empty((n_rows, ks * ks), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().ssg_map_forward(_ptr(x), None, B, C, H, W, _ptr(edges), _ptr(order), _ptr(counts), n_rows,
-                                              ks, kw, float(sigma), float(eps), int(bool(generalization)), _ptr(ssg),
-                                              None, _stream()))
+        _lib.check(_lib.lib().ssg_map_forward(_ptr(x), None, B, C, H, W, _ptr(edges), _ptr(f_order), _ptr(f_rank),
+                                              _ptr(f_plan), _ptr(counts), n_rows, ks, kw, float(sigma), float(eps),
+                                              int(bool(generalization)), _ptr(ssg), None, _stream()))
         ctx.save_for_backward(x, edges, counts, ssg)
         ctx.order = order
         ctx.cfg = (n_rows, ks, kw, float(sigma), int(bool(generalization)))
@@ -116,22 +121,24 @@ class _SSGMapFn(torch.autograd.Function):
         grad = torch.zeros_like(x)
         _lib.check(_lib.lib().ssg_map_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(ctx.order), _ptr(counts), n_rows,
                                                ks, kw, sigma, gen, _ptr(ssg), _ptr(g), _ptr(grad), _stream()))
-        return grad, None, None, None, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None, None, None, None
 
 
-def ssg_map(img, edges, counts, n_rows, ks, kw, sigma, eps=1e-10, generalization=True, order=None):
+def ssg_map(img, edges, counts, n_rows, ks, kw, sigma, eps=1e-10, generalization=True, order=None, fwd=None):
     """(n_rows, ks*ks) SSG rows of `img` (B,C,H,W) at `edges`; differentiable w.r.t. img.
-    `order` (EdgeList.order) is the backward kernel's tile-major job order."""
+    `order` (EdgeList.order) is the backward kernel's tile-major job order, `fwd` (EdgeList.fwd)
+    the forward's (order, rank map, dense/direct plan)."""
     _need_gpu(img, edges, counts, order)
-    return _SSGMapFn.apply(img, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization, order)
+    return _SSGMapFn.apply(img, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization, order, fwd)
 
 
 class _SSGLossFn(torch.autograd.Function):
     """(l1, kl) of the caller loop realesrganssl_model.py:379-430 over a batch."""
 
     @staticmethod
-    def forward(ctx, sr, gt, edges, counts, n_rows, ks, kw, sigma, eps, generalization, w_l1, w_kl, order):
+    def forward(ctx, sr, gt, edges, counts, n_rows, ks, kw, sigma, eps, generalization, w_l1, w_kl, order, fwd):
         L = _lib.lib()
+        f_order, f_rank, f_plan = fwd if fwd is not None else (order, None, None)
         x, y = _f32c(sr), _f32c(gt)
         B, C, H, W = x.shape
         dev = x.device
@@ -141,8 +148,9 @@ class _SSGLossFn(torch.autograd.Function):
         loss = torch.zeros(2, dtype=torch.float32, device=dev)
         scratch = torch.empty(L.ssg_loss_scratch_bytes(B, H, W, n_rows, ks), dtype=torch.uint8, device=dev)
         gen = int(bool(generalization))
-        _lib.check(L.ssg_map_forward(_ptr(x), _ptr(y), B, C, H, W, _ptr(edges), _ptr(order), _ptr(counts), n_rows, ks,
-                                     kw, float(sigma), float(eps), gen, _ptr(ssg_sr), _ptr(ssg_gt), _stream()))
+        _lib.check(L.ssg_map_forward(_ptr(x), _ptr(y), B, C, H, W, _ptr(edges), _ptr(f_order), _ptr(f_rank), _ptr(f_plan),
+                                     _ptr(counts), n_rows, ks, kw, float(sigma), float(eps), gen, _ptr(ssg_sr),
+                                     _ptr(ssg_gt), _stream()))
         _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(order), _ptr(counts), n_rows, ks, kw,
                                        float(sigma), gen, _ptr(ssg_sr), _ptr(ssg_gt), float(w_l1), float(w_kl), None,
                                        _ptr(loss), None, _ptr(scratch), _stream()))
@@ -164,15 +172,15 @@ class _SSGLossFn(torch.autograd.Function):
         _lib.check(_lib.lib().ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(ctx.order), _ptr(counts), n_rows,
                                                 ks, kw, sigma, gen, _ptr(ssg_sr), _ptr(ssg_gt), w_l1, w_kl, _ptr(up),
                                                 _ptr(dummy), _ptr(grad), _ptr(scratch), _stream()))
-        return (grad,) + (None,) * 12
+        return (grad,) + (None,) * 13
 
 
 def ssg_loss(sr, gt, edges, counts, n_rows, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0,
-             w_kl=1.0, order=None):
+             w_kl=1.0, order=None, fwd=None):
     """Differentiable (l1, kl) for a batch given a device edge list; n_rows bounds N."""
     _need_gpu(sr, gt, edges, counts, order)
     return _SSGLossFn.apply(sr, gt, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization, w_l1,
-                            w_kl, order)
+                            w_kl, order, fwd)
 
 
 class LossStep:

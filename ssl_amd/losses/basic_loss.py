@@ -89,4 +89,4 @@ class SSGLoss(nn.Module):
                               lap_threshold=self.lap_threshold, capacity=cap)
         self.last_counts = el.counts
         return engine.ssg_loss(sr, gt.detach(), el.edges, el.counts, cap, self.ks, self.kw, self.sigma, self.eps,
-                               self.generalization, self.w_l1, self.w_kl, order=el.order)
+                               self.generalization, self.w_l1, self.w_kl, order=el.order, fwd=el.fwd)

@@ -51,7 +51,7 @@ class similarity_map():
         el = engine.edge_list(mask=mask, capacity=img.shape[-1] * img.shape[-2])
         num = int(el.counts[0].item())    # the reference synchronises here too (torch.where / nonzero)
         s = engine.ssg_map(img, el.edges, el.counts, num, kernel_size_search, kernel_size_window, sigma, eps,
-                           generalization, order=el.order)
+                           generalization, order=el.order, fwd=el.fwd)
         self.s = s.unsqueeze(0)           # 1, num, k_s*k_s
 
     def ssl_pytorch(self, img, mask, kernel_size_search=25, kernel_size_window=9, sigma=1.0, generalization=False):

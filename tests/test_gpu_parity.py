@@ -498,3 +498,41 @@ def test_diffusion_fork_strategies(dev, strategy):
     assert bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
     with pytest.raises(NotImplementedError):
         dm_similarity_map(x, T(mask[None, None], dev), simself_strategy="imgimg")
+
+
+def test_experimental_dense_forward_kernel_parity(dev):
+    """The opt-in shared-term ("dense tile") forward kernel (SSG_DENSE_THR > 0, ssg_dense.hip): every tile
+    routed through it, SSG rows and the loss step vs the oracle.  Runs in a subprocess because the
+    threshold is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import ssg_oracle as orc
+from ssl_amd import engine, synth
+dev = torch.device("cuda:0")
+ks, kw = 25, 9
+gt = np.stack([synth.natural_like(1600 + i, 72, 100, 0.15, 0.05) for i in range(2)])
+sr = np.stack([synth.degrade(gt[i], 1700 + i, 0.04) for i in range(2)])
+mask = np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(2)])
+mask[:, 0, 0] = mask[:, -1, -1] = 1
+for sigma in (0.004, 1.0):
+    ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask, ks, kw, sigma, 1e3, 1e3)
+    step = engine.LossStep(2, 3, 72, 100, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
+    loss, grad = step(torch.as_tensor(sr, device=dev), torch.as_tensor(gt, device=dev),
+                      torch.as_tensor(mask[:, None].astype(np.float32), device=dev))
+    n = int(step.counts[0])
+    assert n == ref["n_edges"]
+    e1 = np.abs(step.ssg_sr[:n].cpu().numpy() - ref["s_sr"]).max()
+    e2 = np.abs(step.ssg_gt[:n].cpu().numpy() - ref["s_gt"]).max()
+    l = loss.cpu().numpy()
+    assert e1 <= 1e-5 and e2 <= 1e-5, (e1, e2)
+    assert abs(l[0] - ref["l1"]) <= 1e-5 * ref["l1"] and abs(l[1] - ref["kl"]) <= 1e-5 * ref["kl"] + 2e-8
+print("dense ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSG_DENSE_THR="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "dense ok" in out.stdout, out.stdout[-3000:]
