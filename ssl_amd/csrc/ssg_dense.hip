@@ -25,9 +25,20 @@
 // Cost: ~235 wave-instructions per (tile, offset) regardless of the number of edge pixels, against
 // 25 * 12.6 k lane-instructions per edge pixel for the direct kernels: break-even at ~27 edge
 // pixels per 256-pixel tile; the edge-list builder routes tiles above the threshold here.
+#include <type_traits>
+#include <utility>
+
 #include "ssg_common.hpp"
 
 namespace ssg {
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), fully inlined
+// (a `#pragma unroll` over the offset loop was NOT honoured for this body: hipcc kept it rolled and
+// indexed the register arrays through M0, s_set_gpr_idx_on)
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
 
 struct DenseParams {
   const float *img[2];
@@ -179,19 +190,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int i = 0; i < LW; ++i) w[c][i] = rq[c * RH * RS + i];
-#pragma unroll
-    for (int qxi = 0; qxi < KS; ++qxi) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;  // folds: qxi is unrolled
-      // E_q on the lane's LW pixels
+    static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
+      constexpr int qxi = decltype(qc)::value;
+      constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
+      // E_q on the lane's LW pixels; the window of I[u+q] is a circular buffer whose slot index is
+      // a compile-time function of the step: pixel i of step qxi lives in slot (i + qxi) % LW
       float E[LW];
 #pragma unroll
       for (int i = 0; i < LW; ++i) {
         float t = 0.f;
 #pragma unroll
         for (int c = 0; c < ((p.dbg & 4) ? 0 : C); ++c) {
-          const float d = iu[c][i] - w[c][i];
+          const float d = iu[c][i] - w[c][(i + qxi) % LW];
           t = __builtin_fmaf(d, d, t);
         }
         E[i] = t;
@@ -211,14 +221,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       } else {
         asm volatile("" ::"v"(Hs[0]), "v"(Hs[3]), "v"(Hs[7]));
       }
-      // slide the window of I[u+q] (next q_x) while the H rows land
+      // next q_x: the pixel that leaves the window (slot qxi % LW) is replaced by the one that enters
       if (qxi + 1 < KS && !(p.dbg & 32)) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-#pragma unroll
-          for (int i = 0; i + 1 < LW; ++i) w[c][i] = w[c][i + 1];
-          w[c][LW - 1] = rq[c * RH * RS + LW + qxi];
-        }
+        for (int c = 0; c < C; ++c) w[c][qxi % LW] = rq[c * RH * RS + LW + qxi];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private buffer: lockstep hand-off
       // ---- the tile's edge pixels: vertical taps, |I|^2 complement, exp, store ----
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
               d += in ? hv[k] : fv[k];
             }
             // rows that stay, columns that leave (one-sided, compile-time set of <= HK columns)
-            if (xlo > -HK || xhi < HK) {
+            if constexpr (xlo > -HK || xhi < HK) {
               const float *f0 = F + foff[ck];
               float cs[KW];
 #pragma unroll
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // H rows are overwritten by the next step
-    }
+    });
   }
 
   // ---- row sums over the four waves, then rescale the rows this workgroup wrote ----

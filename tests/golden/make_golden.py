@@ -268,6 +268,109 @@ def f7_mask_pil():
     save("f7_edge_mask", rgb=u8, gray=L, lap=lap, mask=mask.astype(np.uint8))
 
 
+def load_reference_dm():
+    """The Diffusion-Based-SR fork's loss_util.py, imported by path.  Its only native dependency is
+    `compute_similarity` (the CUDA operator, similaritywrapper.py:59-69); here it is backed by the fp64 CPU
+    oracle's distance (pinned to the reference by F1-F6; the fork's own F.unfold strategy
+    `areaarea_mask_nonlocal` cross-checks it below) wrapped as a torch autograd function, so every epilogue
+    that runs is the reference's own code."""
+    from oracle import ssg_oracle as orc
+
+    class _Dist(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, image, mask, psize, ksize):
+            pos = orc.mask_to_pos(mask.numpy())
+            img = image.detach().numpy().astype(np.float64)
+            ctx.meta = (img, pos, psize, ksize, image.dtype)
+            return torch.as_tensor(orc.distance(img, pos, psize, ksize)).to(image.dtype)
+
+        @staticmethod
+        def backward(ctx, g):
+            img, pos, psize, ksize, dt = ctx.meta
+            gi = orc.distance_backward(img, pos, psize, ksize, g.numpy().astype(np.float64))
+            return torch.as_tensor(gi).to(dt), None, None, None
+
+    stub = types.ModuleType("basicsr.losses.similarity.similaritywrapper")
+    stub.compute_similarity = lambda image, mask, psize=25, ksize=9: _Dist.apply(image, mask, psize, ksize)
+    for name in ("basicsr", "basicsr.losses", "basicsr.losses.similarity"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    saved = sys.modules.get("basicsr.losses.similarity.similaritywrapper")
+    sys.modules["basicsr.losses.similarity.similaritywrapper"] = stub
+    spec = importlib.util.spec_from_file_location(
+        "ref_dm_loss_util", "/root/reference/Diffusion-Based-SR/basicsr/losses/loss_util.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if saved is not None:
+        sys.modules["basicsr.losses.similarity.similaritywrapper"] = saved
+    return mod
+
+
+def f8_dm_strategies():
+    """F8: every operator-based `simself_strategy` of the Diffusion fork's similarity_map
+    (DM loss_util.py:299-363) + trainable_similarity_map (:1448-1481), fp64, on one 3x48x64 GT/SR pair."""
+    dm = load_reference_dm()
+    ks, kc, sigma = 11, 5, 0.05
+    H, W = 48, 64
+    gt = synth.natural_like(800, H, W)[None]
+    sr = synth.degrade(gt[0], 801)[None]
+    m1 = synth.laplacian_edge_mask(gt[0]).astype(np.float32)
+    rng = np.random.default_rng(8)
+    m3 = np.stack([m1, m1 * (rng.random((H, W)) < 0.6), np.roll(m1, 3, axis=1)]).astype(np.float32)
+    out = dict(gt=gt, sr=sr, mask=m1.astype(np.uint8), mask3=m3.astype(np.uint8), ks=ks, kc=kc, sigma=sigma,
+               kc_list=np.array([3, 5, 7]), largest_k=16, dh=16, dw=32, sigma_raw=sigma * 3 * kc * kc)
+    G, S = torch.as_tensor(gt, dtype=torch.float64), torch.as_tensor(sr, dtype=torch.float64)
+    M1, M3 = torch.as_tensor(m1[None, None], dtype=torch.float64), torch.as_tensor(m3[None], dtype=torch.float64)
+    common = dict(kernel_size=ks, softmax=True, dh=16, dw=32)
+
+    def run(strategy, **kw):
+        a = dict(common, simself_strategy=strategy, scaling_factor=sigma, kernel_size_center=kc, mask=M1)
+        a.update(kw)
+        return dm.similarity_map(G, **a)
+
+    raw = sigma * 3 * kc * kc     # the un-averaged strategies divide D itself by sigma
+    P = "areaarea_mask_"
+    out["nonlocal"] = run(P + "nonlocal", scaling_factor=raw).getitem()[0].numpy()
+    out["nonlocal_cuda_v1"] = run(P + "nonlocal_cuda_v1", scaling_factor=raw).getitem()[0].numpy()
+    assert np.abs(out["nonlocal"] - out["nonlocal_cuda_v1"]).max() < 1e-12   # unfold twin == operator + epilogue
+    out["nonlocal_cuda_v1_patch"] = run(P + "nonlocal_cuda_v1_patch", scaling_factor=raw).getitem()[0].numpy()
+    out["nonlocal_cuda_v2"] = run(P + "nonlocal_cuda_v2", scaling_factor=0.5).getitem()[0].numpy()
+    for name in ("nonlocalavg_cuda_v1", "nonlocalavg_cuda_v2", "eulardistanceavg_cuda_v1", "nonlocalavg_cuda_v3"):
+        out[name] = run(P + name).getitem()[0].numpy()
+    out["nonlocalavg_cuda_v1_nosoftmax"] = run(P + "nonlocalavg_cuda_v1", softmax=False).getitem()[0].numpy()
+    out["nonlocalavg_cuda_v4"] = run(P + "nonlocalavg_cuda_v4", kernel_size_center=[3, 5, 7]).getitem()[0].numpy()
+    out["nonlocalavg_cuda_v1RGB"] = run(P + "nonlocalavg_cuda_v1RGB", mask=M3).getitem()[0].numpy()
+    out["nonlocalavg_cuda_v5_sum"] = run(P + "nonlocalavg_cuda_v5", gene_type="sum").getitem()[0].numpy()
+    out["nonlocalavg_cuda_v5_softmax_top16"] = run(P + "nonlocalavg_cuda_v5", gene_type="softmax",
+                                                   largest_k=16).getitem()[0].numpy()
+    mh = dm.similarity_map(G, mask=M1, img_sr=S, simself_strategy=P + "nonlocalavg_cuda_maxh_v1", kernel_size=ks,
+                           scaling_factor=sigma, softmax=True, kernel_size_center=kc)
+    a, b = mh.getitem_simmutual()
+    out["maxh_gt"], out["maxh_sr"] = a[0].numpy(), b[0].numpy()
+    # learnable bandwidth: maps + d(loss)/d(sigma) and d(loss)/d(sr) of loss = sum((s_gt - s_sr)^2)
+    tm = dm.trainable_similarity_map(scaling_factor=sigma).double()
+    Sg = S.clone().requires_grad_(True)
+    s0, s1 = tm(G, Sg, M1, kernel_size_search=ks, kernel_size_center=kc, softmax=True)
+    loss = (s0 - s1).pow(2).sum()
+    loss.backward()
+    out["trainable_s_gt"], out["trainable_s_sr"] = s0[0].detach().numpy(), s1[0].detach().numpy()
+    out["trainable_loss"] = float(loss.detach())
+    out["trainable_dsigma"] = tm.sigma.grad.numpy()
+    out["trainable_dsr"] = Sg.grad.numpy()
+    # gradient of one epilogue variant through the operator: d sum(s * cot) / d img for v2 (centre removed)
+    Gg = G.clone().requires_grad_(True)
+    s = dm.similarity_map(Gg, mask=M1, simself_strategy=P + "nonlocalavg_cuda_v2", kernel_size=ks,
+                          scaling_factor=sigma, softmax=True, kernel_size_center=kc).getitem()
+    cot = torch.as_tensor(smooth_cotangent(tuple(s.shape), 88))
+    (s * cot).sum().backward()
+    out["v2_cotangent_seed"] = 88
+    out["v2_dimg"] = Gg.grad.numpy()
+    out["row_step"] = 4      # SSG maps are stored as rows [::4] to keep the fixture small
+    for k, v in list(out.items()):
+        if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size > 64:
+            out[k] = (v[::4] if v.ndim == 2 else v).astype(np.float32)
+    save("f8_dm_strategies", **out)
+
+
 def cpu_reference_timing():
     """time the reference ssl_pytorch loss step on this
     container's cores (one 3x256x256 image of the C2 batch, like the reference's
@@ -295,7 +398,7 @@ def cpu_reference_timing():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7"]
+    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8"]
     torch.manual_seed(0)
     if "f1" in which:
         f1_c1()
@@ -311,5 +414,7 @@ if __name__ == "__main__":
         f5_stride_f6_eps()
     if "f7" in which:
         f7_mask_pil()
+    if "f8" in which:
+        f8_dm_strategies()
     if "time" in which:
         cpu_reference_timing()

@@ -128,3 +128,32 @@ def test_two_rank_gloo_sharding_and_global_mean(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+def test_diffusion_fork_epilogue_table_matches_reference_fixture(monkeypatch):
+    """Host logic of ssl_amd.losses.dm_loss_util (every operator-based strategy + trainable_similarity_map)
+    vs fixture F8, which holds what the reference's own epilogues produced.  The device operator is replaced
+    by the oracle's distance here (checker standing in for the kernel; the GPU suite runs the same body
+    through the C ABI); the fused strategy `nonlocalavg_cuda_v1` has no host epilogue and is GPU-only."""
+    from oracle import ssg_oracle as orc
+    from ssl_amd.losses import dm_loss_util as dm
+    import dm_cases
+
+    class Dist(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, image, mask, psize, ksize):
+            pos = orc.mask_to_pos(mask.numpy())
+            img = image.detach().numpy().astype(np.float64)
+            ctx.meta = (img, pos, psize, ksize)
+            return torch.as_tensor(orc.distance(img, pos, psize, ksize)).float()
+
+        @staticmethod
+        def backward(ctx, g):
+            img, pos, psize, ksize = ctx.meta
+            return torch.as_tensor(orc.distance_backward(img, pos, psize, ksize, g.numpy().astype(np.float64))).float(), None, None, None
+
+    monkeypatch.setattr(dm, "compute_similarity", lambda image, mask, psize=25, ksize=9: Dist.apply(image, mask, psize, ksize))
+    worst = dm_cases.run_all(dm, torch.device("cpu"), skip=("nonlocalavg_cuda_v1",))
+    assert len(worst) >= 16
+    with pytest.raises(NotImplementedError):
+        dm.similarity_map(torch.zeros(1, 3, 8, 8), torch.ones(1, 1, 8, 8), simself_strategy="imgimg")

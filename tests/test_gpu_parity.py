@@ -500,6 +500,15 @@ def test_diffusion_fork_strategies(dev, strategy):
         dm_similarity_map(x, T(mask[None, None], dev), simself_strategy="imgimg")
 
 
+def test_diffusion_fork_all_operator_strategies_vs_reference_fixture(dev):
+    """Fixture F8: every operator-based strategy of the Diffusion fork + trainable_similarity_map, as the
+    reference's own epilogue code evaluated them, vs ssl_amd.losses.dm_loss_util on the HIP operator."""
+    from ssl_amd.losses import dm_loss_util as dm
+    import dm_cases
+    worst = dm_cases.run_all(dm, dev)
+    assert len(worst) >= 18
+
+
 def test_experimental_dense_forward_kernel_parity(dev):
     """The opt-in shared-term ("dense tile") forward kernel (SSG_DENSE_THR > 0, ssg_dense.hip): every tile
     routed through it, SSG rows and the loss step vs the oracle.  Runs in a subprocess because the
