@@ -24,15 +24,38 @@
 
 namespace ssg {
 
-template <class G>
-__device__ __forceinline__ void load_grow(const float *tg, const float *zrow, int ry, int cx0,
-                                          const bool (&colv)[G::PW], float (&out)[G::PW]) {
-  const float *rowp = ((unsigned)ry < (unsigned)G::KS) ? (tg + ry * G::S) : zrow;
+// out[j] = sum_{k=0}^{KW-1} v[j+k] for j < BS, BS <= KW: the taps BS-1 .. KW-1 belong to every window and are
+// summed once; window j adds the suffix v[j .. BS-2] and the prefix v[KW .. KW-1+j] (running sums).
+template <int BS, int KW>
+__device__ __forceinline__ void shared_window_sums(const float (&v)[BS + KW - 1], float (&out)[BS]) {
+  static_assert(BS <= KW, "windows must overlap in at least one tap");
+  float mid = v[BS - 1];
 #pragma unroll
-  for (int j = 0; j < G::PW; ++j) {
-    const float v = rowp[cx0 + j];
-    out[j] = colv[j] ? v : 0.f;
+  for (int k = BS; k < KW; ++k) mid += v[k];
+  float suf[BS], pre[BS];  // suf[j] = v[j] + ... + v[BS-2] (j < BS-1), pre[j] = v[KW] + ... + v[KW-1+j] (j >= 1)
+  suf[BS - 1] = 0.f;
+#pragma unroll
+  for (int j = BS - 2; j >= 0; --j) suf[j] = (j == BS - 2) ? v[j] : v[j] + suf[j + 1];
+  pre[0] = 0.f;
+#pragma unroll
+  for (int j = 1; j < BS; ++j) pre[j] = (j == 1) ? v[KW] : pre[j - 1] + v[KW - 1 + j];
+#pragma unroll
+  for (int j = 0; j < BS; ++j) {
+    float t = mid;
+    if (j < BS - 1) t += suf[j];
+    if (j > 0) t += pre[j];
+    out[j] = t;
   }
+}
+
+// Row `ry` of a job's zero-extended G tile, columns cx0 .. cx0+PW-1.  Tile rows are KS values followed
+// by HK zeros (stride KS+HK): the zeros after row r-1 are also the zeros before row r, so columns
+// -HK .. KS+HK-1 need no masking; rows outside the tile come from the all-zero row.
+template <class G>
+__device__ __forceinline__ void load_grow(const float *tg, const float *zrow, int ry, int cx0, float (&out)[G::PW]) {
+  const float *rowp = ((unsigned)ry < (unsigned)G::KS) ? (tg + ry * (G::KS + G::HK)) : zrow;
+#pragma unroll
+  for (int j = 0; j < G::PW; ++j) out[j] = rowp[cx0 + j];
 }
 
 // dL/dS of the two criteria at one element (a = s_sr, b = s_gt), and the
@@ -41,9 +64,18 @@ __device__ __forceinline__ float criteria_elem(float a, float b, float w1m, floa
   const float cl = 1e-10f;
   const float ac = fmaxf(a, cl), bc = fmaxf(b, cl);
   l1 += fabsf(a - b);
-  kl += bc * (logf(bc) - logf(ac));
+  // t (log t - log s) is evaluated as t log(t/s).  Both arguments are clamped to [1e-10, 1], so the ratio is a
+  // normal number and the hardware reciprocal / log2 apply without the range handling of logf() and operator/;
+  // v_log_f32 is relative-accurate (<= 1e-7) also next to 1 (profiles/r1_microbench_log.txt).  The KL sum
+  // cancels to second order where s ~ t, so a *systematic* relative error eps of the ratio would add eps to
+  // every row (v_rcp_f32 alone: 2e-5 of the loss on fixture F1): one Newton step makes the quotient correctly
+  // rounded, i.e. unbiased.
+  const float rc = __builtin_amdgcn_rcpf(ac);
+  const float r0 = bc * rc;
+  const float ratio = __builtin_fmaf(__builtin_fmaf(-r0, ac, bc), rc, r0);
+  kl += bc * (0.69314718056f * __builtin_amdgcn_logf(ratio));
   float g = a > b ? w1m : (a < b ? -w1m : 0.f);
-  if (a >= cl) g -= w2m * bc / ac;
+  if (a >= cl) g -= w2m * ratio;
   return g;
 }
 
@@ -58,7 +90,7 @@ template <class G, int KHC>
 __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
   constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
-  constexpr int JOBS = G::JOBS, PW = G::PW, S = G::S, CHG = G::CH;
+  constexpr int JOBS = G::JOBS, PW = G::PW, S = KS + HK, CHG = KS * S;  // G tile: row stride, size
   constexpr int PADF = (HK + 3) & ~3;
   constexpr int NCH = (KW + KHC - 1) / KHC;  // pass-B chunks of KHC stencil rows
   constexpr int SL = KHC * KW;               // partials per chunk
@@ -67,7 +99,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = p.C, H = p.H, W = p.W;
-  float *gt = smem + PADF;                    // [JOBS][KS][S]   G tiles
+  float *gt = smem + PADF;                    // [JOBS][KS][S]   G tiles, HK zeros after every row
   float *zero = gt + JOBS * CHG;              // zero row
   float *red = zero + ((G::ZROW + 3) & ~3);   // [JOBS][SL][LPJ] pass-B slice
   float *red2 = red + JOBS * SL * LPJ;        // [WG] scalar reductions
@@ -78,7 +110,16 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 
   const int tid = threadIdx.x;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
-  const int job0 = blockIdx.x * JOBS;
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  In tile order, job groups
+  // g and g+1 update overlapping gradient pixels: give every XCD one contiguous range of groups so
+  // that those atomics meet in one L2.
+  int grp = blockIdx.x;
+  if (p.order && !(p.dbg & 16)) {
+    const int ng = (nrows + JOBS - 1) / JOBS, per = (ng + 7) >> 3;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    grp = idx < per ? xcd * per + idx : ng;
+  }
+  const int job0 = grp * JOBS;
   if (job0 >= nrows) {
     if (p.mode == GRAD_LOSS && tid == 0) {
       p.partials[2 * blockIdx.x] = 0.f;
@@ -97,6 +138,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
     sh_edge[tid * 4 + 3] = row;
   }
   for (int i = tid; i < G::ZROW + 4; i += WG) zero[i] = 0.f;
+  for (int i = tid; i < JOBS * KS * HK; i += WG) gt[(i / HK) * S + KS + i % HK] = 0.f;
   if (tid < PADF) smem[tid] = 0.f;
   __syncthreads();
 
@@ -119,9 +161,6 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
     const int mo = m;
     const int by = mo / NB, bx = mo - by * NB;
     const int ry0 = BS * by - HK, cx0 = BS * bx - HK;
-    bool colv[PW];
-#pragma unroll
-    for (int j = 0; j < PW; ++j) colv[j] = (unsigned)(cx0 + j) < (unsigned)KS;
     const int eb = sh_edge[jl * 4 + 0], ey = sh_edge[jl * 4 + 1], ex = sh_edge[jl * 4 + 2];
     const int n = sh_edge[jl * 4 + 3];
     const bool job_on = lane_on && n >= 0;
@@ -261,36 +300,31 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 
     // window sum of Gz around every owned t (channel independent), streamed like pass A: per
     // patch row the k_w-tap horizontal sums, added to every block row the patch row pairs with
+    // (the BS windows of a block share their middle taps: the shared part is summed once and each window
+    // adds its own few taps on either side -- 2.3x fewer additions than BS independent k_w-tap sums)
     float box[BS][BS];
-#pragma unroll
-    for (int i = 0; i < BS; ++i)
-#pragma unroll
-      for (int j = 0; j < BS; ++j) box[i][j] = 0.f;
     {
+      float hrow[PW][BS];  // horizontal k_w-tap sums of the PW patch rows
       float bn[PW];
-      load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
+      load_grow<G>(tg, zrow, ry0, cx0, bn);
 #pragma unroll
       for (int r = 0; r < PW; ++r) {
         float bv[PW];
 #pragma unroll
         for (int j = 0; j < PW; ++j) bv[j] = bn[j];
-        if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
-        float hs[BS];
+        if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, bn);
+        shared_window_sums<BS, KW>(bv, hrow[r]);
+        pin_row<BS>(hrow[r]);
+      }
+      // vertical: box[i][j] = sum_{r=i}^{i+KW-1} hrow[r][j], same sharing along the rows
 #pragma unroll
-        for (int j = 0; j < BS; ++j) {
-          float t = bv[j];
+      for (int j = 0; j < BS; ++j) {
+        float col[PW], out[BS];
 #pragma unroll
-          for (int kx = 1; kx < KW; ++kx) t += bv[j + kx];
-          hs[j] = t;
-        }
+        for (int r = 0; r < PW; ++r) col[r] = hrow[r][j];
+        shared_window_sums<BS, KW>(col, out);
 #pragma unroll
-        for (int i = 0; i < BS; ++i) {
-          const int kh = r - i;
-          if (kh < 0 || kh >= KW) continue;
-#pragma unroll
-          for (int j = 0; j < BS; ++j) box[i][j] += hs[j];
-        }
-        pin_block<BS, BS>(box);
+        for (int i = 0; i < BS; ++i) box[i][j] = out[i];
       }
     }
 
@@ -335,13 +369,13 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 #pragma unroll
           for (int kx = 0; kx < KW; ++kx) af[kh][kx] = ac[(KW - 1 - kh) * KW + (KW - 1 - kx)];
         float bn[PW];
-        load_grow<G>(tg, zrow, ry0, cx0, colv, bn);
+        load_grow<G>(tg, zrow, ry0, cx0, bn);
 #pragma unroll
         for (int r = 0; r < PW; ++r) {
           float bv[PW];
 #pragma unroll
           for (int j = 0; j < PW; ++j) bv[j] = bn[j];
-          if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, colv, bn);
+          if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, bn);
 #pragma unroll
           for (int i = 0; i < BS; ++i) {
             const int kh = r - i;
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 #pragma unroll 1
         for (int r = 0; r < PW; ++r) {
           float bv[PW];
-          load_grow<G>(tg, zrow, ry0 + r, cx0, colv, bv);
+          load_grow<G>(tg, zrow, ry0 + r, cx0, bv);
 #pragma unroll
           for (int i = 0; i < BS; ++i) {
             const int kh = r - i;
@@ -397,13 +431,13 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
           for (int kx = 0; kx < KW; ++kx) pp[a][kx] = 0.f;
         // patch rows r = kh' + i, kh' in [kh0, kh0+KHC), i in [0,BS)
         float bn[PW];
-        load_grow<G>(tg, zrow, ry0 + kh0, cx0, colv, bn);
+        load_grow<G>(tg, zrow, ry0 + kh0, cx0, bn);
 #pragma unroll
         for (int rr = 0; rr < KHC + BS - 1; ++rr) {
           float bv[PW];
 #pragma unroll
           for (int j = 0; j < PW; ++j) bv[j] = bn[j];
-          if (rr + 1 < KHC + BS - 1) load_grow<G>(tg, zrow, ry0 + kh0 + rr + 1, cx0, colv, bn);
+          if (rr + 1 < KHC + BS - 1) load_grow<G>(tg, zrow, ry0 + kh0 + rr + 1, cx0, bn);
 #pragma unroll
           for (int a = 0; a < KHC; ++a) {
             const int i = rr - a;  // block row paired with stencil row kh0+a on this patch row
@@ -485,8 +519,9 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
             dy[j] = on ? sh_edge[j * 4 + 1] - my0 : -(1 << 20);
             dx[j] = on ? sh_edge[j * 4 + 2] - mx0 : -(1 << 20);
           }
+          const float inv_ww = 1.f / (float)ww;  // i / ww for i < MH * MW, exact in fp32
           for (int i = tid; i < wh * ww; i += WG) {
-            const int ry = i / ww, rx = i - ry * ww;
+            const int ry = (int)(((float)i + 0.5f) * inv_ww), rx = i - ry * ww;
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < JOBS; ++j) {
@@ -665,9 +700,11 @@ __global__ __launch_bounds__(1024) void ssg_loss_finalize(const float *partials,
 template <class G, int KHC>
 static size_t bwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
-  return sizeof(float) * (size_t)(PADF + G::JOBS * G::CH + ((G::ZROW + 3) & ~3) + G::JOBS * KHC * G::KW * G::LPJ +
+  return sizeof(float) * (size_t)(PADF + G::JOBS * G::KS * (G::KS + G::HK) + ((G::ZROW + 3) & ~3) + G::JOBS * KHC * G::KW * G::LPJ +
                                   G::WG + G::JOBS * 4 + G::JOBS * 4 + G::JOBS * (C + 1) * G::KW * G::KW + 8);
 }
+
+unsigned bwd_grid(const BwdParams &p);
 
 template <class G, int KHC>
 static int launch_bwd_tiled(const BwdParams &p, hipStream_t st) {
@@ -679,18 +716,20 @@ static int launch_bwd_tiled(const BwdParams &p, hipStream_t st) {
                               160 * 1024);
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((p.n_host + G::JOBS - 1) / G::JOBS);
+  const unsigned grid = bwd_grid(p);
   if (p.n_host == 0) return 0;
   hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(grid), dim3(G::WG), lds, st, p);
   return (int)hipGetLastError();
 }
 
 // Number of workgroups (= rows of `partials`) launch_bwd will use.
+// Tiled variants: a multiple of 8 workgroups, so that the XCD-contiguous group mapping covers every group.
 unsigned bwd_grid(const BwdParams &p) {
-  if (p.ks == 25 && p.kw == 9) return (unsigned)((p.n_host + Geo<25, 9, 5, 128>::JOBS - 1) / Geo<25, 9, 5, 128>::JOBS);
-  if (p.ks == 11 && p.kw == 5) return (unsigned)((p.n_host + Geo<11, 5, 4, 64>::JOBS - 1) / Geo<11, 5, 4, 64>::JOBS);
+  auto tiled = [&](int jobs) { return (unsigned)(((p.n_host + jobs - 1) / jobs + 7) / 8 * 8); };
+  if (p.ks == 25 && p.kw == 9) return tiled(Geo<25, 9, 5, 128>::JOBS);
+  if (p.ks == 11 && p.kw == 5) return tiled(Geo<11, 5, 4, 64>::JOBS);
   if (p.ks == 49 && p.kw == 13 && bwd_lds_bytes<Geo<49, 13, 7, 128>, 4>(p.C) <= 160 * 1024)
-    return (unsigned)((p.n_host + Geo<49, 13, 7, 128>::JOBS - 1) / Geo<49, 13, 7, 128>::JOBS);
+    return tiled(Geo<49, 13, 7, 128>::JOBS);
   return (unsigned)p.n_host;
 }
 
@@ -699,7 +738,7 @@ size_t bwd_max_partials(int B, int H, int W, int n_rows) {
   (void)B;
   (void)H;
   (void)W;
-  return n_rows > 0 ? (size_t)n_rows : 1;
+  return (size_t)(n_rows > 0 ? n_rows : 1) + 8;
 }
 
 int launch_bwd(const BwdParams &p, hipStream_t st) {
