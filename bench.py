@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a recorded HIP graph instead of "
+                    "launching its kernels one by one (measured: no difference, the step is not launch-bound)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,7 +163,7 @@ def main():
     sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
     n_edges = int(mask_np.sum())
     step = engine.LossStep(BATCH, C, H, W, KS, KW, SIGMA, EPS, True, W_L1, W_KL, device=dev,
-                           capacity=n_edges + 1024)
+                           capacity=n_edges + 1024, graph=args.graph)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -206,6 +208,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: batch 16 x 3x256x256 per GPU, Laplacian mask, k_s=25 k_w=9 sigma=1.0, "
                                    "L1+KL w=1e3, SSGs materialised",
+                       "launch": "HIP graph replay" if args.graph else "per-kernel",
                        "edge_px_per_gpu": n_edges, "mask_density": n_edges / (BATCH * H * W),
                        "input_checksum": synth.checksum(sr_np, gt_np, mask_np), "parallelism": f"images sharded x{world}",
                        "l1": float(loss[0]), "kl": float(loss[1])},

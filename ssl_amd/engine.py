@@ -189,10 +189,15 @@ class LossStep:
 
     This is the path bench.py times.  No host synchronisation happens inside; `counts[0]`
     (device) holds the edge-pixel count N of the last step, `loss` the two scalars.
+
+    graph=True records the step's ~17 launches (memset, edge-list builder, two forward variants,
+    backward, finalize) into a HIP graph on first use and replays it afterwards: nothing in the
+    step depends on host-side values (the edge count stays on the device), so the recording is
+    valid for any input CONTENT at the same addresses; a call with other tensors re-records.
     """
 
     def __init__(self, B, C, H, W, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0, w_kl=1.0,
-                 mask_stride=0, lap_threshold=20.0, capacity=None, device="cuda"):
+                 mask_stride=0, lap_threshold=20.0, capacity=None, device="cuda", graph=False):
         L = _lib.lib()
         self.shape = (B, C, H, W)
         self.cfg = (ks, kw, float(sigma), float(eps), int(bool(generalization)), float(w_l1), float(w_kl),
@@ -206,6 +211,8 @@ class LossStep:
         self.grad = torch.zeros((B, C, H, W), dtype=torch.float32, device=device)
         self.ws_bytes = L.ssg_loss_workspace_bytes(B, H, W, self.capacity, ks)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.use_graph = bool(graph)
+        self._graph, self._graph_key, self._graph_refs = None, None, None
 
     def edges(self):
         """View of the workspace's edge list (capacity,3) int32."""
@@ -227,9 +234,24 @@ class LossStep:
             assert mask.dtype == torch.float32
         if mp is not None:
             assert mp.is_contiguous()
-        self.grad.zero_()
-        _lib.check(_lib.lib().ssg_loss_fwd_bwd(_ptr(sr), _ptr(gt), _ptr(mp), kind, mc, B, C, H, W, ks, kw, sigma, eps,
-                                               gen, w_l1, w_kl, stride, thr, self.capacity, _ptr(self.ssg_sr),
-                                               _ptr(self.ssg_gt), _ptr(self.counts), _ptr(self.loss), _ptr(self.grad),
-                                               _ptr(self.ws), self.ws_bytes, _stream()))
+
+        def launch():
+            self.grad.zero_()
+            _lib.check(_lib.lib().ssg_loss_fwd_bwd(_ptr(sr), _ptr(gt), _ptr(mp), kind, mc, B, C, H, W, ks, kw, sigma,
+                                                   eps, gen, w_l1, w_kl, stride, thr, self.capacity, _ptr(self.ssg_sr),
+                                                   _ptr(self.ssg_gt), _ptr(self.counts), _ptr(self.loss),
+                                                   _ptr(self.grad), _ptr(self.ws), self.ws_bytes, _stream()))
+
+        if not self.use_graph:
+            launch()
+            return self.loss, self.grad
+        key = (_ptr(sr), _ptr(gt), _ptr(mp), kind, mc)
+        if self._graph is None or key != self._graph_key:
+            launch()                      # eager once: function attributes are set outside the recording
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launch()
+            self._graph, self._graph_key, self._graph_refs = g, key, (sr, gt, mp)   # keep the recorded buffers alive
+        self._graph.replay()
         return self.loss, self.grad

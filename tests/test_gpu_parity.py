@@ -504,6 +504,39 @@ def test_diffusion_fork_strategies(dev, strategy):
         dm_similarity_map(x, T(mask[None, None], dev), simself_strategy="imgimg")
 
 
+def test_loss_step_hip_graph_replay_matches_eager(dev):
+    """LossStep(graph=True): the recorded HIP graph must reproduce the per-kernel launches bit for bit in
+    the losses/SSGs (gradient: fp32 atomics, order-dependent) -- also after the input CONTENT changes at
+    the recorded addresses (different edge count: nothing host-side is baked into the recording) and after
+    a call with other tensors (re-record)."""
+    from ssl_amd import engine, synth
+    B, H, W, ks, kw, sigma = 2, 80, 96, 25, 9, 0.004
+    eager = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
+    graph = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, graph=True)
+    sr_np, gt_np, m_np = synth.make_batch(B, H, W, seed0=900)
+    sr, gt, mask = T(sr_np, dev), T(gt_np, dev), T(m_np, dev)
+
+    def same():
+        l0, g0 = eager(sr, gt, mask)
+        l1, g1 = graph(sr, gt, mask)
+        n = int(eager.counts[0])
+        assert int(graph.counts[0]) == n and n > 0
+        assert torch.equal(l0, l1)
+        assert torch.equal(eager.ssg_sr[:n], graph.ssg_sr[:n]) and torch.equal(eager.ssg_gt[:n], graph.ssg_gt[:n])
+        assert float((g0 - g1).abs().max()) <= 2e-6 * float(g0.abs().max())
+        return n
+
+    n1 = same()
+    n1b = same()                                   # replay
+    assert n1 == n1b and graph._graph is not None
+    sr2, gt2, m2 = synth.make_batch(B, H, W, seed0=950)
+    sr.copy_(T(sr2, dev)); gt.copy_(T(gt2, dev)); mask.copy_(T(m2, dev))   # new content, same addresses
+    n2 = same()
+    assert n2 != n1
+    sr, gt, mask = T(sr_np, dev), T(gt_np, dev), T(m_np, dev)              # new tensors: re-record
+    assert same() == n1
+
+
 def test_diffusion_fork_all_operator_strategies_vs_reference_fixture(dev):
     """Fixture F8: every operator-based strategy of the Diffusion fork + trainable_similarity_map, as the
     reference's own epilogue code evaluated them, vs ssl_amd.losses.dm_loss_util on the HIP operator."""
