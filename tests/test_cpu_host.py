@@ -157,3 +157,36 @@ def test_diffusion_fork_epilogue_table_matches_reference_fixture(monkeypatch):
     assert len(worst) >= 16
     with pytest.raises(NotImplementedError):
         dm.similarity_map(torch.zeros(1, 3, 8, 8), torch.ones(1, 1, 8, 8), simself_strategy="imgimg")
+
+
+def test_mask_files_roundtrip_and_density_report_format(tmp_path):
+    """ssl_amd.maskio: .mat written as the reference writes it (key 'mat', integer (H,W), compressed;
+    generate_mask.py:41) and read back as the datasets do (float32 (H,W,1),
+    my_realesrgan_image_mask_dataset.py:79-83); statis.txt lines as generate_mask_simmatrix.py:71-90."""
+    import scipy.io as sio
+    from ssl_amd import maskio
+    rng = np.random.default_rng(3)
+    m = (rng.random((37, 53)) < 0.1).astype(np.uint8)
+    path = str(tmp_path / "a.mat")
+    maskio.save_mask_mat(path, m)
+    raw = sio.loadmat(path)["mat"]
+    assert raw.shape == (37, 53) and np.issubdtype(raw.dtype, np.integer) and np.array_equal(raw, m)
+    assert os.path.getsize(path) < m.size * 8 // 4            # compressed
+    back = maskio.load_mask_mat(path)
+    assert back.dtype == np.float32 and back.shape == (37, 53, 1) and back.flags["C_CONTIGUOUS"]
+    assert np.array_equal(back[..., 0], m.astype(np.float32))
+    with pytest.raises(ValueError):
+        maskio.save_mask_mat(path, np.zeros((2, 3, 4)))
+    from PIL import Image
+    maskio.save_mask_png(str(tmp_path / "a.png"), m)
+    assert np.array_equal(np.array(Image.open(str(tmp_path / "a.png"))), m * 255)
+    rep = maskio.DensityReport(str(tmp_path / "statis.txt"))
+    rep.add("img0", 1000, 400, 80)
+    rep.add("img1", 2000, 500, 100)
+    lines = rep.close()
+    text = open(str(tmp_path / "statis.txt")).read()
+    assert text.startswith("img0:\nImage number-1000, grad number-400-0.4000, mask number-80-0.0800\n\nimg1:\n")
+    assert lines == ["Maximum of grad is 500.00, percentage is 0.250000", "Minium of grad is 400.00, percentage is 0.2000",
+                     "Average of grad is 450.00, percentage is 0.3000", "Maximum of mask is 100.00, percentage is 0.050000",
+                     "Minium of grad is 80.00, percentage is 0.0400", "Average of grad is 90.00, percentage is 0.0600"]
+    assert text.endswith("\n".join(lines) + "\n")

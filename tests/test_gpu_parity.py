@@ -504,6 +504,40 @@ def test_diffusion_fork_strategies(dev, strategy):
         dm_similarity_map(x, T(mask[None, None], dev), simself_strategy="imgimg")
 
 
+def test_offline_mask_tool_writes_reference_formats(dev, tmp_path):
+    """scripts/generate_mask.py (generate_mask.py:17-41 + generate_mask_simmatrix.py:22-92 on the GPU): PNG
+    inputs of two sizes incl. a greyscale file -> mat/png/statis.txt; masks bit-exact vs the oracle's
+    PIL-'L' + Laplacian restatement, counts in the report match."""
+    import importlib.util
+    import os
+    from PIL import Image
+    from ssl_amd import maskio, synth
+    src, out = tmp_path / "gt", tmp_path / "masks"
+    src.mkdir()
+    imgs = {}
+    for i, (h, w) in enumerate([(64, 80), (64, 80), (48, 40)]):
+        u8 = np.ascontiguousarray((synth.natural_like(700 + i, h, w) * 255 + 0.5).astype(np.uint8).transpose(1, 2, 0))
+        imgs[f"im{i}"] = u8
+        Image.fromarray(u8).save(str(src / f"im{i}.png"))
+    grey = (synth.natural_like(710, 40, 56)[0] * 255 + 0.5).astype(np.uint8)
+    imgs["grey"] = np.repeat(grey[..., None], 3, axis=2)
+    Image.fromarray(grey).save(str(src / "grey.png"))
+    spec = importlib.util.spec_from_file_location(
+        "generate_mask", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "generate_mask.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    assert tool.main(["--input", str(src), "--save", str(out), "--threshold", "20", "--statis", "--batch", "2"]) == 0
+    report = open(str(out / "statis.txt")).read()
+    for name, u8 in imgs.items():
+        want = orc.edge_mask_rgb8(u8, 20.0)
+        got = maskio.load_mask_mat(str(out / "mat" / f"{name}.mat"))
+        assert got.shape == want.shape + (1,) and np.array_equal(got[..., 0], want.astype(np.float32)), name
+        assert np.array_equal(np.array(Image.open(str(out / "png" / f"{name}.png"))), want * 255)
+        n, ng, nm = want.size, int(orc.edge_mask_rgb8(u8, 0.0).sum()), int(want.sum())
+        assert f"{name}:\nImage number-{n}, grad number-{ng}-{ng / n:.4f}, mask number-{nm}-{nm / n:.4f}\n" in report
+    assert "Average of grad is" in report
+
+
 def test_loss_step_hip_graph_replay_matches_eager(dev):
     """LossStep(graph=True): the recorded HIP graph must reproduce the per-kernel launches bit for bit in
     the losses/SSGs (gradient: fp32 atomics, order-dependent) -- also after the input CONTENT changes at
