@@ -52,7 +52,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   const int C = p.C, H = p.H, W = p.W;
   float *tiles = smem + PADF;                                      // [JOBS][C][KS][S] or [C][MH][MS]
   float *zero = tiles + (MERGED ? C * MH * MS : JOBS * C * CH);    // ZROW zeros (also absorbs tail over-reads)
-  float *red = zero + ((G::ZROW + 3) & ~3);                        // [WG] row-sum scratch
+  double *red = (double *)(zero + ((G::ZROW + 3) & ~3));           // [WG] row-sum scratch (8-byte aligned)
   int *sh_edge = (int *)(red + WG);                                // [JOBS][6]: b, y, x, row, which, pad
 
   const int tid = threadIdx.x;
@@ -303,8 +303,14 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   // ---- epilogue: e = exp(-(D/den)/sigma), row sum, normalise ----
   // -(D/(C k_w^2))/sigma as one multiply by a host-rounded constant: |x| differs from the
   // reference's two divisions by <= 1.5 ulp, i.e. e by < 1e-5 relative even at e ~ 1e-38
+  //
+  // The row sum and the scale 1/(sum + eps) are carried in fp64 and every s = fl32(e * scale) is rounded on its
+  // own.  With an fp32 scale all k_s^2 entries of a row share the scale's rounding error delta (~3e-8), and the
+  // KL criterion sum t log(t/s) -- second order in (t - s) -- picks up the full (delta_t - delta_s) per row:
+  // on flat rows (fixture F1) that is ~1.5e-5 of the loss, above the 1e-5 parity bar, for ANY fp32
+  // normalisation (the reference's own fp32 run included).  ~100 fp64 ops per lane, 1 % of the kernel.
   const float nk = -1.f / ((float)(C * KW * KW) * p.sigma);
-  float lsum = 0.f;
+  double lsum = 0.0;
 #pragma unroll
   for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -312,15 +318,18 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
       const int py = BS * by + i, px = BS * bx + j;
       const float e = (py < KS && px < KS) ? expf(acc[i][j] * nk) : 0.f;
       acc[i][j] = e;
-      lsum += e;
+      lsum += (double)e;
     }
   red[tid] = lsum;
   __syncthreads();  // also: every lane is done reading the tiles -> reuse as staging
-  float scale = 1.f;
   if (p.generalization) {
-    float tot = 0.f;
+    double tot = 0.0;
     for (int k = 0; k < LPJ; ++k) tot += red[jl * LPJ + k];
-    scale = 1.f / (tot + p.eps);
+    const double scale = 1.0 / (tot + (double)p.eps);
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) acc[i][j] = (float)((double)acc[i][j] * scale);
   }
   float *stage = tiles + (MERGED ? jl * P : (jl * C) * CH);  // >= P floats per job
   if (lane_on) {
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
         const int py = BS * by + i, px = BS * bx + j;
-        if (py < KS && px < KS) stage[py * KS + px] = scale * acc[i][j];
+        if (py < KS && px < KS) stage[py * KS + px] = acc[i][j];
       }
   }
   __syncthreads();
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_generic(FwdParams p) {
   const int ks = p.ks, kw = p.kw, hp = ks / 2, hk = kw / 2, P = ks * ks;
   const int C = p.C, H = p.H, W = p.W, tid = threadIdx.x;
   float *tile = smem;        // [C][ks][ks]
-  float *red = smem + C * P; // [256]
+  float *red = smem + ((C * P + 1) & ~1); // [256] doubles (8-byte aligned)
   const int nrows = rows_to_do(p.n_dev, p.n_host);
   const int q = blockIdx.x;
   if (q >= nrows * p.nimg) return;
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_generic(FwdParams p) {
   __syncthreads();
   const float den = (float)(C * kw * kw);
   float *o = p.out[which] + (size_t)n * P;
-  float lsum = 0.f;
+  double lsum = 0.0;
   for (int pidx = tid; pidx < P; pidx += 256) {
     const int py = pidx / ks, px = pidx - py * ks;
     float acc = 0.f;
@@ -380,16 +389,18 @@ __global__ __launch_bounds__(256) void ssg_fwd_generic(FwdParams p) {
     } else {
       const float ev = expf(-1.f * (acc / den) / p.sigma);
       o[pidx] = ev;  // normalised below
-      lsum += ev;
+      lsum += (double)ev;
     }
   }
   if (p.raw || !p.generalization) return;
-  red[tid] = lsum;
+  // fp64 row sum and scale, each entry rounded once (see the tiled kernel's epilogue)
+  double *dred = (double *)red;
+  dred[tid] = lsum;
   __syncthreads();
-  float tot = 0.f;
-  for (int k = 0; k < 256; ++k) tot += red[k];
-  const float scale = 1.f / (tot + p.eps);
-  for (int pidx = tid; pidx < P; pidx += 256) o[pidx] = scale * o[pidx];
+  double tot = 0.0;
+  for (int k = 0; k < 256; ++k) tot += dred[k];
+  const double scale = 1.0 / (tot + (double)p.eps);
+  for (int pidx = tid; pidx < P; pidx += 256) o[pidx] = (float)(scale * (double)o[pidx]);
 }
 
 // ------------------------------------------------------------------ host ----
@@ -398,7 +409,7 @@ static size_t fwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
   constexpr int MH = G::KS + 7, MS = G::KS + 16;
   const size_t tiles = MERGED ? (size_t)C * MH * MS : (size_t)G::JOBS * C * G::CH;
-  return sizeof(float) * (size_t)(PADF + tiles + ((G::ZROW + 3) & ~3) + 4 + G::WG) + sizeof(int) * 6 * G::JOBS;
+  return sizeof(float) * (size_t)(PADF + tiles + ((G::ZROW + 3) & ~3) + 4 + 2 * G::WG) + sizeof(int) * 6 * G::JOBS;
 }
 
 template <class G, bool MERGED>
@@ -437,7 +448,7 @@ int launch_fwd(const FwdParams &p_in, hipStream_t st) {
   if (p.ks == 11 && p.kw == 5) return launch_fwd_tiled<Geo<11, 5, 4, 64>, false>(p, st);
   if (p.ks == 49 && p.kw == 13 && fwd_lds_bytes<Geo<49, 13, 7, 128>, false>(p.C) <= 160 * 1024)
     return launch_fwd_tiled<Geo<49, 13, 7, 128>, false>(p, st);
-  const size_t lds = sizeof(float) * ((size_t)p.C * p.ks * p.ks + 256);
+  const size_t lds = sizeof(float) * ((size_t)p.C * p.ks * p.ks + 2 + 512);
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;
   if (!attr_set) {
