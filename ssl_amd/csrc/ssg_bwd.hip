@@ -728,8 +728,8 @@ unsigned bwd_grid(const BwdParams &p) {
   auto tiled = [&](int jobs) { return (unsigned)(((p.n_host + jobs - 1) / jobs + 7) / 8 * 8); };
   if (p.ks == 25 && p.kw == 9) return tiled(Geo<25, 9, 5, 128>::JOBS);
   if (p.ks == 11 && p.kw == 5) return tiled(Geo<11, 5, 4, 64>::JOBS);
-  if (p.ks == 49 && p.kw == 13 && bwd_lds_bytes<Geo<49, 13, 7, 128>, 4>(p.C) <= 160 * 1024)
-    return tiled(Geo<49, 13, 7, 128>::JOBS);
+  if (p.ks == 49 && p.kw == 13 && bwd_lds_bytes<Geo<49, 13, 7, 256>, 4>(p.C) <= 160 * 1024)
+    return tiled(Geo<49, 13, 7, 256>::JOBS);
   return (unsigned)p.n_host;
 }
 
@@ -744,8 +744,8 @@ size_t bwd_max_partials(int B, int H, int W, int n_rows) {
 int launch_bwd(const BwdParams &p, hipStream_t st) {
   if (p.ks == 25 && p.kw == 9) return launch_bwd_tiled<Geo<25, 9, 5, 128>, 3>(p, st);
   if (p.ks == 11 && p.kw == 5) return launch_bwd_tiled<Geo<11, 5, 4, 64>, 5>(p, st);
-  if (p.ks == 49 && p.kw == 13 && bwd_lds_bytes<Geo<49, 13, 7, 128>, 4>(p.C) <= 160 * 1024)
-    return launch_bwd_tiled<Geo<49, 13, 7, 128>, 4>(p, st);
+  if (p.ks == 49 && p.kw == 13 && bwd_lds_bytes<Geo<49, 13, 7, 256>, 4>(p.C) <= 160 * 1024)
+    return launch_bwd_tiled<Geo<49, 13, 7, 256>, 4>(p, st);
   const size_t lds = sizeof(float) * ((size_t)(p.C + 1) * p.ks * p.ks + 256);
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;
@@ -768,7 +768,7 @@ int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, in
 const char *bwd_kernel_name(int ks, int kw) {
   if (ks == 25 && kw == 9) return "ssg_bwd_tiled<Geo<25,9,5,128>,3>";
   if (ks == 11 && kw == 5) return "ssg_bwd_tiled<Geo<11,5,4,64>,5>";
-  if (ks == 49 && kw == 13) return "ssg_bwd_tiled<Geo<49,13,7,128>,4>";
+  if (ks == 49 && kw == 13) return "ssg_bwd_tiled<Geo<49,13,7,256>,4>";
   return "ssg_bwd_generic";
 }
 

@@ -51,7 +51,9 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = p.C, H = p.H, W = p.W;
   float *tiles = smem + PADF;                                      // [JOBS][C][KS][S] or [C][MH][MS]
-  float *zero = tiles + (MERGED ? C * MH * MS : JOBS * C * CH);    // ZROW zeros (also absorbs tail over-reads)
+  // (merged: the shared region is reused to stage the JOBS output rows, whichever is larger)
+  const int merged_floats = (C * MH * MS > JOBS * P ? C * MH * MS : JOBS * P + 1) & ~1;
+  float *zero = tiles + (MERGED ? merged_floats : JOBS * C * CH);  // ZROW zeros (also absorbs tail over-reads)
   double *red = (double *)(zero + ((G::ZROW + 3) & ~3));           // [WG] row-sum scratch (8-byte aligned)
   int *sh_edge = (int *)(red + WG);                                // [JOBS][6]: b, y, x, row, which, pad
 
@@ -408,7 +410,8 @@ template <class G, bool MERGED>
 static size_t fwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
   constexpr int MH = G::KS + 7, MS = G::KS + 16;
-  const size_t tiles = MERGED ? (size_t)C * MH * MS : (size_t)G::JOBS * C * G::CH;
+  const size_t region = (size_t)C * MH * MS, rows = (size_t)G::JOBS * G::P;
+  const size_t tiles = MERGED ? ((region > rows ? region : rows + 1) & ~(size_t)1) : (size_t)G::JOBS * C * G::CH;
   return sizeof(float) * (size_t)(PADF + tiles + ((G::ZROW + 3) & ~3) + 4 + 2 * G::WG) + sizeof(int) * 6 * G::JOBS;
 }
 
@@ -431,19 +434,26 @@ static int launch_fwd_tiled(const FwdParams &p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// Tile-ordered launch of both variants over the same job groups (merged groups run in the first, the rest in
+// the second); without an order (reference operator, raw distances) the single variant alone in row order.
+template <class G>
+static int launch_fwd_pair(FwdParams p, hipStream_t st) {
+  const bool can_merge = p.order && !p.raw && fwd_lds_bytes<G, true>(p.C) <= 160 * 1024;
+  if (!can_merge) p.order = nullptr;
+  if (can_merge) {
+    const int rc = launch_fwd_tiled<G, true>(p, st);
+    if (rc) return rc;
+  }
+  return launch_fwd_tiled<G, false>(p, st);
+}
+
 int launch_fwd(const FwdParams &p_in, hipStream_t st) {
   FwdParams p = p_in;
-  if (p.ks == 25 && p.kw == 9) {
-    using G = Geo<25, 9, 5, 128>;
-    // the merged variant stages its JOBS output rows in the shared region: needs C*(k_s+7)*(k_s+16) >= JOBS*k_s^2
-    const bool can_merge = p.order && !p.raw && (size_t)p.C * (G::KS + 7) * (G::KS + 16) >= (size_t)G::JOBS * G::P;
-    if (!can_merge) p.order = nullptr;
-    if (can_merge) {
-      const int rc = launch_fwd_tiled<G, true>(p, st);
-      if (rc) return rc;
-    }
-    return launch_fwd_tiled<G, false>(p, st);
-  }
+  if (p.ks == 25 && p.kw == 9) return launch_fwd_pair<Geo<25, 9, 5, 128>>(p, st);
+  // (49,13): 5 jobs x 49 lanes in 256-lane workgroups; the merged variant needs 48 KB of LDS (3 workgroups
+  // per CU), the single one 147 KB (groups that straddle tiles or images only)
+  if (p.ks == 49 && p.kw == 13 && p.order && !p.raw && fwd_lds_bytes<Geo<49, 13, 7, 256>, false>(p.C) <= 160 * 1024)
+    return launch_fwd_pair<Geo<49, 13, 7, 256>>(p, st);
   p.order = nullptr;  // the other geometries run in row order
   if (p.ks == 11 && p.kw == 5) return launch_fwd_tiled<Geo<11, 5, 4, 64>, false>(p, st);
   if (p.ks == 49 && p.kw == 13 && fwd_lds_bytes<Geo<49, 13, 7, 128>, false>(p.C) <= 160 * 1024)
@@ -464,7 +474,7 @@ int launch_fwd(const FwdParams &p_in, hipStream_t st) {
 const char *fwd_kernel_name(int ks, int kw) {
   if (ks == 25 && kw == 9) return "ssg_fwd_tiled<Geo<25,9,5,128>,merged|single>";
   if (ks == 11 && kw == 5) return "ssg_fwd_tiled<Geo<11,5,4,64>,single>";
-  if (ks == 49 && kw == 13) return "ssg_fwd_tiled<Geo<49,13,7,128>,single>";
+  if (ks == 49 && kw == 13) return "ssg_fwd_tiled<Geo<49,13,7,256>,merged|single>";
   return "ssg_fwd_generic";
 }
 
