@@ -303,22 +303,26 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
     return;
   }
   // ---- epilogue: e = exp(-(D/den)/sigma), row sum, normalise ----
-  // -(D/(C k_w^2))/sigma as one multiply by a host-rounded constant: |x| differs from the
-  // reference's two divisions by <= 1.5 ulp, i.e. e by < 1e-5 relative even at e ~ 1e-38
+  // -(D/(C k_w^2))/sigma as one multiply by a host-rounded constant (|x| differs from the reference's two
+  // divisions by <= 1.5 ulp).
   //
   // The row sum and the scale 1/(sum + eps) are carried in fp64 and every s = fl32(e * scale) is rounded on its
   // own.  With an fp32 scale all k_s^2 entries of a row share the scale's rounding error delta (~3e-8), and the
   // KL criterion sum t log(t/s) -- second order in (t - s) -- picks up the full (delta_t - delta_s) per row:
   // on flat rows (fixture F1) that is ~1.5e-5 of the loss, above the 1e-5 parity bar, for ANY fp32
   // normalisation (the reference's own fp32 run included).  ~100 fp64 ops per lane, 1 % of the kernel.
-  const float nk = -1.f / ((float)(C * KW * KW) * p.sigma);
+  // exp(x) = 2^(x log2 e) on v_exp_f32 with the constant folded on the host side of the multiply: the
+  // argument's rounding (|x| * 6e-8) costs e a relative 1e-6 at |x| = 20 (e = 2e-9) and nothing near e = 1 --
+  // far inside the 1e-5 budget on s in [0,1] -- and saves expf()'s ~12-instruction range reduction per offset.
+  // Results below 2^-126 flush to 0 (expf would return denormals, i.e. < 1.2e-38).
+  const float nk = (float)(-1.4426950408889634 / ((double)(C * KW * KW) * (double)p.sigma));
   double lsum = 0.0;
 #pragma unroll
   for (int i = 0; i < BS; ++i)
 #pragma unroll
     for (int j = 0; j < BS; ++j) {
       const int py = BS * by + i, px = BS * bx + j;
-      const float e = (py < KS && px < KS) ? expf(acc[i][j] * nk) : 0.f;
+      const float e = (py < KS && px < KS) ? __builtin_amdgcn_exp2f(acc[i][j] * nk) : 0.f;
       acc[i][j] = e;
       lsum += (double)e;
     }
