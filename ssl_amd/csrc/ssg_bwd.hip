@@ -388,22 +388,30 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
           pin_block<BS, BS>(acc);
         }
       } else {
-#pragma unroll 1
+        // large stencils: same fully unrolled row stream, the flipped stencil row is re-read from LDS
+        // (broadcast) where it is used instead of living in k_w^2 registers
+        float bn[PW];
+        load_grow<G>(tg, zrow, ry0, cx0, bn);
+#pragma unroll
         for (int r = 0; r < PW; ++r) {
           float bv[PW];
-          load_grow<G>(tg, zrow, ry0 + r, cx0, bv);
+#pragma unroll
+          for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+          if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, bn);
 #pragma unroll
           for (int i = 0; i < BS; ++i) {
             const int kh = r - i;
             if (kh < 0 || kh >= KW) continue;
             const float *ar = ac + (KW - 1 - kh) * KW;
+            float av[KW];
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-              const float av = ar[KW - 1 - kx];
+            for (int kx = 0; kx < KW; ++kx) av[kx] = ar[KW - 1 - kx];
 #pragma unroll
-              for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(av, bv[j + kx], acc[i][j]);
-            }
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+              for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(av[kx], bv[j + kx], acc[i][j]);
           }
+          pin_block<BS, BS>(acc);
         }
       }
       // S[c,t] of the owned block: loaded only now (pass A's register footprint is acc + stencil
