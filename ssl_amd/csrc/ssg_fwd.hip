@@ -249,32 +249,34 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
         pin_block<BS, BS>(acc);
       }
     } else {
-      // large windows: the centre row is re-read (LDS broadcast) per patch row
-#pragma unroll 1
+      // large windows: same fully unrolled, software-pipelined row stream; the centre-window row is re-read
+      // from LDS (broadcast) where it is used instead of living in k_w^2 registers
+      float bn[PW];
+      load_row<G>(tc, rs, zrow, ry0, cx0, colv, bn);
+#pragma unroll
       for (int r = 0; r < PW; ++r) {
-        const int ry = ry0 + r;
-        const float *rowp = ((unsigned)ry < (unsigned)KS) ? (tc + ry * rs) : zrow;
         float bv[PW];
 #pragma unroll
-        for (int j = 0; j < PW; ++j) {
-          const float v = rowp[cx0 + j];
-          bv[j] = colv[j] ? v : 0.f;
-        }
+        for (int j = 0; j < PW; ++j) bv[j] = bn[j];
+        if (r + 1 < PW) load_row<G>(tc, rs, zrow, ry0 + r + 1, cx0, colv, bn);
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
           const int kh = r - i;
-          if (kh < 0 || kh >= KW) continue;  // runtime r: predicated
+          if (kh < 0 || kh >= KW) continue;
           const float *ar = tc + (HP - HK + kh) * rs + (HP - HK);
+          float av[KW];
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) av[kx] = ar[kx];
 #pragma unroll
           for (int kx = 0; kx < KW; ++kx) {
-            const float av = ar[kx];
+            float d[BS];
 #pragma unroll
-            for (int j = 0; j < BS; ++j) {
-              const float d = av - bv[j + kx];
-              acc[i][j] = __builtin_fmaf(d, d, acc[i][j]);
-            }
+            for (int j = 0; j < BS; ++j) d[j] = av[kx] - bv[j + kx];
+#pragma unroll
+            for (int j = 0; j < BS; ++j) acc[i][j] = __builtin_fmaf(d[j], d[j], acc[i][j]);
           }
         }
+        pin_block<BS, BS>(acc);
       }
     }
   }
