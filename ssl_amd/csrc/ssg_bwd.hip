@@ -196,14 +196,32 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
           vg[k] = g;
           dot = __builtin_fmaf(g, va[k], dot);
         }
+        // one barrier pair serves the per-job dot products and the workgroup's criteria partial sums
+        // (`red` is free until pass B): lanes [8,16) / [16,24) each sum an eighth of the l1 / kl terms
         red2[tid] = dot;
+        red[tid] = l1p;
+        red[WG + tid] = klp;
         __syncthreads();
         if (tid < JOBS) {
           float t = 0.f;
           for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
           jsc[tid * 4 + 0] = p.generalization ? t : 0.f;
+        } else if (tid >= 8 && tid < 24) {
+          const int h = (tid - 8) >> 3, part = (tid - 8) & 7;
+          float t = 0.f;
+          for (int k = 0; k < WG / 8; ++k) t += red[h * WG + part * (WG / 8) + k];
+          red[2 * WG + (tid - 8)] = t;
         }
         __syncthreads();
+        if (p.mode == GRAD_LOSS && tid == 0) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int k = 0; k < 8; ++k) {
+            t1 += red[2 * WG + k];
+            t2 += red[2 * WG + 8 + k];
+          }
+          p.partials[2 * blockIdx.x] = t1;
+          p.partials[2 * blockIdx.x + 1] = t2;
+        }
         dot = jsc[jl * 4 + 0];
 #pragma unroll
         for (int k = 0; k < EPL; ++k) va[k] = -(va[k] * kfac) * (vg[k] - dot);
@@ -219,21 +237,9 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
         }
       }
     }
-    if (p.mode == GRAD_LOSS) {  // criteria partial sums of this workgroup
-      __syncthreads();
-      red2[tid] = l1p;
-      __syncthreads();
-      float t1 = 0.f, t2 = 0.f;
-      if (tid == 0)
-        for (int k = 0; k < WG; ++k) t1 += red2[k];
-      __syncthreads();
-      red2[tid] = klp;
-      __syncthreads();
-      if (tid == 0) {
-        for (int k = 0; k < WG; ++k) t2 += red2[k];
-        p.partials[2 * blockIdx.x] = t1;
-        p.partials[2 * blockIdx.x + 1] = t2;
-      }
+    if (p.mode == GRAD_LOSS && (p.dbg & 1) && tid == 0) {  // (profiling ablation without criteria)
+      p.partials[2 * blockIdx.x] = 0.f;
+      p.partials[2 * blockIdx.x + 1] = 0.f;
     }
     if (need_grad) {
     // G at the centre offset multiplies (A - B) == 0 exactly (B is the window itself there), but
@@ -349,6 +355,8 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 
     float *gst = red + jl * SL * LPJ;  // job's gradient staging tile [KS][KS], aliases its slice
     static_assert(SL * LPJ >= P, "staging tile must fit the reduction slice");
+    static_assert(JOBS <= 8 && WG >= 24 && WG % 8 == 0 && JOBS * SL * LPJ >= 2 * WG + 16,
+                  "stage-1 reductions: lanes [0,JOBS) / [8,24) and their scratch in the pass-B slice");
 
 #pragma unroll 1
     for (int c = 0; c < C; ++c) {
