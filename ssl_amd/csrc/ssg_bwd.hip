@@ -226,28 +226,30 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 #pragma unroll
         for (int k = 0; k < EPL; ++k) va[k] = -(va[k] * kfac) * (vg[k] - dot);
       }
+      // G at the centre offset multiplies (A - B) == 0 exactly (B is the window itself there), but it is the
+      // largest entry of the row by orders of magnitude when sigma is small; in the split sums below its two
+      // copies would cancel only to fp32 round-off (measured 2.4e-4 of max|grad| at sigma = 0.004).  Dropping
+      // it is exact.  The lane's share of sum_p G (without the centre) goes to the per-job reduction.
+      float ls = 0.f;
       if (lane_on) {
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
           const int e = mo + k * LPJ;
           if (e < P) {
             const int py = e / KS, px = e - py * KS;
-            tg[py * S + px] = va[k];
+            const float gv = (e == HP * KS + HP) ? 0.f : va[k];
+            tg[py * S + px] = gv;
+            ls += gv;
           }
         }
       }
+      red2[tid] = ls;  // (the dot products were consumed before the barrier above)
     }
     if (p.mode == GRAD_LOSS && (p.dbg & 1) && tid == 0) {  // (profiling ablation without criteria)
       p.partials[2 * blockIdx.x] = 0.f;
       p.partials[2 * blockIdx.x + 1] = 0.f;
     }
     if (need_grad) {
-    // G at the centre offset multiplies (A - B) == 0 exactly (B is the window itself there), but
-    // it is the largest entry of the row by orders of magnitude when sigma is small; in the split
-    // sums below its two copies would cancel only to fp32 round-off (measured 2.4e-4 of
-    // max|grad| at sigma = 0.004).  Dropping it is exact.
-    __syncthreads();
-    if (tid < JOBS) gt[tid * CHG + HP * S + HP] = 0.f;
     // centre windows A (reflect by index mirroring); loads of all jobs in flight together
     {
       constexpr int APT = (3 * KW * KW + WG - 1) / WG;  // elements per thread per job when C <= 3
@@ -283,26 +285,12 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
         }
       }
     }
-    __syncthreads();
-    {  // sum_p G per job
-      float ls = 0.f;
-      if (lane_on) {
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-          const int e = mo + k * LPJ, py = e / KS;
-          if (e < P) ls += tg[py * S + (e - py * KS)];
-        }
-      }
-      red2[tid] = ls;
-      __syncthreads();
-      if (tid < JOBS) {
-        float t = 0.f;
-        for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
-        jsc[tid * 4 + 1] = t;
-      }
-      __syncthreads();
+    __syncthreads();  // G tiles, centre windows and the sum_p G shares are in LDS
+    if (tid < JOBS) {
+      float t = 0.f;
+      for (int k = 0; k < LPJ; ++k) t += red2[tid * LPJ + k];
+      jsc[tid * 4 + 1] = t;  // read in pass B's reduction, several barriers downstream
     }
-    const float sumG = jsc[jl * 4 + 1];
 
     // window sum of Gz around every owned t (channel independent), streamed like pass A: per
     // patch row the k_w-tap horizontal sums, added to every block row the patch row pairs with
@@ -481,7 +469,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
               float t = 0.f;
               for (int k = 0; k < LPJ; ++k) t += rp[k];
               const int kh = KW - 1 - khp, kx = KW - 1 - (o % KW);  // k = -k'
-              gwin[jl * KW * KW + kh * KW + kx] = 2.f * (ac[kh * KW + kx] * sumG - t);  // unique owner
+              gwin[jl * KW * KW + kh * KW + kx] = 2.f * (ac[kh * KW + kx] * jsc[jl * 4 + 1] - t);  // unique owner
             }
           }
         lds_barrier();
