@@ -233,15 +233,28 @@ __global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int 
     const int lo = tid * run, hi = lo + run < m ? lo + run : m;
     int s = 0;
     for (int i = lo; i < hi; ++i) s += stage[i];
-    buf[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int t = tid >= o ? buf[tid - o] : 0;
-      __syncthreads();
-      buf[tid] += t;
-      __syncthreads();
+    // inclusive scan of the 1024 run sums: shuffles inside each wave, then the 16 wave totals
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if ((tid & 63) >= o) incl += t;
     }
-    int acc = carry + buf[tid] - s;
+    if ((tid & 63) == 63) buf[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 64) {
+      int w = tid < 16 ? buf[tid] : 0;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const int t = __shfl_up(w, o, 64);
+        if (tid >= o) w += t;
+      }
+      if (tid < 16) buf[16 + tid] = w;  // inclusive wave totals
+    }
+    __syncthreads();
+    incl += (tid >> 6) ? buf[16 + (tid >> 6) - 1] : 0;
+    if (tid == 1023) buf[1023] = incl;
+    int acc = carry + incl - s;
     for (int i = lo; i < hi; ++i) {
       const int v = stage[i];
       stage[i] = acc;
