@@ -21,7 +21,7 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
                      int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
                      void *scratch, hipStream_t st);
 size_t fwd_plan_bytes(int B, int H, int W, int capacity);
-int fwd_plan_order_offset(int B, int H, int W);
+int fwd_plan_flags_offset(int B, int H, int W);
 struct DenseParams {
   const float *img[2];
   float *out[2];
@@ -45,22 +45,29 @@ int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride
 
 using namespace ssg;
 
-// SSG_DEBUG_SKIP=<bitmask> ablates kernel phases for profiling (results are then WRONG);
-// read once, 0 in production.
-// Edge pixels per 8 x 32 tile from which the dense ("shared-term") forward kernel takes the tile.
-// EXPERIMENTAL and OFF by default (0): the kernel is correct (the whole GPU suite passes with
-// SSG_DENSE_THR=1) but at 1-2 waves/SIMD and two LDS hand-offs per offset it is still slower than
-// the direct kernels at every density measured (profiles/r1_dense_forward_experiment.txt), so the
-// product path neither builds a forward plan nor launches it unless SSG_DENSE_THR > 0.
+// Edge pixels per 8 x 32 tile from which the dense ("shared-term") forward kernel takes the tile; 0 = off
+// (default).  Measured (profiles/r1_dense_forward_v2.txt): it beats the direct kernels from ~25 % tile density
+// (-26 % forward time at 30 %, -35 % at 50 %, -27 % at 100 % Bernoulli density with threshold 64) and is neutral
+// to slightly slower on the 7 % Laplacian masks of the benchmark, whose tiles rarely reach it -- hence opt-in:
+// ssg_set_dense_threshold(n) or the environment variable SSG_DENSE_THR read at first use.
+static int g_dense_thr = -1;
 static int dense_threshold() {
-  static int v = -1;
-  if (v < 0) {
+  if (g_dense_thr < 0) {
     const char *e = getenv("SSG_DENSE_THR");
-    v = e ? atoi(e) : 0;
+    g_dense_thr = e ? atoi(e) : 0;
+    if (g_dense_thr < 0) g_dense_thr = 0;
   }
-  return v;
+  return g_dense_thr;
 }
 
+extern "C" int ssg_set_dense_threshold(int edge_pixels_per_tile) {
+  const int prev = dense_threshold();
+  g_dense_thr = edge_pixels_per_tile > 0 ? edge_pixels_per_tile : 0;
+  return prev;
+}
+
+// SSG_DEBUG_SKIP=<bitmask> ablates kernel phases for profiling (results are then WRONG);
+// read once, 0 in production.
 static int dbg_mask() {
   static int v = -1;
   if (v < 0) {
@@ -194,7 +201,7 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
   p.kw = kw;
   p.dbg = dbg_mask() & 0xff;
   if (dense_threshold() > 0 && fwd_plan && rank_map && dense_supported(ks, kw, C)) {
-    // dense tiles -> shared-term kernel; the rest (plan's own tile-major order) -> direct kernels
+    // dense tiles -> shared-term kernel; the direct kernels drop the jobs of flagged super-tiles
     DenseParams d{};
     d.img[0] = img;
     d.img[1] = img2;
@@ -216,8 +223,7 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
     d.dbg = (dbg_mask() >> 16) & 0xff;
     const int rc = launch_fwd_dense(d, ks, kw, C, (hipStream_t)stream);
     if (rc) return rc;
-    p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
-    p.n_dev = fwd_plan;  // n_sparse
+    p.dense_flag = fwd_plan + fwd_plan_flags_offset(B, H, W);
   }
   return launch_fwd(p, (hipStream_t)stream);
 }

@@ -53,13 +53,13 @@ struct DenseParams {
   int B, H, W;
   float sigma, eps;
   int generalization;
-  int dbg;  // profiling ablations: bit0 no stores, bit1 no edge stage, bit2 no E/H stage, bit3 no rescale
+  int dbg;  // profiling ablations: bit0 no stores, bit1 no edge stage, bit3 no rescale, bit6 no main loop
 };
 
 constexpr int DT_Y = 8, DT_X = 32;  // centres per tile
 
 template <int KS, int KW, int C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void ssg_fwd_dense(DenseParams p) {
+__global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK;
   constexpr int RH = DT_Y + 2 * HALO, RWD = DT_X + 2 * HALO, RS = RWD + 1;  // image region
   constexpr int UH = DT_Y + 2 * HK, UW = DT_X + 2 * HK;                      // window halo U
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   float *F = reg + C * RH * RS;            // [UH][UW]   sum_c I^2 on U
   float *HF = F + UH * UW;                 // [UH][DT_X] full-window horizontal sums of F
   float *Hb = HF + UH * DT_X;              // [4][UH][DT_X] per-wave horizontal sums of E_q
-  float *rsum = Hb + 4 * UH * DT_X;        // [4][NE_MAX] per-wave partial row sums
-  int *elist = (int *)(rsum + 4 * NE_MAX); // [NE_MAX][3] (ey, ex, row)
+  double *rsum = (double *)(Hb + 4 * UH * DT_X);  // [4][NE_MAX] per-wave partial row sums (fp64, see ssg_fwd.hip)
+  int *elist = (int *)(rsum + 4 * NE_MAX);        // [NE_MAX][3] (ey, ex, row)
   int *misc = elist + NE_MAX * 3;          // [8]: wave counts, n_e
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     }
     F[i] = t;
   }
-  for (int i = tid; i < 4 * NE_MAX; i += 256) rsum[i] = 0.f;
+  for (int i = tid; i < 4 * NE_MAX; i += 256) rsum[i] = 0.0;
   __syncthreads();
   for (int i = tid; i < UH * DT_X; i += 256) {
     const int ur = i / DT_X, tc = i - ur * DT_X;
@@ -159,15 +159,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   for (int c = 0; c < C; ++c)
 #pragma unroll
     for (int i = 0; i < LW; ++i) iu[c][i] = reg[(c * RH + r + HP) * RS + 8 * g + HP + i];
+  float Fr[LW];  // |I|^2 of the lane's LW pixels (complement of the columns that leave the area)
+#pragma unroll
+  for (int i = 0; i < LW; ++i) Fr[i] = F[r * UW + 8 * g + i];
   float *hb = Hb + wv * UH * DT_X;
   float *hrow = hb + r * DT_X + 8 * g;
-  const float nk = -1.f / ((float)(C * KW * KW) * p.sigma);
-  float rs[NCHUNK];
+  // exp(x) = 2^(x log2 e), constant folded (see ssg_fwd.hip)
+  const float nk = (float)(-1.4426950408889634 / ((double)(C * KW * KW) * (double)p.sigma));
+  double rs[NCHUNK];
 #pragma unroll
-  for (int k = 0; k < NCHUNK; ++k) rs[k] = 0.f;
+  for (int k = 0; k < NCHUNK; ++k) rs[k] = 0.0;
   float *outp = p.out[which];
   // this lane's edge pixels (one per chunk of 64 list entries), hoisted out of the offset loops
-  int hoff[NCHUNK], foff[NCHUNK];
+  int hoff[NCHUNK];
   size_t orow[NCHUNK];
   bool eon[NCHUNK];
 #pragma unroll
@@ -176,20 +180,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     eon[ck] = e < n_e;
     const int ec = eon[ck] ? e : 0;
     const int ey = elist[3 * ec], ex = elist[3 * ec + 1];
-    hoff[ck] = (ey + HK) * DT_X + ex;
-    foff[ck] = (ey + HK) * UW + ex + HK;
+    hoff[ck] = ey * DT_X + ex;  // window row k of the centre is U-row ey + k
     orow[ck] = (size_t)elist[3 * ec + 2] * P;
   }
 
+  const int n_e_stage = (p.dbg & 2) ? 0 : n_e;  // profiling ablations: 2 no edge stage, 1 no stores, 64 no main loop
+  const bool do_store = !(p.dbg & 1);
 #pragma unroll 1
   for (int qyi = wv; qyi < ((p.dbg & 64) ? 0 : KS); qyi += 4) {
+    // D[n,q] = sum_{k in K(q)} E_q[x+k] + sum_{k not in K(q)} |I[x+k]|^2 with K(q) = rows [ylo,yhi] x columns
+    // [xlo,xhi] of the window.  Rows: wave-uniform 0/1 weights.  Columns: the lane adds the |I|^2 of the
+    // columns that left (compile-time set) to its horizontal sums, so H' rows carry E inside and |I|^2 outside
+    // [xlo,xhi]; rows outside [ylo,yhi] contribute their full-width |I|^2 sums (HF), gathered once per q_y.
     const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
+    float wgt[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) wgt[k] = (k - HK >= ylo && k - HK <= yhi) ? 1.f : 0.f;
+    float av[NCHUNK];
+#pragma unroll
+    for (int ck = 0; ck < NCHUNK; ++ck) {
+      av[ck] = 0.f;
+      if (ck * 64 < n_e && (ylo > -HK || yhi < HK)) {
+        const float *fc = HF + hoff[ck];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) av[ck] = __builtin_fmaf(1.f - wgt[k], fc[k * DT_X], av[ck]);
+      }
+    }
     const float *rq = reg + (r + qyi) * RS + 8 * g;  // + c*RH*RS + column (i + qxi)
     float w[C][LW];
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int i = 0; i < LW; ++i) w[c][i] = rq[c * RH * RS + i];
+    float evb[NCHUNK][4];  // four consecutive offsets per edge pixel, stored together
     static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
@@ -200,78 +223,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       for (int i = 0; i < LW; ++i) {
         float t = 0.f;
 #pragma unroll
-        for (int c = 0; c < ((p.dbg & 4) ? 0 : C); ++c) {
+        for (int c = 0; c < C; ++c) {
           const float d = iu[c][i] - w[c][(i + qxi) % LW];
           t = __builtin_fmaf(d, d, t);
         }
+        // pixels whose column left the area enter the sums with |I|^2 instead of E_q: window tap kx of centre
+        // column j is pixel i = j + HK + kx, i.e. kx = i - HK - j; only one-sided sets occur, so the swap can be
+        // made per (i, j) at compile time below
         E[i] = t;
       }
-      // horizontal box sums over taps [xlo, xhi] for the 8 centre columns
+      // horizontal sums for the 8 centre columns: E on taps [xlo, xhi], |I|^2 on the others
       float Hs[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = E[j + HK + xlo];
 #pragma unroll
         for (int kx = xlo + 1; kx <= xhi; ++kx) t += E[j + HK + kx];
+#pragma unroll
+        for (int kx = -HK; kx < xlo; ++kx) t += Fr[j + HK + kx];
+#pragma unroll
+        for (int kx = xhi + 1; kx <= HK; ++kx) t += Fr[j + HK + kx];
         Hs[j] = t;
       }
-      if (!(p.dbg & 16)) {
-        *(float4 *)(hrow) = make_float4(Hs[0], Hs[1], Hs[2], Hs[3]);
-        *(float4 *)(hrow + 4) = make_float4(Hs[4], Hs[5], Hs[6], Hs[7]);
-      } else {
-        asm volatile("" ::"v"(Hs[0]), "v"(Hs[3]), "v"(Hs[7]));
-      }
+      *(float4 *)(hrow) = make_float4(Hs[0], Hs[1], Hs[2], Hs[3]);
+      *(float4 *)(hrow + 4) = make_float4(Hs[4], Hs[5], Hs[6], Hs[7]);
       // next q_x: the pixel that leaves the window (slot qxi % LW) is replaced by the one that enters
-      if (qxi + 1 < KS && !(p.dbg & 32)) {
+      if (qxi + 1 < KS) {
 #pragma unroll
         for (int c = 0; c < C; ++c) w[c][qxi % LW] = rq[c * RH * RS + LW + qxi];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private buffer: lockstep hand-off
-      // ---- the tile's edge pixels: vertical taps, |I|^2 complement, exp, store ----
-      const int pofs = qyi * KS + qxi;
+      // ---- the tile's edge pixels: weighted vertical taps, row complement, exp, store ----
 #pragma unroll
       for (int ck = 0; ck < NCHUNK; ++ck) {
-        if (ck * 64 < n_e && !(p.dbg & 2)) {
-          if (eon[ck]) {
-            // every tap is loaded unconditionally (all loads of the step in flight together) and
-            // selected by the wave-uniform row range [ylo,yhi]: a rolled `for kh` pays one LDS
-            // latency per tap (measured 10x slower)
-            const float *hc = hb + hoff[ck];
-            const float *fc = HF + hoff[ck];
-            float hv[KW], fv[KW];
+        if (ck * 64 < n_e_stage) {
+          const float *hc = hb + hoff[ck];
+          float hv[KW];
 #pragma unroll
-            for (int k = 0; k < KW; ++k) {
-              hv[k] = hc[(k - HK) * DT_X];   // horizontal sums of E_q, window row k
-              fv[k] = fc[(k - HK) * DT_X];   // whole-row |I|^2, used where the partner row leaves the area
+          for (int k = 0; k < KW; ++k) hv[k] = hc[k * DT_X];
+          float d = av[ck];
+#pragma unroll
+          for (int k = 0; k < KW; ++k) d = __builtin_fmaf(wgt[k], hv[k], d);
+          const float ev = __builtin_amdgcn_exp2f(d * nk);
+          rs[ck] += (double)ev;
+          // every lane writes its own SSG row: single dwords are one L2 request per lane and step (request-
+          // rate bound at high density), so four consecutive offsets leave as one 16-byte store
+          evb[ck][qxi % 4] = ev;
+          if (eon[ck] && do_store) {
+            float *o = outp + orow[ck] + qyi * KS;
+            if constexpr (qxi % 4 == 3) {
+              float4 v4 = make_float4(evb[ck][0], evb[ck][1], evb[ck][2], evb[ck][3]);
+              __builtin_memcpy(o + (qxi - 3), &v4, 16);
+            } else if constexpr (qxi == KS - 1) {
+#pragma unroll
+              for (int t = 0; t <= qxi % 4; ++t) o[qxi - (qxi % 4) + t] = evb[ck][t];
             }
-            float d = 0.f;
-#pragma unroll
-            for (int k = 0; k < KW; ++k) {
-              const bool in = (k - HK) >= ylo && (k - HK) <= yhi;
-              d += in ? hv[k] : fv[k];
-            }
-            // rows that stay, columns that leave (one-sided, compile-time set of <= HK columns)
-            if constexpr (xlo > -HK || xhi < HK) {
-              const float *f0 = F + foff[ck];
-              float cs[KW];
-#pragma unroll
-              for (int k = 0; k < KW; ++k) {
-                float t = 0.f;
-#pragma unroll
-                for (int kx = -HK; kx < xlo; ++kx) t += f0[(k - HK) * UW + kx];
-#pragma unroll
-                for (int kx = xhi + 1; kx <= HK; ++kx) t += f0[(k - HK) * UW + kx];
-                cs[k] = t;
-              }
-#pragma unroll
-              for (int k = 0; k < KW; ++k) {
-                const bool in = (k - HK) >= ylo && (k - HK) <= yhi;
-                d += in ? cs[k] : 0.f;
-              }
-            }
-            const float ev = expf(d * nk);
-            rs[ck] += ev;
-            if (!(p.dbg & 1)) outp[orow[ck] + pofs] = ev;
           }
         }
       }
@@ -291,10 +297,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int e = wv; e < n_e; e += 4) {
-    const float tot = rsum[e] + rsum[NE_MAX + e] + rsum[2 * NE_MAX + e] + rsum[3 * NE_MAX + e];
-    const float scale = 1.f / (tot + p.eps);
+    const double tot = rsum[e] + rsum[NE_MAX + e] + rsum[2 * NE_MAX + e] + rsum[3 * NE_MAX + e];
+    const double scale = 1.0 / (tot + (double)p.eps);
     float *o = outp + (size_t)elist[3 * e + 2] * P;
-    for (int q = lane; q < P; q += 64) o[q] = scale * __builtin_nontemporal_load(o + q);
+    for (int q = lane; q < P; q += 64) o[q] = (float)(scale * (double)__builtin_nontemporal_load(o + q));
   }
 }
 
@@ -303,7 +309,7 @@ template <int KS, int KW, int C>
 static size_t dense_lds_bytes() {
   constexpr int HALO = KS / 2 + KW / 2, RH = DT_Y + 2 * HALO, RS = DT_X + 2 * HALO + 1;
   constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X;
-  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_X + 4 * UH * DT_X + 4 * NE) + sizeof(int) * (NE * 3 + 8);
+  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_X + 4 * UH * DT_X + 2 * 4 * NE) + sizeof(int) * (NE * 3 + 8);
 }
 
 bool dense_supported(int ks, int kw, int C) { return ks == 25 && kw == 9 && C == 3; }

@@ -318,12 +318,14 @@ size_t edge_scratch_bytes(int B, int H, int W) {
   return (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64;
 }
 
-// forward plan: [0] n_sparse, [1] n_dense, [2..3] -, [4, 4+n_super_tiles) the dense kernel's super-tile
-// ids, then (capacity) the tile-major order of the rows the direct kernels compute
-int fwd_plan_order_offset(int B, int H, int W) { return 4 + (int)n_super_tiles(B, H, W); }
+// forward plan: [0] -, [1] n_dense, [2..3] -, [4, 4+ns) the dense kernel's super-tile ids, [4+ns, 4+2ns) one
+// flag per super-tile (ns = n_super_tiles).  The direct kernels walk the common tile-major order and drop
+// the jobs whose super-tile is flagged.
+int fwd_plan_flags_offset(int B, int H, int W) { return 4 + (int)n_super_tiles(B, H, W); }
 
 size_t fwd_plan_bytes(int B, int H, int W, int capacity) {
-  return sizeof(int) * (4 + (size_t)(capacity > 0 ? capacity : 1) + n_super_tiles(B, H, W));
+  (void)capacity;
+  return sizeof(int) * (4 + 2 * n_super_tiles(B, H, W));
 }
 
 static void build_order(const int *rank, int B, int H, int W, int *order, int capacity, const int *edges,
@@ -354,13 +356,12 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts);
   hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank);
   const int nt = (int)n_order_tiles(B, H, W);
-  int *tcnt = blockoff + nblk, *toff = tcnt + nt, *dflag = toff + nt;
+  int *tcnt = blockoff + nblk, *toff = tcnt + nt;
   if (order) build_order(rank, B, H, W, order, capacity, edges, counts, nullptr, nullptr, tcnt, toff, st);
   if (plan) {
     const int ns = (int)n_super_tiles(B, H, W);
     (void)hipMemsetAsync(plan, 0, 4 * sizeof(int), st);
-    hipLaunchKernelGGL(plan_classify, dim3(ns), dim3(256), 0, st, rank, H, W, dense_thr, dflag, plan, plan + 4);
-    build_order(rank, B, H, W, plan + 4 + ns, capacity, edges, nullptr, plan, dflag, tcnt, toff, st);
+    hipLaunchKernelGGL(plan_classify, dim3(ns), dim3(256), 0, st, rank, H, W, dense_thr, plan + 4 + ns, plan, plan + 4);
   }
   return (int)hipGetLastError();
 }

@@ -670,6 +670,41 @@ def test_diffusion_fork_all_operator_strategies_vs_reference_fixture(dev):
     assert len(worst) >= 18
 
 
+def test_dense_threshold_knob_same_results(dev):
+    """engine.set_dense_threshold(): a 60 %-dense mask through the direct kernels and with the dense tiles routed
+    to the shared-term kernel -- same SSG rows (1e-6), same loss, same gradient."""
+    from ssl_amd import engine, synth
+    B, H, W, ks, kw, sigma = 2, 64, 96, 25, 9, 0.05
+    rng = np.random.default_rng(77)
+    gt = np.stack([synth.natural_like(1400 + i, H, W) for i in range(B)])
+    sr = np.stack([synth.degrade(gt[i], 1450 + i) for i in range(B)])
+    mask = (rng.random((B, 1, H, W)) < 0.6).astype(np.float32)
+    mask[0, 0, :16, :32] = 0                                  # one empty tile, one sparse neighbourhood
+    mask[0, 0, 16:24, :32] = (rng.random((8, 32)) < 0.05)
+    out = []
+    prev = engine.set_dense_threshold(0)
+    try:
+        for thr in (0, 64):
+            engine.set_dense_threshold(thr)
+            step = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
+            loss, grad = step(T(sr, dev), T(gt, dev), T(mask, dev))
+            n = int(step.counts[0])
+            out.append((loss.clone(), grad.clone(), step.ssg_sr[:n].clone(), step.ssg_gt[:n].clone(), n))
+    finally:
+        engine.set_dense_threshold(prev)
+    (l0, g0, a0, b0, n0), (l1, g1, a1, b1, n1) = out
+    assert n0 == n1 == int(mask.sum())
+    assert float((a0 - a1).abs().max()) <= 1e-6 and float((b0 - b1).abs().max()) <= 1e-6
+    assert float((l0 - l1).abs().max()) <= 1e-5 * float(l0.abs().max())
+    # the backward is the same code on both sides; the SSG rows differ by ~1e-8, which flips sign() of the L1
+    # term at the few near-ties among 4 M entries
+    assert float((g0 - g1).abs().max()) <= 5e-3 * float(g0.abs().max())
+    pos = orc.mask_to_pos(mask[1, 0])[:64]
+    want = orc.ssg_epilogue(orc.distance(gt[1].astype(np.float64), pos, ks, kw), kw, 3, sigma, True)
+    n_img0 = int(mask[0].sum())
+    assert maxerr(b1[n_img0:n_img0 + 64].cpu(), want) <= 1e-5
+
+
 def test_experimental_dense_forward_kernel_parity(dev):
     """The opt-in shared-term ("dense tile") forward kernel (SSG_DENSE_THR > 0, ssg_dense.hip): every tile
     routed through it, SSG rows and the loss step vs the oracle.  Runs in a subprocess because the
