@@ -105,16 +105,16 @@ int ssg_compute_similarity_backward(const float *image, const float *grads,
  *                 least ssg_set_dense_threshold() edge pixels go to the
  *                 shared-term ("dense") kernel; the direct kernels walk
  *                 tile_order and skip those tiles' rows.  Unused while the
- *                 threshold is 0.
+ *                 threshold is 0 or for kernel sizes other than (25, 9, C=3).
  * scratch: ssg_edge_scratch_bytes(B,H,W) bytes of device memory. */
 size_t ssg_edge_scratch_bytes(int B, int H, int W);
 size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
 /* Threshold (edge pixels per 8x32 tile) from which the forward routes a tile to the
- * shared-term kernel; 0 = never (default; initial value from the environment variable
- * SSG_DENSE_THR).  Worth enabling (e.g. 64) for masks denser than ~25 %; results are the
- * same either way (parity-tested with every tile routed through it).  Process-wide; takes
- * effect at the next ssg_edge_list().  Returns the previous value.  No reference
- * counterpart: the reference has one code path. */
+ * shared-term kernel; 0 = never.  Default 28 (initial value overridable with the
+ * environment variable SSG_DENSE_THR).  Results are the same either way (parity-tested
+ * with every tile routed through it and with none).  Process-wide; takes effect at the
+ * next ssg_edge_list().  Returns the previous value.  No reference counterpart: the
+ * reference has one code path. */
 int ssg_set_dense_threshold(int edge_pixels_per_tile);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int H, int W, int mask_stride, float lap_threshold,

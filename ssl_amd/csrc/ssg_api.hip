@@ -45,16 +45,17 @@ int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride
 
 using namespace ssg;
 
-// Edge pixels per 8 x 32 tile from which the dense ("shared-term") forward kernel takes the tile; 0 = off
-// (default).  Measured (profiles/r1_dense_forward_v2.txt): it beats the direct kernels from ~25 % tile density
-// (-26 % forward time at 30 %, -35 % at 50 %, -27 % at 100 % Bernoulli density with threshold 64) and is neutral
-// to slightly slower on the 7 % Laplacian masks of the benchmark, whose tiles rarely reach it -- hence opt-in:
-// ssg_set_dense_threshold(n) or the environment variable SSG_DENSE_THR read at first use.
+// Edge pixels per 8 x 32 tile from which the dense ("shared-term") forward kernel takes the tile (0 = never).
+// Measured (profiles/r1_dense_forward_v2.txt): with the tiles of >= 28 edge pixels routed to it the forward of
+// the benchmark batch (7 % Laplacian masks) takes 0.93 instead of 1.09 ms, and 1.5 instead of 3.55 ms at 100 %
+// density; below ~16 pixels per tile the direct kernels win.  Default 28; ssg_set_dense_threshold(n) or the
+// environment variable SSG_DENSE_THR (read at first use) override it.
+constexpr int DENSE_THR_DEFAULT = 28;
 static int g_dense_thr = -1;
 static int dense_threshold() {
   if (g_dense_thr < 0) {
     const char *e = getenv("SSG_DENSE_THR");
-    g_dense_thr = e ? atoi(e) : 0;
+    g_dense_thr = e ? atoi(e) : DENSE_THR_DEFAULT;
     if (g_dense_thr < 0) g_dense_thr = 0;
   }
   return g_dense_thr;
@@ -339,6 +340,8 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
 }
 
 const char *ssg_kernel_name(int ks, int kw, int backward) {
+  if (!backward && ks == 25 && kw == 9 && dense_threshold() > 0)
+    return "ssg_fwd_dense<25,9,3>+ssg_fwd_tiled<Geo<25,9,5,128>,merged|single>";
   return backward ? bwd_kernel_name(ks, kw) : fwd_kernel_name(ks, kw);
 }
 

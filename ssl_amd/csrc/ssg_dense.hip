@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int i = 0; i < LW; ++i) w[c][i] = rq[c * RH * RS + i];
-    float evb[NCHUNK][4];  // four consecutive offsets per edge pixel, stored together
+    constexpr int SB = 13;  // consecutive offsets per edge pixel buffered in registers and stored together
+    float evb[NCHUNK][SB];
     static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
@@ -267,16 +268,19 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
           const float ev = __builtin_amdgcn_exp2f(d * nk);
           rs[ck] += (double)ev;
           // every lane writes its own SSG row: single dwords are one L2 request per lane and step (request-
-          // rate bound at high density), so four consecutive offsets leave as one 16-byte store
-          evb[ck][qxi % 4] = ev;
+          // rate bound at high density), so SB consecutive offsets leave together as 16-byte stores
+          evb[ck][qxi % SB] = ev;
           if (eon[ck] && do_store) {
             float *o = outp + orow[ck] + qyi * KS;
-            if constexpr (qxi % 4 == 3) {
-              float4 v4 = make_float4(evb[ck][0], evb[ck][1], evb[ck][2], evb[ck][3]);
-              __builtin_memcpy(o + (qxi - 3), &v4, 16);
-            } else if constexpr (qxi == KS - 1) {
+            if constexpr (qxi % SB == SB - 1 || qxi == KS - 1) {
+              constexpr int cnt = qxi % SB + 1, q0 = qxi - (cnt - 1);
 #pragma unroll
-              for (int t = 0; t <= qxi % 4; ++t) o[qxi - (qxi % 4) + t] = evb[ck][t];
+              for (int t = 0; t + 4 <= cnt; t += 4) {
+                float4 v4 = make_float4(evb[ck][t], evb[ck][t + 1], evb[ck][t + 2], evb[ck][t + 3]);
+                __builtin_memcpy(o + q0 + t, &v4, 16);
+              }
+#pragma unroll
+              for (int t = cnt & ~3; t < cnt; ++t) o[q0 + t] = evb[ck][t];
             }
           }
         }
@@ -300,7 +304,18 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     const double tot = rsum[e] + rsum[NE_MAX + e] + rsum[2 * NE_MAX + e] + rsum[3 * NE_MAX + e];
     const double scale = 1.0 / (tot + (double)p.eps);
     float *o = outp + (size_t)elist[3 * e + 2] * P;
-    for (int q = lane; q < P; q += 64) o[q] = (float)(scale * (double)__builtin_nontemporal_load(o + q));
+    constexpr int RPL = (P + 63) / 64;  // row elements per lane: all loads of the row in flight before the first store
+    float v[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      const int q = lane + 64 * k;
+      v[k] = q < P ? __builtin_nontemporal_load(o + q) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      const int q = lane + 64 * k;
+      if (q < P) o[q] = (float)(scale * (double)v[k]);
+    }
   }
 }
 

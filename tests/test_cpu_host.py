@@ -31,7 +31,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.ssg_abi_version() == 1
     assert lib.ssg_status_string(0) == b"ok"
     assert b"LDS" in lib.ssg_status_string(-2)
-    assert lib.ssg_kernel_name(25, 9, 0).startswith(b"ssg_fwd_tiled")
+    assert lib.ssg_kernel_name(25, 9, 0).startswith(b"ssg_fwd_")
     assert lib.ssg_kernel_name(7, 3, 1) == b"ssg_bwd_generic"
     assert lib.ssg_loss_workspace_bytes(16, 256, 256, 100000, 25) > 100000 * 12
 

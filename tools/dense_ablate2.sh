@@ -1,0 +1,28 @@
+#!/bin/bash
+# phase ablation of the dense forward kernel at 100 % and 30 % density (threshold 64), 4 x 3x256x256
+cd "${GRAFT_REPO_ROOT:-.}"
+cat > /tmp/dd2.py <<'PY'
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from ssl_amd import engine, synth, _lib
+dev = torch.device("cuda:0")
+sr_np, gt_np, _ = synth.make_batch(4, 256, 256)
+rng = np.random.default_rng(0)
+for dens in (0.3, 1.0):
+    m = (rng.random((4, 1, 256, 256)) < dens).astype(np.float32)
+    sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, m))
+    el = engine.edge_list(mask=mask)
+    n = int(el.counts[0])
+    L = _lib.lib(); P = engine._ptr
+    s1 = torch.empty((n, 625), device=dev); s2 = torch.empty((n, 625), device=dev)
+    def f():
+        _lib.check(L.ssg_map_forward(P(sr), P(gt), 4, 3, 256, 256, P(el.edges), P(el.order), P(el.rank), P(el.plan), P(el.counts), n, 25, 9, 1.0, 1e-10, 1, P(s1), P(s2), torch.cuda.current_stream().cuda_stream))
+    f(); torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(5): f()
+    en.record(); en.synchronize()
+    print(f"  density {dens:4.2f}: fwd {st.elapsed_time(en)/5:.3f} ms", end="")
+print()
+PY
+for m in 0 1 2 8 9 10 64 72; do echo -n "dense_dbg=$m:"; SSG_DENSE_THR=64 SSG_DEBUG_SKIP=$((m<<16)) python /tmp/dd2.py 2>&1 | tail -1; done
