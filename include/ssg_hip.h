@@ -103,8 +103,8 @@ int ssg_compute_similarity_backward(const float *image, const float *grads,
  *          fwd_plan (nullable, needs rank_map) ssg_forward_plan_bytes() bytes:
  *                 the forward's work split -- 8x32-pixel tiles holding at
  *                 least ssg_set_dense_threshold() edge pixels go to the
- *                 shared-term ("dense") kernel; the direct kernels walk
- *                 tile_order and skip those tiles' rows.  Unused while the
+ *                 shared-term ("dense") kernel, the remaining rows, in their
+ *                 own tile-major order, to the direct kernels.  Unused while the
  *                 threshold is 0 or for kernel sizes other than (25, 9, C=3).
  * scratch: ssg_edge_scratch_bytes(B,H,W) bytes of device memory. */
 size_t ssg_edge_scratch_bytes(int B, int H, int W);

@@ -21,7 +21,7 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
                      int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
                      void *scratch, hipStream_t st);
 size_t fwd_plan_bytes(int B, int H, int W, int capacity);
-int fwd_plan_flags_offset(int B, int H, int W);
+int fwd_plan_order_offset(int B, int H, int W);
 struct DenseParams {
   const float *img[2];
   float *out[2];
@@ -202,7 +202,7 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
   p.kw = kw;
   p.dbg = dbg_mask() & 0xff;
   if (dense_threshold() > 0 && fwd_plan && rank_map && dense_supported(ks, kw, C)) {
-    // dense tiles -> shared-term kernel; the direct kernels drop the jobs of flagged super-tiles
+    // dense tiles -> shared-term kernel; the rest (plan's own tile-major order) -> direct kernels
     DenseParams d{};
     d.img[0] = img;
     d.img[1] = img2;
@@ -224,7 +224,8 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
     d.dbg = (dbg_mask() >> 16) & 0xff;
     const int rc = launch_fwd_dense(d, ks, kw, C, (hipStream_t)stream);
     if (rc) return rc;
-    p.dense_flag = fwd_plan + fwd_plan_flags_offset(B, H, W);
+    p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
+    p.n_dev = fwd_plan;  // n_sparse
   }
   return launch_fwd(p, (hipStream_t)stream);
 }

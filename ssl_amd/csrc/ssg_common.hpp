@@ -115,7 +115,6 @@ struct FwdParams {
   int raw;  // 1: out += D (reference operator)   0: SSG epilogue
   int ks, kw;  // used by the generic kernel only
   int dbg;     // profiling ablations (0 in production): bit0 skip fill, bit1 skip compute, bit2 skip epilogue/store
-  const int *dense_flag;  // nullable: per 8x32 super-tile, 1 = its edge pixels belong to the dense-tile kernel
 };
 
 // How the backward kernel obtains G = dL/dD for a job.

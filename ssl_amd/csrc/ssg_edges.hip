@@ -192,23 +192,23 @@ __global__ __launch_bounds__(256) void tile_count(const int *rank, int B, int H,
   if (lane == 0) cnt[tile] = (skip && skip[super_tile_of(tile, H, W)]) ? 0 : __popcll(bal);
 }
 
-// one workgroup per 8 x 32 super-tile: count its edge pixels, flag it dense at >= thr and append it
-// to the dense list (plan[1] = count, zeroed by the caller)
-__global__ __launch_bounds__(256) void plan_classify(const int *rank, int H, int W, int thr, int *dflag, int *plan,
-                                                     int *dense_ids) {
-  __shared__ int wc[4];
-  const int sx_n = (W + 31) / 32, ty_n = (H + OT - 1) / OT;
-  const int st = blockIdx.x, b = st / (sx_n * ty_n), t = st - b * sx_n * ty_n;
-  const int y = (t / sx_n) * OT + threadIdx.x / 32, x = (t % sx_n) * 32 + threadIdx.x % 32;
-  const int r = (y < H && x < W) ? rank[((size_t)b * H + y) * W + x] : -1;
-  const unsigned long long bal = __ballot(r >= 0);
-  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int n = wc[0] + wc[1] + wc[2] + wc[3];
-    const int dense = thr > 0 && n >= thr;
-    dflag[st] = dense;
-    if (dense) dense_ids[atomicAdd(&plan[1], 1)] = st;
+// one lane per 8 x 32 super-tile (4 order tiles of a tile row): from the order tiles' counts, flag it dense at
+// >= thr edge pixels, append it to the dense list (plan[1] = count, zeroed by the caller) and zero the counts
+// of its tiles in place, so that the scan + scatter that follow build the order of the REMAINING rows
+__global__ __launch_bounds__(256) void plan_from_counts(int *tcnt, int B, int H, int W, int thr, int *dflag, int *plan,
+                                                        int *dense_ids) {
+  const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT, sx_n = (W + 31) / 32;
+  const int st = blockIdx.x * 256 + threadIdx.x;
+  if (st >= B * ty_n * sx_n) return;
+  const int row = st / sx_n, sx = st - row * sx_n;  // row = b * ty_n + tile row
+  const int t0 = row * tx_n + 4 * sx, nt = (4 * sx + 4 <= tx_n) ? 4 : tx_n - 4 * sx;
+  int n = 0;
+  for (int k = 0; k < nt; ++k) n += tcnt[t0 + k];
+  const int dense = thr > 0 && n >= thr;
+  dflag[st] = dense;
+  if (dense) {
+    dense_ids[atomicAdd(&plan[1], 1)] = st;
+    for (int k = 0; k < nt; ++k) tcnt[t0 + k] = 0;
   }
 }
 
@@ -318,24 +318,26 @@ size_t edge_scratch_bytes(int B, int H, int W) {
   return (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64;
 }
 
-// forward plan: [0] -, [1] n_dense, [2..3] -, [4, 4+ns) the dense kernel's super-tile ids, [4+ns, 4+2ns) one
-// flag per super-tile (ns = n_super_tiles).  The direct kernels walk the common tile-major order and drop
-// the jobs whose super-tile is flagged.
-int fwd_plan_flags_offset(int B, int H, int W) { return 4 + (int)n_super_tiles(B, H, W); }
+// forward plan: [0] n_sparse, [1] n_dense, [2..3] -, [4, 4+ns) the dense kernel's super-tile ids (ns =
+// n_super_tiles), then (capacity) the tile-major order of the rows left to the direct kernels
+int fwd_plan_order_offset(int B, int H, int W) { return 4 + (int)n_super_tiles(B, H, W); }
 
 size_t fwd_plan_bytes(int B, int H, int W, int capacity) {
-  (void)capacity;
-  return sizeof(int) * (4 + 2 * n_super_tiles(B, H, W));
+  return sizeof(int) * (4 + (size_t)(capacity > 0 ? capacity : 1) + n_super_tiles(B, H, W));
 }
 
-static void build_order(const int *rank, int B, int H, int W, int *order, int capacity, const int *edges,
-                        const int *n_ptr, int *total_out, const int *skip, int *tcnt, int *toff, hipStream_t st) {
+static void ensure_scan_attr() {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(int) * (SCAN_LDS + 1024 + 4)));
     attr_set = true;
   }
+}
+
+static void build_order(const int *rank, int B, int H, int W, int *order, int capacity, const int *edges,
+                        const int *n_ptr, int *total_out, const int *skip, int *tcnt, int *toff, hipStream_t st) {
+  ensure_scan_attr();
   const int nt = (int)n_order_tiles(B, H, W);
   hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, skip);
   hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), sizeof(int) * (SCAN_LDS + 1024 + 4), st, tcnt, toff, nt, total_out);
@@ -359,9 +361,19 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   int *tcnt = blockoff + nblk, *toff = tcnt + nt;
   if (order) build_order(rank, B, H, W, order, capacity, edges, counts, nullptr, nullptr, tcnt, toff, st);
   if (plan) {
+    // needs the full order's tile counts (tcnt): built above when `order` is given, else here
+    ensure_scan_attr();
+    if (!order) hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, nullptr);
     const int ns = (int)n_super_tiles(B, H, W);
+    int *dflag = toff + nt, *order2 = plan + 4 + ns;
     (void)hipMemsetAsync(plan, 0, 4 * sizeof(int), st);
-    hipLaunchKernelGGL(plan_classify, dim3(ns), dim3(256), 0, st, rank, H, W, dense_thr, plan + 4 + ns, plan, plan + 4);
+    hipLaunchKernelGGL(plan_from_counts, dim3((ns + 255) / 256), dim3(256), 0, st, tcnt, B, H, W, dense_thr, dflag, plan,
+                       plan + 4);
+    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), sizeof(int) * (SCAN_LDS + 1024 + 4), st, tcnt, toff, nt, plan);
+    hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order2, capacity, dflag);
+    const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
+    if (ngroups > 0)
+      hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256), dim3(256), 0, st, order2, edges, plan, capacity);
   }
   return (int)hipGetLastError();
 }

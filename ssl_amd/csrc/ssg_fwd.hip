@@ -86,10 +86,6 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
       which = (job0 + tid) - row * p.nimg;
     }
     const Edge e = load_edge(p.edges, p.estride, row < 0 ? 0 : row);
-    if (p.dense_flag && row >= 0) {  // the dense-tile kernel computes this pixel's rows
-      const int sx_n = (W + 31) / 32, ty_n = (H + 7) / 8;
-      if (p.dense_flag[(e.b * ty_n + e.y / 8) * sx_n + e.x / 32]) row = -1;
-    }
     sh_edge[tid * 6 + 0] = e.b;
     sh_edge[tid * 6 + 1] = e.y;
     sh_edge[tid * 6 + 2] = e.x;
@@ -99,12 +95,6 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   for (int i = tid; i < G::ZROW + 4; i += WG) zero[i] = 0.f;
   if (tid < PADF) smem[tid] = 0.f;
   __syncthreads();
-  if (p.dense_flag) {  // nothing left for the direct kernels in this group?
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < JOBS; ++j) any = any || sh_edge[j * 6 + 3] >= 0;
-    if (!any) return;
-  }
 
   // common window of the group's jobs (uniform across the workgroup; merged variant only)
   int my0 = 1 << 30, mx0 = 1 << 30, my1 = -1, mx1 = -1, mb0 = 0, mw0 = 0;
