@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
 #pragma unroll
         for (int c = 0; c < C; ++c) w[c][qxi % LW] = rq[c * RH * RS + LW + qxi];
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private buffer: lockstep hand-off
+      // (the H buffer is private to this wave and LDS operations of one wave execute in issue order: the reads
+      // below see the writes above, and the next step's writes cannot overtake them -- no wait, no barrier)
       // ---- the tile's edge pixels: weighted vertical taps, row complement, exp, store ----
 #pragma unroll
       for (int ck = 0; ck < NCHUNK; ++ck) {
@@ -285,7 +286,6 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
           }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // H rows are overwritten by the next step
     });
   }
 
