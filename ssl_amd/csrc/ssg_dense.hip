@@ -72,8 +72,11 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   float *F = reg + C * RH * RS;            // [UH][UW]   sum_c I^2 on U
   float *HF = F + UH * UW;                 // [UH][DT_X] full-window horizontal sums of F
   float *Hb = HF + UH * DT_X;              // [4][UH][DT_X] per-wave horizontal sums of E_q
-  double *rsum = (double *)(Hb + 4 * UH * DT_X);  // [4][NE_MAX] per-wave partial row sums (fp64, see ssg_fwd.hip)
-  int *elist = (int *)(rsum + 4 * NE_MAX);        // [NE_MAX][3] (ey, ex, row)
+  // per-wave partial row sums (fp64, see ssg_fwd.hip): wave w's NE_MAX doubles reuse ITS OWN H buffer once its
+  // offset rows are done (same size, wave-private, so no other wave is still reading it)
+  double *rsum = (double *)Hb;                    // [4][NE_MAX]
+  static_assert(NE_MAX * sizeof(double) == UH * DT_X * sizeof(float), "row sums alias the wave's H buffer");
+  int *elist = (int *)(Hb + 4 * UH * DT_X);       // [NE_MAX][3] (ey, ex, row)
   int *misc = elist + NE_MAX * 3;          // [8]: wave counts, n_e
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -141,7 +144,6 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     }
     F[i] = t;
   }
-  for (int i = tid; i < 4 * NE_MAX; i += 256) rsum[i] = 0.0;
   __syncthreads();
   for (int i = tid; i < UH * DT_X; i += 256) {
     const int ur = i / DT_X, tc = i - ur * DT_X;
@@ -324,7 +326,7 @@ template <int KS, int KW, int C>
 static size_t dense_lds_bytes() {
   constexpr int HALO = KS / 2 + KW / 2, RH = DT_Y + 2 * HALO, RS = DT_X + 2 * HALO + 1;
   constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X;
-  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_X + 4 * UH * DT_X + 2 * 4 * NE) + sizeof(int) * (NE * 3 + 8);
+  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_X + 4 * UH * DT_X) + sizeof(int) * (NE * 3 + 8);
 }
 
 bool dense_supported(int ks, int kw, int C) { return ks == 25 && kw == 9 && C == 3; }
