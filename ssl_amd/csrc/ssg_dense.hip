@@ -237,6 +237,17 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
       }
       // horizontal sums for the 8 centre columns: E on taps [xlo, xhi], |I|^2 on the others
       float Hs[8];
+      if constexpr (xlo == -HK && xhi == HK && KW == 9) {
+        // full 9-tap windows (17 of the 25 steps): pair / quad / octet sums shared between the 8 outputs,
+        // 44 additions instead of 64
+        float p2[15], p4[13];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) p2[i] = E[i] + E[i + 1];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) p4[i] = p2[i] + p2[i + 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Hs[j] = (p4[j] + p4[j + 4]) + E[j + 8];
+      } else
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = E[j + HK + xlo];
