@@ -92,7 +92,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters):
                                        p(lscratch), st))
 
     out = {}
-    for name, f in (("edge_list+plan(13 kernels)", f_edges), (L.ssg_kernel_name(KS, KW, 0).decode(), f_fwd),
+    for name, f in (("edge_list+order+plan", f_edges), (L.ssg_kernel_name(KS, KW, 0).decode(), f_fwd),
                     (L.ssg_kernel_name(KS, KW, 1).decode() + "+finalize", f_bwd)):
         f()
         torch.cuda.synchronize()
