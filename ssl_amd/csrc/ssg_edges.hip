@@ -212,58 +212,66 @@ __global__ __launch_bounds__(256) void plan_from_counts(int *tcnt, int B, int H,
   }
 }
 
-// exclusive scan of cnt[0..n) by one workgroup: the counts are staged in LDS with coalesced
-// loads (up to SCAN_LDS entries per round), each of the 1024 lanes sums a contiguous run from
-// LDS, one Hillis-Steele pass scans the run totals, the runs are re-walked in LDS and the
-// offsets leave with coalesced stores.
-constexpr int SCAN_LDS = 16384;
+// exclusive scan of cnt[0..n) by one workgroup, 16 Ki entries per round: every lane keeps a run of 16
+// consecutive counts in registers (four 16-byte loads), the run sums are scanned with shuffles inside the waves
+// and across the 16 wave totals (two barriers per round), and the offsets leave as four 16-byte stores.
+constexpr int SCAN_RUN = 16, SCAN_ROUND = 1024 * SCAN_RUN;
 
 __global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int n, int *total_out) {
-  extern __shared__ int stage[];  // [SCAN_LDS] + [1024] + carry
-  int *buf = stage + SCAN_LDS;
-  int &carry = stage[SCAN_LDS + 1024];
-  const int tid = threadIdx.x;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += SCAN_LDS) {
-    const int m = n - base < SCAN_LDS ? n - base : SCAN_LDS;
-    for (int i = tid; i < m; i += 1024) stage[i] = cnt[base + i];
-    __syncthreads();
-    const int run = (m + 1023) / 1024;
-    const int lo = tid * run, hi = lo + run < m ? lo + run : m;
+  __shared__ int wtot[16], wincl[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int carry = 0;  // kept identical in every lane
+  for (int base = 0; base < n; base += SCAN_ROUND) {
+    const int lo = base + tid * SCAN_RUN;
+    int v[SCAN_RUN];
+    if (lo + SCAN_RUN <= n && ((size_t)(cnt + lo) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < SCAN_RUN; k += 4) {
+        const int4 q = *(const int4 *)(cnt + lo + k);
+        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SCAN_RUN; ++k) v[k] = lo + k < n ? cnt[lo + k] : 0;
+    }
     int s = 0;
-    for (int i = lo; i < hi; ++i) s += stage[i];
-    // inclusive scan of the 1024 run sums: shuffles inside each wave, then the 16 wave totals
+#pragma unroll
+    for (int k = 0; k < SCAN_RUN; ++k) s += v[k];
     int incl = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int t = __shfl_up(incl, o, 64);
-      if ((tid & 63) >= o) incl += t;
+      if (lane >= o) incl += t;
     }
-    if ((tid & 63) == 63) buf[tid >> 6] = incl;
+    if (lane == 63) wtot[wv] = incl;
     __syncthreads();
     if (tid < 64) {
-      int w = tid < 16 ? buf[tid] : 0;
+      int w = tid < 16 ? wtot[tid] : 0;
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
         const int t = __shfl_up(w, o, 64);
         if (tid >= o) w += t;
       }
-      if (tid < 16) buf[16 + tid] = w;  // inclusive wave totals
+      if (tid < 16) wincl[tid] = w;
     }
     __syncthreads();
-    incl += (tid >> 6) ? buf[16 + (tid >> 6) - 1] : 0;
-    if (tid == 1023) buf[1023] = incl;
-    int acc = carry + incl - s;
-    for (int i = lo; i < hi; ++i) {
-      const int v = stage[i];
-      stage[i] = acc;
-      acc += v;
+    int acc = carry + (wv ? wincl[wv - 1] : 0) + incl - s;
+    carry += wincl[15];
+#pragma unroll
+    for (int k = 0; k < SCAN_RUN; ++k) {
+      const int t = v[k];
+      v[k] = acc;
+      acc += t;
     }
-    __syncthreads();
-    for (int i = tid; i < m; i += 1024) off[base + i] = stage[i];
-    if (tid == 1023) carry += buf[1023];
-    __syncthreads();
+    if (lo + SCAN_RUN <= n && ((size_t)(off + lo) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < SCAN_RUN; k += 4) *(int4 *)(off + lo + k) = make_int4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < SCAN_RUN; ++k)
+        if (lo + k < n) off[lo + k] = v[k];
+    }
+    __syncthreads();  // wtot / wincl are rewritten by the next round
   }
   if (total_out && tid == 0) *total_out = carry;
 }
@@ -326,21 +334,11 @@ size_t fwd_plan_bytes(int B, int H, int W, int capacity) {
   return sizeof(int) * (4 + (size_t)(capacity > 0 ? capacity : 1) + n_super_tiles(B, H, W));
 }
 
-static void ensure_scan_attr() {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(int) * (SCAN_LDS + 1024 + 4)));
-    attr_set = true;
-  }
-}
-
 static void build_order(const int *rank, int B, int H, int W, int *order, int capacity, const int *edges,
                         const int *n_ptr, int *total_out, const int *skip, int *tcnt, int *toff, hipStream_t st) {
-  ensure_scan_attr();
   const int nt = (int)n_order_tiles(B, H, W);
   hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, skip);
-  hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), sizeof(int) * (SCAN_LDS + 1024 + 4), st, tcnt, toff, nt, total_out);
+  hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, total_out);
   hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity, skip);
   const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
   if (ngroups > 0)
@@ -362,14 +360,13 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   if (order) build_order(rank, B, H, W, order, capacity, edges, counts, nullptr, nullptr, tcnt, toff, st);
   if (plan) {
     // needs the full order's tile counts (tcnt): built above when `order` is given, else here
-    ensure_scan_attr();
-    if (!order) hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, nullptr);
+      if (!order) hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, nullptr);
     const int ns = (int)n_super_tiles(B, H, W);
     int *dflag = toff + nt, *order2 = plan + 4 + ns;
     (void)hipMemsetAsync(plan, 0, 4 * sizeof(int), st);
     hipLaunchKernelGGL(plan_from_counts, dim3((ns + 255) / 256), dim3(256), 0, st, tcnt, B, H, W, dense_thr, dflag, plan,
                        plan + 4);
-    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), sizeof(int) * (SCAN_LDS + 1024 + 4), st, tcnt, toff, nt, plan);
+    hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, plan);
     hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order2, capacity, dflag);
     const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
     if (ngroups > 0)
