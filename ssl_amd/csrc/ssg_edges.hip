@@ -293,7 +293,11 @@ __global__ __launch_bounds__(256) void tile_scatter(const int *rank, int B, int 
 // Marks the groups of ORDER_GROUP consecutive jobs whose edge pixels are one image's and lie within
 // 8 rows x 16 columns (bit ORDER_FLAG of the group's first entry): the forward kernel variants pick
 // their groups from this flag with a single load.
-__global__ __launch_bounds__(256) void tile_group_flags(int *order, const int *edges, const int *n_ptr, int capacity) {
+// (up to two orders per launch: blockIdx.y picks the (order, row count) pair)
+__global__ __launch_bounds__(256) void tile_group_flags(int *order_a, const int *n_a, int *order_b, const int *n_b,
+                                                        const int *edges, int capacity) {
+  int *order = blockIdx.y ? order_b : order_a;
+  const int *n_ptr = blockIdx.y ? n_b : n_a;
   const int g = blockIdx.x * 256 + threadIdx.x;
   int n = n_ptr[0];
   n = n < capacity ? n : capacity;
@@ -335,15 +339,15 @@ size_t fwd_plan_bytes(int B, int H, int W, int capacity) {
 }
 
 static void build_order(const int *rank, int B, int H, int W, int *order, int capacity, const int *edges,
-                        const int *n_ptr, int *total_out, const int *skip, int *tcnt, int *toff, hipStream_t st) {
+                        const int *n_ptr, bool flags, int *tcnt, int *toff, hipStream_t st) {
   const int nt = (int)n_order_tiles(B, H, W);
-  hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, skip);
-  hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, total_out);
-  hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity, skip);
+  hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, nullptr);
+  hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, nullptr);
+  hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity, nullptr);
   const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
-  if (ngroups > 0)
-    hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256), dim3(256), 0, st, order, edges,
-                       total_out ? total_out : n_ptr, capacity);
+  if (flags && ngroups > 0)
+    hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256, 1), dim3(256), 0, st, order, n_ptr, nullptr, nullptr,
+                       edges, capacity);
 }
 
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
@@ -357,7 +361,8 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank);
   const int nt = (int)n_order_tiles(B, H, W);
   int *tcnt = blockoff + nblk, *toff = tcnt + nt;
-  if (order) build_order(rank, B, H, W, order, capacity, edges, counts, nullptr, nullptr, tcnt, toff, st);
+  // (with a forward plan the group flags of both orders are set by one launch at the end)
+  if (order) build_order(rank, B, H, W, order, capacity, edges, counts, !plan, tcnt, toff, st);
   if (plan) {
     // needs the full order's tile counts (tcnt): built above when `order` is given, else here
       if (!order) hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, nullptr);
@@ -370,7 +375,8 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
     hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order2, capacity, dflag);
     const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
     if (ngroups > 0)
-      hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256), dim3(256), 0, st, order2, edges, plan, capacity);
+      hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256, order ? 2 : 1), dim3(256), 0, st, order2, plan, order,
+                         counts, edges, capacity);
   }
   return (int)hipGetLastError();
 }
