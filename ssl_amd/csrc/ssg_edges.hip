@@ -69,8 +69,13 @@ __device__ __forceinline__ unsigned chunk_bits(const EdgeParams &p, int &b, int 
   return bits;
 }
 
-__global__ __launch_bounds__(256) void edge_count(EdgeParams p, int *blockcnt) {
+constexpr int OT = 8;  // order tile side (pixels)
+
+// (also zeroes the order tiles' counters that edge_scatter fills)
+__global__ __launch_bounds__(256) void edge_count(EdgeParams p, int *blockcnt, int *tcnt, int nt) {
   __shared__ int wsum[4];
+  if (tcnt)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gridDim.x * 256) tcnt[i] = 0;
   int b, pix0;
   const unsigned bits = chunk_bits(p, b, pix0);
   int c = __popc(bits);
@@ -84,10 +89,11 @@ __global__ __launch_bounds__(256) void edge_count(EdgeParams p, int *blockcnt) {
 // exclusive scan of blockcnt[0..nblk) -> blockoff, plus counts (B+2):
 // counts[0] = N, counts[1+b] = first row of image b, counts[1+B] = N.
 __global__ __launch_bounds__(1024) void edge_scan(const int *blockcnt, int *blockoff, int nblk, int nblk_img, int B,
-                                                  int *counts) {
+                                                  int *counts, int *plan_header) {
   __shared__ int buf[1024];
   __shared__ int carry;
   const int tid = threadIdx.x;
+  if (plan_header && tid < 4) plan_header[tid] = 0;
   if (tid == 0) carry = 0;
   __syncthreads();
   for (int base = 0; base < nblk; base += 1024) {
@@ -117,31 +123,34 @@ __global__ __launch_bounds__(1024) void edge_scan(const int *blockcnt, int *bloc
 }
 
 __global__ __launch_bounds__(256) void edge_scatter(EdgeParams p, const int *blockoff, int *edges, int capacity,
-                                                    int *rank) {
-  __shared__ int buf[256];
+                                                    int *rank, int *tcnt) {
+  __shared__ int wtot[4];
   int b, pix0;
   const unsigned bits = chunk_bits(p, b, pix0);
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = __popc(bits);
-  buf[tid] = c;
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    const int t = tid >= o ? buf[tid - o] : 0;
-    __syncthreads();
-    buf[tid] += t;
-    __syncthreads();
+  int incl = c;  // inclusive scan over the 256 lanes: shuffles inside the waves + the 4 wave totals
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
   }
-  int pos = blockoff[blockIdx.x] + buf[tid] - c;
+  if (lane == 63) wtot[wv] = incl;
+  __syncthreads();
+  for (int k = 0; k < wv; ++k) incl += wtot[k];
+  int pos = blockoff[blockIdx.x] + incl - c;
   const int HW = p.H * p.W;
+  const int tx_n = (p.W + OT - 1) / OT, ty_n = (p.H + OT - 1) / OT;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int pix = pix0 + k;
     const bool on = bits & (1u << k);
     if (on && pos < capacity) {
-      const int y = pix / p.W;
+      const int y = pix / p.W, x = pix - y * p.W;
       edges[3 * (size_t)pos + 0] = b;
       edges[3 * (size_t)pos + 1] = y;
-      edges[3 * (size_t)pos + 2] = pix - y * p.W;
+      edges[3 * (size_t)pos + 2] = x;
+      if (tcnt) atomicAdd(&tcnt[(b * ty_n + y / OT) * tx_n + x / OT], 1);  // rows per 8x8 order tile
     }
     // rank map: row index of every pixel (-1: not an edge pixel / beyond capacity)
     if (rank && pix < HW) rank[(size_t)b * HW + pix] = (on && pos < capacity) ? pos : -1;
@@ -162,7 +171,6 @@ __global__ __launch_bounds__(256) void edge_mask_write(EdgeParams p, uint8_t *ou
 // order[k] = row of `edges` that job k works on: rows grouped by 8x8 image tile (tiles in
 // image-major, row-major order; row-major inside a tile), so consecutive jobs are spatial
 // neighbours.  Built from the rank map: one wave per tile.
-constexpr int OT = 8;
 
 __device__ __forceinline__ int tile_rank(const int *rank, int B, int H, int W, int tile, int lane, int &n_valid) {
   const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT;
@@ -180,17 +188,6 @@ __device__ __forceinline__ int super_tile_of(int tile, int H, int W) {
   return (b * ty_n + t / tx_n) * sx_n + (t % tx_n) / 4;
 }
 
-// `skip` (nullable): per super-tile flag; tiles of flagged super-tiles contribute no rows (they are
-// the dense forward kernel's)
-__global__ __launch_bounds__(256) void tile_count(const int *rank, int B, int H, int W, int ntiles, int *cnt,
-                                                  const int *skip) {
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (tile >= ntiles) return;
-  int nv;
-  const int r = tile_rank(rank, B, H, W, tile, lane, nv);
-  const unsigned long long bal = __ballot(r >= 0);
-  if (lane == 0) cnt[tile] = (skip && skip[super_tile_of(tile, H, W)]) ? 0 : __popcll(bal);
-}
 
 // one lane per 8 x 32 super-tile (4 order tiles of a tile row): from the order tiles' counts, flag it dense at
 // >= thr edge pixels, append it to the dense list (plan[1] = count, zeroed by the caller) and zero the counts
@@ -341,7 +338,6 @@ size_t fwd_plan_bytes(int B, int H, int W, int capacity) {
 static void build_order(const int *rank, int B, int H, int W, int *order, int capacity, const int *edges,
                         const int *n_ptr, bool flags, int *tcnt, int *toff, hipStream_t st) {
   const int nt = (int)n_order_tiles(B, H, W);
-  hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, nullptr);
   hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, nullptr);
   hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity, nullptr);
   const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
@@ -355,20 +351,19 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
                      void *scratch, hipStream_t st) {
   EdgeParams p{mask, kind, mask_channels, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
   const int nblk = B * p.nblk_img;
-  int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;
-  hipLaunchKernelGGL(edge_count, dim3(nblk), dim3(256), 0, st, p, blockcnt);
-  hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts);
-  hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank);
   const int nt = (int)n_order_tiles(B, H, W);
+  int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;
   int *tcnt = blockoff + nblk, *toff = tcnt + nt;
+  const bool need_tiles = order || plan;  // rows per 8x8 order tile, counted while the edges are scattered
+  hipLaunchKernelGGL(edge_count, dim3(nblk), dim3(256), 0, st, p, blockcnt, need_tiles ? tcnt : nullptr, nt);
+  hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts, plan);
+  hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank,
+                     need_tiles ? tcnt : nullptr);
   // (with a forward plan the group flags of both orders are set by one launch at the end)
   if (order) build_order(rank, B, H, W, order, capacity, edges, counts, !plan, tcnt, toff, st);
   if (plan) {
-    // needs the full order's tile counts (tcnt): built above when `order` is given, else here
-      if (!order) hipLaunchKernelGGL(tile_count, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, tcnt, nullptr);
     const int ns = (int)n_super_tiles(B, H, W);
     int *dflag = toff + nt, *order2 = plan + 4 + ns;
-    (void)hipMemsetAsync(plan, 0, 4 * sizeof(int), st);
     hipLaunchKernelGGL(plan_from_counts, dim3((ns + 255) / 256), dim3(256), 0, st, tcnt, B, H, W, dense_thr, dflag, plan,
                        plan + 4);
     hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, plan);
