@@ -12,15 +12,17 @@ sr = np.stack([synth.degrade(gt[i], 2100 + i) for i in range(B)])
 mask = np.stack([orc.mask_stride(synth.laplacian_edge_mask(gt[i]), 3) for i in range(B)]).astype(np.float32)
 step = engine.LossStep(B, 3, H, W, 25, 9, 0.004, 1e-20, True, 5e2, 5e2, device=dev)
 T = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
-loss, grad = step(T(sr), T(gt), T(mask[:, None]))
+a, b, c = T(sr), T(gt), T(mask[:, None])
+loss, grad = step(a, b, c)
 n = int(step.counts[0])
 ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask, 25, 9, 0.004, 5e2, 5e2, eps=1e-20)
 l = loss.cpu().numpy()
 ge = float(np.abs(grad.cpu().numpy() - ref["grad"]).max() / np.abs(ref["grad"]).max())
-ms = bench.event_time_ms(lambda: step(T(sr), T(gt), T(mask[:, None])), 5)
+ms = bench.event_time_ms(lambda: step(a, b, c), 10)
 print(f"C4-shaped: N={n} (oracle {ref['n_edges']})  l1 {l[0]:.6g} vs {ref['l1']:.6g}  kl {l[1]:.6g} vs {ref['kl']:.6g}  grad rel err {ge:.2e}  {ms:.3f} ms/step")
 # the same with the mask at full density (no stride): dense tiles appear
 mask2 = np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(B)]).astype(np.float32)
-loss, grad = step(T(sr), T(gt), T(mask2[:, None])); n2 = int(step.counts[0])
-ms2 = bench.event_time_ms(lambda: step(T(sr), T(gt), T(mask2[:, None])), 5)
+c2 = T(mask2[:, None])
+loss, grad = step(a, b, c2); n2 = int(step.counts[0])
+ms2 = bench.event_time_ms(lambda: step(a, b, c2), 10)
 print(f"  without mask_stride: N={n2}  {ms2:.3f} ms/step")
