@@ -87,7 +87,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters):
                                      n_edges, KS, KW, SIGMA, EPS, 1, p(step.ssg_sr), p(step.ssg_gt), st))
 
     def f_bwd():
-        _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(step.counts), n_edges, KS, KW, SIGMA, 1,
+        _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts), n_edges, KS, KW, SIGMA, 1,
                                        p(step.ssg_sr), p(step.ssg_gt), W_L1, W_KL, None, p(step.loss), p(step.grad),
                                        p(lscratch), st))
 

@@ -73,7 +73,9 @@ int ssg_compute_similarity_backward(const float *image, const float *grads,
  * mask_kind: 0 = fp32 mask (B,mask_channels,H,W), an edge pixel is
  *                `mask[b,0,y,x] == 1.0f` (loss_util.py:196 on channel 0, like
  *                ssl_cuda's mask[0,0], loss_util.py:233);
- *            1 = uint8 mask, same layout, `!= 0`;
+ *            1 = uint8 mask, same layout, `== 1` (a 0/255 PNG mask must be
+ *                divided by 255 first, exactly as for the reference's
+ *                `mask == 1`);
  *            2 = no mask tensor: `mask` is the fp32 GT batch (B,3,H,W) in
  *                [0,1] and the reference's offline mask is generated on the
  *                fly: u8 = round(255 x), L = PIL 'L' (ITU-R 601-2 16.16 fixed
@@ -103,9 +105,11 @@ int ssg_compute_similarity_backward(const float *image, const float *grads,
  *          fwd_plan (nullable, needs rank_map) ssg_forward_plan_bytes() bytes:
  *                 the forward's work split -- 8x32-pixel tiles holding at
  *                 least ssg_set_dense_threshold() edge pixels go to the
- *                 shared-term ("dense") kernel, the remaining rows, in their
- *                 own tile-major order, to the direct kernels.  Unused while the
- *                 threshold is 0 or for kernel sizes other than (25, 9, C=3).
+ *                 shared-term ("dense") kernels, the remaining rows, in their
+ *                 own tile-major order, to the direct kernels.  The plan records
+ *                 its own split (with threshold 0: no dense tile, every row in
+ *                 the direct order), so its consumers never read the process-wide
+ *                 threshold.  Kernel sizes other than (25, 9, C=3) ignore it.
  * scratch: ssg_edge_scratch_bytes(B,H,W) bytes of device memory. */
 size_t ssg_edge_scratch_bytes(int B, int H, int W);
 size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
@@ -150,13 +154,21 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H,
                     float *ssg, float *ssg2, ssg_stream_t stream);
 
 /* Backward of the above: grad_img (B,C,H,W) += d/d img of sum(grad_ssg * ssg)
- * (reflect fold included).  `ssg` is the forward output (saved). */
+ * (reflect fold included).  `ssg` is the forward output (saved).
+ * With rank_map, fwd_plan (both from ssg_edge_list) and `scratch`
+ * (ssg_backward_scratch_bytes(n_rows, ks) bytes) the backward is split like
+ * the forward: dL/dD rows are formed once (ssg_grad_rows), the plan's dense
+ * tiles go through the shared-term backward kernel and the remaining rows
+ * through the direct one.  Any of the three null: direct kernel for every row. */
+size_t ssg_backward_scratch_bytes(int n_rows, int ks);
 int ssg_map_backward(const float *img, int B, int C, int H, int W,
                      const int *edges, const int *tile_order /* nullable */,
+                     const int *rank_map /* nullable */,
+                     const int *fwd_plan /* nullable */,
                      const int *n_edges_dev, int n_rows,
                      int ks, int kw, float sigma, int generalization,
                      const float *ssg, const float *grad_ssg, float *grad_img,
-                     ssg_stream_t stream);
+                     void *scratch /* nullable */, ssg_stream_t stream);
 
 /* ---------------------------------------------------------------- (D) ----
  * The whole loss step of the caller loop over a batch:
@@ -166,7 +178,9 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W,
  * and grad_sr (B,C,H,W) += d(l1+kl)/d sr.
  *
  * ssg_loss_backward consumes SSGs already computed by ssg_map_forward
- * (API-compatible mode: SSG tensors are materialised once each).  `upstream`
+ * (API-compatible mode: SSG tensors are materialised once each); rank_map and
+ * fwd_plan (nullable, from ssg_edge_list) select the split backward described
+ * at ssg_map_backward (its scratch is part of ssg_loss_scratch_bytes).  `upstream`
  * (nullable) points at two DEVICE floats {dL/dl1, dL/dkl} that scale the two
  * criteria's gradients (autograd's incoming gradients, read on device so the
  * host never synchronises); null means {1,1}.
@@ -174,6 +188,8 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W,
 size_t ssg_loss_scratch_bytes(int B, int H, int W, int n_rows, int ks);
 int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
                       const int *edges, const int *tile_order /* nullable */,
+                      const int *rank_map /* nullable */,
+                      const int *fwd_plan /* nullable */,
                       const int *n_edges_dev, int n_rows,
                       int ks, int kw, float sigma, int generalization,
                       const float *ssg_sr, const float *ssg_gt, float w_l1,

@@ -41,6 +41,11 @@ bool dense_supported(int ks, int kw, int C);
 int dense_max_tiles(int B, int H, int W);
 int launch_fwd_dense(const DenseParams &p, int ks, int kw, int C, hipStream_t st);
 int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride, uint8_t *out, hipStream_t st);
+bool grow_supported(int ks, int kw);
+unsigned grow_grid(int n_host);
+int launch_grad_rows(const GrowParams &p, int ks, int kw, hipStream_t st);
+bool dense_bwd_supported(int ks, int kw, int C);
+int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st);
 }  // namespace ssg
 
 using namespace ssg;
@@ -78,13 +83,88 @@ static int dbg_mask() {
   return v;
 }
 
-static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (kw & 1); }
+static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (kw & 1) && kw <= ks; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Waves per tile of the dense-tile backward (each takes a contiguous range of offset rows); SSG_BWD_QSPLIT
+// overrides it for experiments.
+static int bwd_qsplit() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SSG_BWD_QSPLIT");
+    v = e ? atoi(e) : 1;
+    if (v < 1) v = 1;
+    if (v > 25) v = 25;
+  }
+  return v;
+}
+
+// Scratch of the split backward (ssg_grad_rows -> dense-tile kernel + direct kernel): G (n, k_s^2), sum_b (n).
+static size_t split_scratch_bytes(int n_rows, int ks) {
+  const size_t n = (size_t)(n_rows > 0 ? n_rows : 1);
+  return align_up(sizeof(float) * n * ks * ks, 256) + align_up(sizeof(float) * n, 256);
+}
+
+// Backward over a forward plan: G rows (+ criteria sums) by ssg_grad_rows, the dense tiles by the shared-term
+// kernel, the remaining rows by the direct kernel in GRAD_D mode.  `p` carries the sources as for launch_bwd.
+static int split_backward(BwdParams p, const int *rank, const int *plan, void *scratch, hipStream_t st) {
+  float *G = (float *)scratch;
+  float *sum_b = (float *)((char *)scratch + align_up(sizeof(float) * (size_t)p.n_host * p.ks * p.ks, 256));
+  GrowParams g{};
+  g.mode = p.mode;
+  g.gin = p.gin;
+  g.ssg = p.ssg;
+  g.ssg2 = p.ssg2;
+  g.n_dev = p.n_dev;
+  g.n_host = p.n_host;
+  g.C = p.C;
+  g.sigma = p.sigma;
+  g.generalization = p.generalization;
+  g.w_l1 = p.w_l1;
+  g.w_kl = p.w_kl;
+  g.upstream = p.upstream;
+  g.G = p.grad ? G : nullptr;
+  g.sum_b = p.grad ? sum_b : nullptr;
+  g.partials = p.partials;
+  int rc = launch_grad_rows(g, p.ks, p.kw, st);
+  if (rc || !p.grad) return rc;
+  const float *grows = p.mode == GRAD_D ? p.gin : G;
+  DenseBwdParams d{};
+  d.img = p.img;
+  d.grad = p.grad;
+  d.G = grows;
+  d.sum_b = sum_b;
+  d.rank = rank;
+  d.n_dense = plan + 1;
+  d.tiles = plan + 4;
+  d.max_tiles = dense_max_tiles(p.B, p.H, p.W);
+  d.n_dev = p.n_dev;
+  d.n_host = p.n_host;
+  d.B = p.B;
+  d.H = p.H;
+  d.W = p.W;
+  d.qsplit = bwd_qsplit();
+  d.dbg = p.dbg;
+  rc = launch_bwd_dense(d, p.ks, p.kw, p.C, st);
+  if (rc) return rc;
+  BwdParams s = p;
+  s.mode = GRAD_D;
+  s.gin = grows;
+  s.order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
+  s.n_dev = plan;  // n_sparse
+  s.partials = nullptr;
+  return launch_bwd(s, st);
+}
+
+static bool split_ok(int ks, int kw, int C, const int *rank, const int *plan, const void *scratch) {
+  return rank && plan && scratch && grow_supported(ks, kw) && dense_bwd_supported(ks, kw, C) &&
+         !(dbg_mask() & (1 << 24));
+}
+
 extern "C" {
 
-int ssg_abi_version(void) { return 1; }
+int ssg_abi_version(void) { return 2; }
 
 const char *ssg_status_string(int status) {
   switch (status) {
@@ -146,7 +226,7 @@ int ssg_compute_similarity_backward(const float *image, const float *grads, cons
   p.sigma = 1.f;
   p.ks = psize;
   p.kw = ksize;
-  p.dbg = dbg_mask() >> 8;
+  p.dbg = (dbg_mask() >> 8) & 0xff;
   return launch_bwd(p, (hipStream_t)stream);
 }
 
@@ -160,9 +240,10 @@ int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int
   if (!mask || !edges || !counts || !scratch || B <= 0 || H <= 0 || W <= 0 || capacity < 0 || mask_kind < 0 ||
       mask_kind > 2 || mask_channels <= 0 || ((tile_order || fwd_plan) && !rank_map))
     return SSG_E_BADARG;
+  // (the plan is always built when asked for -- with threshold 0 it lists no dense tile and every row in its
+  // direct order -- so that the kernels consuming it never depend on the process-wide threshold)
   return launch_edge_list(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, edges, capacity,
-                          counts, rank_map, tile_order, dense_threshold() > 0 ? fwd_plan : nullptr, dense_threshold(),
-                          scratch, (hipStream_t)stream);
+                          counts, rank_map, tile_order, fwd_plan, dense_threshold(), scratch, (hipStream_t)stream);
 }
 
 int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_threshold, int mask_stride,
@@ -201,7 +282,7 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
   p.ks = ks;
   p.kw = kw;
   p.dbg = dbg_mask() & 0xff;
-  if (dense_threshold() > 0 && fwd_plan && rank_map && dense_supported(ks, kw, C)) {
+  if (fwd_plan && rank_map && dense_supported(ks, kw, C)) {
     // dense tiles -> shared-term kernel; the rest (plan's own tile-major order) -> direct kernels
     DenseParams d{};
     d.img[0] = img;
@@ -230,9 +311,12 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
   return launch_fwd(p, (hipStream_t)stream);
 }
 
+size_t ssg_backward_scratch_bytes(int n_rows, int ks) { return split_scratch_bytes(n_rows, ks); }
+
 int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *edges, const int *tile_order,
-                     const int *n_edges_dev, int n_rows, int ks, int kw, float sigma, int generalization,
-                     const float *ssg, const float *grad_ssg, float *grad_img, ssg_stream_t stream) {
+                     const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
+                     float sigma, int generalization, const float *ssg, const float *grad_ssg, float *grad_img,
+                     void *scratch, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -256,17 +340,22 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *ed
   p.generalization = generalization;
   p.ks = ks;
   p.kw = kw;
-  p.dbg = dbg_mask() >> 8;
+  p.dbg = (dbg_mask() >> 8) & 0xff;
+  if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) return split_backward(p, rank_map, fwd_plan, scratch, (hipStream_t)stream);
   return launch_bwd(p, (hipStream_t)stream);
 }
 
+static size_t partials_bytes(int B, int H, int W, int n_rows) {
+  return align_up(2 * sizeof(float) * bwd_max_partials(B, H, W, n_rows) + 64, 256);
+}
+
 size_t ssg_loss_scratch_bytes(int B, int H, int W, int n_rows, int ks) {
-  (void)ks;
-  return 2 * sizeof(float) * bwd_max_partials(B, H, W, n_rows) + 64;
+  return partials_bytes(B, H, W, n_rows) + split_scratch_bytes(n_rows, ks);
 }
 
 int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *tile_order,
-                      const int *n_edges_dev, int n_rows, int ks, int kw, float sigma, int generalization,
+                      const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
+                      float sigma, int generalization,
                       const float *ssg_sr, const float *ssg_gt, float w_l1, float w_kl, const float *upstream,
                       float *loss_out, float *grad_sr, void *scratch, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
@@ -297,7 +386,12 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
   p.upstream = upstream;
   p.ks = ks;
   p.kw = kw;
-  p.dbg = dbg_mask() >> 8;
+  p.dbg = (dbg_mask() >> 8) & 0xff;
+  if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
+    const int rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st);
+    if (rc) return rc;
+    return launch_loss_finalize(p.partials, (int)grow_grid(n_rows), n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
+  }
   int rc = launch_bwd(p, st);
   if (rc) return rc;
   return launch_loss_finalize(p.partials, (int)bwd_grid(p), n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
@@ -336,8 +430,8 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
                        generalization, ssg_sr, ssg_gt, stream);
   if (rc) return rc;
-  return ssg_loss_backward(sr, B, C, H, W, edges, order, counts, capacity, ks, kw, sigma, generalization, ssg_sr,
-                           ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);
+  return ssg_loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
+                           ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);
 }
 
 const char *ssg_kernel_name(int ks, int kw, int backward) {

@@ -58,27 +58,6 @@ __device__ __forceinline__ void load_grow(const float *tg, const float *zrow, in
   for (int j = 0; j < G::PW; ++j) out[j] = rowp[cx0 + j];
 }
 
-// dL/dS of the two criteria at one element (a = s_sr, b = s_gt), and the
-// criteria's un-normalised terms.
-__device__ __forceinline__ float criteria_elem(float a, float b, float w1m, float w2m, float &l1, float &kl) {
-  const float cl = 1e-10f;
-  const float ac = fmaxf(a, cl), bc = fmaxf(b, cl);
-  l1 += fabsf(a - b);
-  // t (log t - log s) is evaluated as t log(t/s).  Both arguments are clamped to [1e-10, 1], so the ratio is a
-  // normal number and the hardware reciprocal / log2 apply without the range handling of logf() and operator/;
-  // v_log_f32 is relative-accurate (<= 1e-7) also next to 1 (profiles/r1_microbench_log.txt).  The KL sum
-  // cancels to second order where s ~ t, so a *systematic* relative error eps of the ratio would add eps to
-  // every row (v_rcp_f32 alone: 2e-5 of the loss on fixture F1): one Newton step makes the quotient correctly
-  // rounded, i.e. unbiased.
-  const float rc = __builtin_amdgcn_rcpf(ac);
-  const float r0 = bc * rc;
-  const float ratio = __builtin_fmaf(__builtin_fmaf(-r0, ac, bc), rc, r0);
-  kl += bc * (0.69314718056f * __builtin_amdgcn_logf(ratio));
-  float g = a > b ? w1m : (a < b ? -w1m : 0.f);
-  if (a >= cl) g -= w2m * ratio;
-  return g;
-}
-
 // Workgroup w takes JOBS consecutive entries of the job order: either the caller's row order
 // (reference operator interface: arbitrary pos list) or, when `p.order` is given, the tile-major
 // permutation the edge-list builder wrote (8x8 image tiles, row-major inside a tile).  In tile

@@ -1,0 +1,479 @@
+// Dense-tile ("shared-term") backward SSG kernel for gfx950.
+//
+// The direct backward (ssg_bwd.hip) spends ~2*C*k_w^2 FMAs per (edge pixel, search offset).  Where
+// edge pixels are dense the work is shared, exactly as in the forward (ssg_dense.hip): with
+//     D[n,q] = sum_{k in K(q)} sum_c (I[x_n+k] - I[x_n+k+q])^2 + sum_{k in win \ K(q)} sum_c I[x_n+k]^2
+// (K(q) = the part of the k_w x k_w window whose partner stays inside the search area: the reference's
+// "B = 0 outside the area" rule, similarity.cu:43-47 == F.unfold zero padding, loss_util.py:208) and
+// G = dL/dD, the reference's per-term atomics (similarity.cu:113-128) sum to
+//     dL/dI[c,v] = 2 sum_q { W_q[v] (I[v] - I[v+q])  -  W_q[v-q] (I[v-q] - I[v])  +  V_q[v] I[v] }
+//     W_q[u] = sum_{n : u - x_n in K(q)} G[n,q]         (truncated box sum of the sparse field G[.,q])
+//     V_q[u] = sum_{n : u - x_n in win \ K(q)} G[n,q]
+// in padded coordinates (the reflect fold follows by index mirroring when the result is added to the
+// image gradient).  sum_q V_q = Box(sum_b) - sum_{q border} W_q with sum_b[n] = sum of G[n,q] over the
+// offsets whose window is truncated (from ssg_grad_rows), so V costs one extra box sum per tile.
+//
+// One WAVE owns a tile of TY x 32 candidate centres (TY + k_w - 1 = 16) and, for a range of offset
+// rows q_y, walks the k_s offsets q_x fully unrolled.  Per offset:
+//   1. the tile's edge pixels (census from the rank map) drop G[n,q] into a zero-padded LDS field;
+//   2. W_q on the tile grown by the window halo (U, 16 x (32 + k_w - 1) pixels): horizontal truncated
+//      sums in lanes (tile row, column group), vertical inclusive prefix across the tile rows with DPP
+//      row shifts, prefix rows to LDS; lane (U-row r, column group g) reads two prefix rows: the
+//      vertical window is their difference (at most TY terms deep);
+//   3. lane (r, g) owns NPX consecutive pixels u of U-row r: I[c,u], a circular register window of
+//      I[c,u+q] (one LDS dword per channel and step), accumulators for dL/dI[c,u] (live for the whole
+//      sweep) and a circular window of accumulators for dL/dI[c,u+q]; the column of that window that
+//      is complete after the step is added to a 16-row LDS band of the gradient region (plain
+//      read-modify-write: one wave, in-order LDS, distinct addresses per lane).
+// After an offset row the band row that is complete goes to HBM with one fp32 atomic per non-zero
+// pixel and the image band advances by one row.  Cost per (tile, offset): ~200 wave instructions
+// whatever the number of edge pixels, against ~19 k lane-instructions per edge pixel and offset row
+// in the direct kernel.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "ssg_common.hpp"
+
+namespace ssg {
+
+template <int SH>
+__device__ __forceinline__ float dpp_row_shr(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xf, 0xf, true));
+}
+
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Nothing moves across an offset step: without it hipcc hoists the address arithmetic and the LDS loads of all
+// k_s unrolled steps to the top of the offset row (1,100 live values, 650 spilled).
+__device__ __forceinline__ void step_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KS, int KW, int C, int TY>
+struct DenseBwdGeo {
+  static constexpr int TX = 32, HP = KS / 2, HK = KW / 2, HALO = HP + HK, P = KS * KS;
+  static constexpr int UH = TY + 2 * HK, UW = TX + 2 * HK;    // tile grown by the window halo
+  static constexpr int NPX = UW / 4, NPXP = (NPX + 1) & ~1;   // pixels per lane (and padded)
+  static constexpr int RW = UW + KS - 1, RH = UH + KS - 1;    // gradient / image region
+  static constexpr int RWS = RW | 1;                          // odd row stride: rows fall on distinct banks
+  static constexpr int BR = 16;                               // band rows
+  static constexpr int HG = 64 / TY, HOUT = (UW + HG - 1) / HG;
+  // padded G field row.  The horizontal-sum lanes (tile row hty, group hg) read dword hty*GQS + HOUT*hg + m: with
+  // GQS = 20 (mod 32) for (TY 8, HOUT 5) / 8 (mod 32) for (TY 4, HOUT 3) the 32 lanes of a half-wave fall on 32
+  // different banks
+  static constexpr int GQS_MIN = (HG * HOUT > UW ? HG * HOUT : UW) + 2 * HK;
+  static constexpr int GQS_RES = TY == 8 ? 20 : 8;
+  static constexpr int GQS = GQS_MIN + ((GQS_RES - GQS_MIN % 32) + 32) % 32;
+  static constexpr int PS = 4 * NPXP;                         // prefix row
+  static constexpr int FSZ = TY * GQS + (TY + 1) * PS;        // one field + its prefix rows (two copies: steps alternate)
+  static constexpr int NE_MAX = TY * TX, NCHUNK = NE_MAX / 64;
+  static constexpr int NG = KS / 4;                           // full groups of 4 offsets per offset row
+  static constexpr int CPL = (RW + 63) / 64;                  // region columns per lane (row loads / flushes)
+  static_assert(UH == 16 && UW % 4 == 0, "lane map: 16 U-rows x 4 column groups");
+  static_assert(KS % 4 == 1, "offset rows are consumed as groups of 4 + 1");
+  static_assert(64 % TY == 0 && TY <= 8, "prefix lanes: tile row in the low lane bits");
+  static constexpr size_t lds_bytes() {
+    return sizeof(float) * (size_t)(2 * BR * C * RWS + 2 * FSZ + 4);
+  }
+};
+
+// NCH = 64-pixel chunks of the tile's edge-pixel list this instantiation carries per offset step; a wave
+// whose tile needs another count leaves at once (every instantiation is launched over the same tile list), so
+// the offset loop is free of control flow.
+template <int KS, int KW, int C, int TY, int NCH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_bwd_dense(DenseBwdParams p) {
+  using G = DenseBwdGeo<KS, KW, C, TY>;
+  constexpr int TX = G::TX, HP = G::HP, HK = G::HK, HALO = G::HALO, P = G::P;
+  constexpr int UW = G::UW, NPX = G::NPX, NPXP = G::NPXP, RW = G::RW, RH = G::RH, RWS = G::RWS;
+  constexpr int HOUT = G::HOUT, GQS = G::GQS, PS = G::PS, NCHUNK = G::NCHUNK, NG = G::NG, CPL = G::CPL;
+  constexpr int FSZ = G::FSZ;
+  constexpr int DUMMY = 2 * FSZ;  // word after both copies (relative to the first field): absorbs the field writes of lanes without an edge pixel
+  constexpr int NCH_LO = NCH <= 2 ? 0 : NCH / 2;  // instantiations: 2 and 4 chunks
+  static_assert(NG % 2 == 0 && NCH <= NCHUNK, "two G slots alternate over an even number of groups");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *imgb = smem;                       // [16][C][RWS] image band: region rows q_y .. q_y+15
+  float *grb = imgb + 16 * C * RWS;         // [16][C][RWS] gradient band, same rows
+  // two copies (offset steps alternate) of { [TY][GQS] G[.,q] on the tile, 2*HK zeros left of every row;
+  //                                          [TY+1][PS] vertical prefix of the horizontal sums (row 0 = 0) }
+  float *fld = grb + 16 * C * RWS;
+  int *elist = (int *)imgb;  // [NE_MAX][2] (field offset, row): prologue only, the image band is filled afterwards
+  static_assert(2 * G::NE_MAX <= 16 * C * RWS, "edge list aliases the image band");
+
+  const int lane = threadIdx.x;
+  const int tslot = blockIdx.x;
+  if (tslot >= *p.n_dense) return;
+  const int H = p.H, W = p.W;
+  const int tx_n = (W + TX - 1) / TX, ty_n = (H + TY - 1) / TY;
+  const int tile = p.tiles[tslot];
+  const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
+  const int ty0 = (tr / tx_n) * TY, tx0 = (tr % tx_n) * TX;
+  const int nrows = rows_to_do(p.n_dev, p.n_host);
+  const int qy0 = (KS * (int)blockIdx.y) / p.qsplit, qy1 = (KS * ((int)blockIdx.y + 1)) / p.qsplit;
+
+  // ---- census of the tile's edge pixels (row-major inside the tile) ----
+  int n_e = 0;
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k) {
+    const int pos = lane + 64 * k, ey = pos / TX, ex = pos - ey * TX;
+    const int y = ty0 + ey, x = tx0 + ex;
+    int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+    if (r >= nrows) r = -1;
+    const unsigned long long bal = __ballot(r >= 0);
+    if (r >= 0) {
+      const int at = n_e + __popcll(bal & ((1ull << lane) - 1ull));
+      elist[2 * at] = ey * GQS + 2 * HK + ex;
+      elist[2 * at + 1] = r;
+    }
+    n_e += __popcll(bal);
+  }
+  if (n_e <= 64 * NCH_LO || n_e > 64 * NCH) return;
+  for (int i = lane; i < 2 * FSZ + 4; i += 64) fld[i] = 0.f;  // fields (pads stay 0) and prefix rows 0
+  for (int i = lane; i < 16 * C * RWS; i += 64) grb[i] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+
+  int epos[NCH];
+  const float *gp[NCH];
+  int erow[NCH];
+#pragma unroll
+  for (int ck = 0; ck < NCH; ++ck) {
+    const int e = ck * 64 + lane;
+    const bool on = e < n_e;
+    epos[ck] = on ? elist[2 * e] : DUMMY;
+    erow[ck] = on ? elist[2 * e + 1] : elist[1];
+    gp[ck] = p.G + (size_t)erow[ck] * P;
+  }
+
+  // lane roles: main (U-row r, column group g); prefix (tile row hty, column group hg)
+  const int r = lane >> 2, g = lane & 3;
+  const int hty = lane % TY, hg = lane / TY;
+  const float m1 = hty >= 1 ? 1.f : 0.f, m2 = hty >= 2 ? 1.f : 0.f, m4 = hty >= 4 ? 1.f : 0.f;
+  const int hsrc = hty * GQS + HOUT * hg;  // (offsets relative to a copy's base)
+  int hdst[HOUT];
+#pragma unroll
+  for (int i = 0; i < HOUT; ++i) {
+    const int uc = HOUT * hg + i;
+    hdst[i] = TY * GQS + (hty + 1) * PS + (uc < UW ? (uc / NPX) * NPXP + uc % NPX : PS - 1);
+  }
+
+  // The box sum W of the field in copy `f` on the lane's NPX pixels comes in two halves, so that consecutive
+  // offset steps overlap (x_stage of step s+1 runs beside the body of step s):
+  //   x_stage: horizontal sums over the column taps kept (XLO..XHI), vertical inclusive prefix, prefix rows to LDS;
+  //   y_read : the lane's pixels = difference of the two prefix rows bounding the row taps kept.
+  auto x_stage = [&](auto xlo_c, auto xhi_c, float *f) {
+    constexpr int XLO = decltype(xlo_c)::value, XHI = decltype(xhi_c)::value;
+    constexpr int M0 = HK - XHI, M1 = HOUT - 1 + HK - XLO;  // taps m of output i: [i + HK - XHI, i + HK - XLO]
+    float v[HOUT + 2 * HK];
+#pragma unroll
+    for (int m = M0; m <= M1; ++m) v[m] = f[hsrc + m];
+    float out[HOUT];
+#pragma unroll
+    for (int i = 0; i < HOUT; ++i) {
+      float t = v[i + HK - XHI];
+#pragma unroll
+      for (int m = i + HK - XHI + 1; m <= i + HK - XLO; ++m) t += v[m];
+      out[i] = t;
+    }
+    // inclusive prefix over the tile rows (adjacent lanes); the 0/1 factors stop a row group from reading
+    // its neighbour's lanes
+#pragma unroll
+    for (int i = 0; i < HOUT; ++i) {
+      out[i] = __builtin_fmaf(dpp_row_shr<1>(out[i]), m1, out[i]);
+      if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
+      if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < HOUT; ++i) f[hdst[i]] = out[i];
+  };
+  auto y_read = [&](const float *f, int pa, int pb, float (&Wv)[NPX]) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) Wv[i] = f[pb + i] - f[pa + i];
+  };
+  // prefix rows of U-row r for row taps [ylo, yhi]: tile rows [r-HK-yhi, r-HK-ylo] clipped to the tile
+  auto prefix_rows = [&](int ylo, int yhi, int &pa, int &pb) {
+    int a = r - HK - yhi, bb = r - HK - ylo;
+    a = a < 0 ? 0 : a;
+    bb = bb > TY - 1 ? TY - 1 : bb;
+    const bool none = a > bb;
+    pa = TY * GQS + (none ? 0 : a * PS) + NPXP * g;
+    pb = TY * GQS + (none ? 0 : (bb + 1) * PS) + NPXP * g;
+  };
+
+  // ---- the lane's own pixels, and Box(sum_b) on them ----
+  const float *src = p.img + (size_t)b * C * H * W;
+  float iu[C][NPX];
+  {
+    int gy = reflect_idx(ty0 - HK + r, H);
+    gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      int gx = reflect_idx(tx0 - HK + NPX * g + i, W);
+      gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+#pragma unroll
+      for (int c = 0; c < C; ++c) iu[c][i] = src[((size_t)c * H + gy) * W + gx];
+    }
+  }
+  // image band rows: global -> registers -> LDS (lane = region column)
+  auto load_img_row = [&](int rho, float (&v)[C][CPL]) {
+    int gy = reflect_idx(ty0 - HALO + rho, H);
+    gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int col = lane + 64 * k;
+      int gx = reflect_idx(tx0 - HALO + (col < RW ? col : 0), W);
+      gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[c][k] = src[((size_t)c * H + gy) * W + gx];
+    }
+  };
+  auto store_img_row = [&](int rho, const float (&v)[C][CPL]) {
+    float *dst = imgb + (rho & 15) * C * RWS;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int col = lane + 64 * k;
+      if (col < RW) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) dst[c * RWS + col] = v[c][k];
+      }
+    }
+  };
+  // one finished row of the gradient band -> HBM (reflect fold by index mirroring), band row cleared
+  auto flush_row = [&](int rho) {
+    float *brow = grb + (rho & 15) * C * RWS;
+    const int py = ty0 - HALO + rho;
+    const int gy = reflect_idx(py, H);
+    const bool yok = gy >= 0 && gy < H;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int col = lane + 64 * k;
+      if (col < RW) {
+        const int gx = reflect_idx(tx0 - HALO + col, W);
+        const bool ok = yok && gx >= 0 && gx < W;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float v = brow[c * RWS + col];
+          brow[c * RWS + col] = 0.f;
+          if (ok && v != 0.f && !(p.dbg & 8)) unsafeAtomicAdd(p.grad + (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v);
+        }
+      }
+    }
+  };
+
+  for (int rho = qy0; rho < qy0 + 16; ++rho) {
+    float v[C][CPL];
+    load_img_row(rho, v);
+    store_img_row(rho, v);
+  }
+
+  float gu[C][NPX], swb[NPX];
+#pragma unroll
+  for (int i = 0; i < NPX; ++i) {
+    swb[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gu[c][i] = 0.f;
+  }
+
+  // G values of the lane's edge pixels, 4 offsets per load, one group ahead (two register slots) + the row's
+  // last offset on its own
+  float4u gbuf[2][NCH];
+  float gl[NCH];
+  auto load_group = [&](int qyi, int k, float4u (&dst)[NCH]) {
+#pragma unroll
+    for (int ck = 0; ck < NCH; ++ck) dst[ck] = *(const float4u *)(gp[ck] + qyi * KS + 4 * k);
+  };
+  auto load_last = [&](int qyi) {
+#pragma unroll
+    for (int ck = 0; ck < NCH; ++ck) gl[ck] = gp[ck][qyi * KS + KS - 1];
+  };
+  load_group(qy0, 0, gbuf[0]);
+  load_group(qy0, 1, gbuf[1]);
+  load_last(qy0);
+  // G[.,q] of one offset into field copy f; x_put(.., qyi, qxi) reads the registers the schedule below filled
+  auto x_put = [&](auto qx_c, int qyi, float *f) {
+    constexpr int qxi = decltype(qx_c)::value, grp = qxi / 4, gj = qxi % 4;
+#pragma unroll
+    for (int ck = 0; ck < NCH; ++ck) {
+      float gv = grp < NG ? gbuf[grp & 1][ck][gj] : gl[ck];
+      if constexpr (qxi == HP) gv = (qyi == HP) ? 0.f : gv;  // centre offset: A - B == 0 exactly
+      f[epos[ck]] = gv;
+    }
+  };
+  // The work of one offset t is spread over three steps so that a step waits for LDS ONCE:
+  //   end of step t-2 : G[., t] into field copy t&1                       (x_put)
+  //   step t-1        : top: read the field; horizontal sums + prefix; end: prefix rows to copy t&1   (x_stage)
+  //   step t          : top: read the two prefix rows (W), the band column to flush, the next window
+  //                     column; body; end: band column, next step's writes
+  // Every LDS read of a step is issued at its top and touches only what earlier steps wrote.
+  {  // first two offsets of the sweep (copy = parity of the offset's linear index; k_s is odd)
+    float *f0 = fld + ((qy0 * KS) & 1) * FSZ, *f1 = fld + (((qy0 * KS) & 1) ^ 1) * FSZ;
+    x_put(std::integral_constant<int, 0>{}, qy0, f0);
+    x_put(std::integral_constant<int, 1>{}, qy0, f1);
+    __builtin_amdgcn_wave_barrier();
+    x_stage(std::integral_constant<int, (-HK > 0 ? -HK : 0)>{}, std::integral_constant<int, HK>{}, f0);
+    step_fence();
+  }
+
+#pragma unroll 1
+  for (int qyi = qy0; qyi < qy1; ++qyi) {
+    // (next row's prefetches run unconditionally on clamped rows: the offset loop stays branch-free)
+    const int qyn = qyi + 1 < KS ? qyi + 1 : KS - 1;
+    float nrow[C][CPL];
+    load_img_row(qyi + 16 < RH ? qyi + 16 : RH - 1, nrow);
+    const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
+    const float ymask = (ylo > -HK || yhi < HK) ? 1.f : 0.f;
+    int pa, pb;
+    prefix_rows(ylo, yhi, pa, pb);
+    float *fe = fld + (qyi & 1) * FSZ, *fo = fld + ((qyi & 1) ^ 1) * FSZ;  // copies of the even / odd q_x of this row
+    const int slr = (r + qyi) & 15;
+    const float *ib = imgb + slr * C * RWS + NPX * g;
+    float *gb = grb + slr * C * RWS + NPX * g;
+    float w[C][NPX], gr[C][NPX];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        w[c][i] = ib[c * RWS + i];
+        gr[c][i] = 0.f;
+      }
+    static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
+      constexpr int qxi = decltype(qc)::value;
+      constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
+      constexpr int grp = qxi / 4, gj = qxi % 4;
+      constexpr int qxn = (qxi + 1) % KS, qx2 = (qxi + 2) % KS;  // offsets prepared during this step
+      constexpr int nlo = (-HK > -qxn) ? -HK : -qxn, nhi = (HK < KS - 1 - qxn) ? HK : KS - 1 - qxn;
+      constexpr int M0 = HK - nhi, M1 = HOUT - 1 + HK - nlo;
+      float *fc = (qxi & 1) ? fo : fe, *fn = (qxi & 1) ? fe : fo;  // (k_s odd: the next row's offsets continue the alternation)
+      // G prefetch, two groups ahead: group grp+2 (of the next row past the end) replaces group grp, whose last
+      // value went to LDS a step ago; the row's last offset on its own
+      if constexpr (gj == 2 && grp < NG) {
+        if constexpr (grp + 2 < NG) load_group(qyi, grp + 2, gbuf[grp & 1]);
+        else load_group(qyn, grp + 2 - NG, gbuf[grp & 1]);
+      }
+      if constexpr (qxi == KS - 2) load_last(qyn);
+      // ---- top: every LDS read of the step ----
+      float wa[NPX], wb[NPX], v[HOUT + 2 * HK], fl[C], wn[C];
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        wb[i] = fc[pb + i];
+        wa[i] = fc[pa + i];
+      }
+#pragma unroll
+      for (int m = M0; m <= M1; ++m) v[m] = fn[hsrc + m];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        fl[c] = gb[c * RWS + qxi];
+        wn[c] = (qxi + 1 < KS) ? ib[c * RWS + qxi + NPX] : 0.f;
+      }
+      // ---- both ends of every pair (u, u+q) ----
+      constexpr bool xborder = xlo > -HK || xhi < HK;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const float Wi = wb[i] - wa[i];
+        if constexpr (xborder) swb[i] += Wi;
+        else swb[i] = __builtin_fmaf(Wi, ymask, swb[i]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float d = iu[c][i] - w[c][(i + qxi) % NPX];
+          gu[c][i] = __builtin_fmaf(Wi, d, gu[c][i]);
+          gr[c][(i + qxi) % NPX] = __builtin_fmaf(-Wi, d, gr[c][(i + qxi) % NPX]);
+        }
+      }
+      // ---- next offset: horizontal sums over its column taps, vertical prefix ----
+      float out[HOUT];
+#pragma unroll
+      for (int i = 0; i < HOUT; ++i) {
+        float t = v[i + HK - nhi];
+#pragma unroll
+        for (int m = i + HK - nhi + 1; m <= i + HK - nlo; ++m) t += v[m];
+        out[i] = t;
+      }
+#pragma unroll
+      for (int i = 0; i < HOUT; ++i) {
+        out[i] = __builtin_fmaf(dpp_row_shr<1>(out[i]), m1, out[i]);
+        if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
+        if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
+      }
+      // ---- end: every LDS write of the step ----
+#pragma unroll
+      for (int i = 0; i < HOUT; ++i) fn[hdst[i]] = out[i];
+      // region column NPX*g + qxi of this band row is complete: to the band; the window moves on
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        gb[c * RWS + qxi] = fl[c] + gr[c][qxi % NPX];
+        gr[c][qxi % NPX] = 0.f;
+        if constexpr (qxi + 1 < KS) w[c][qxi % NPX] = wn[c];
+      }
+      x_put(std::integral_constant<int, qx2>{}, qxi + 2 < KS ? qyi : qyn, fc);
+      // (the accumulators of the lane's own pixels pass through an empty asm: they are not read again before
+      // the end of the sweep, and hipcc otherwise sinks their FMAs below all k_s steps, keeping every step's
+      // W and differences alive: 1,000 spilled registers)
+      pin_block<C, NPX>(gu);
+      pin_row<NPX>(swb);
+      step_fence();
+    });
+    // the row's last NPX-1 columns
+#pragma unroll
+    for (int i = 1; i < NPX; ++i)
+#pragma unroll
+      for (int c = 0; c < C; ++c) gb[c * RWS + KS - 1 + i] += gr[c][(i + KS - 1) % NPX];
+    __builtin_amdgcn_wave_barrier();
+    flush_row(qyi);
+    store_img_row(qyi + 16, nrow);
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int rho = qy1; rho < qy1 + 15; ++rho) flush_row(rho);
+
+  // ---- the lane's own pixels: + I * sum_q V_q (Box(sum_b) - sum of the border W_q), then to HBM ----
+  float vbox[NPX];
+  {
+#pragma unroll
+    for (int ck = 0; ck < NCH; ++ck) fld[epos[ck]] = (blockIdx.y == 0) ? p.sum_b[erow[ck]] : 0.f;
+    __builtin_amdgcn_wave_barrier();
+    int pa, pb;
+    prefix_rows(-HK, HK, pa, pb);
+    x_stage(std::integral_constant<int, -HK>{}, std::integral_constant<int, HK>{}, fld);
+    __builtin_amdgcn_wave_barrier();
+    y_read(fld, pa, pb, vbox);
+    step_fence();
+  }
+
+  {
+    const int py = ty0 - HK + r;
+    const int gy = reflect_idx(py, H);
+    const bool yok = gy >= 0 && gy < H;
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int gx = reflect_idx(tx0 - HK + NPX * g + i, W);
+      const bool ok = yok && gx >= 0 && gx < W;
+      const float vt = vbox[i] - swb[i];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float v = __builtin_fmaf(iu[c][i], vt, gu[c][i]);
+        if (ok && v != 0.f && !(p.dbg & 8)) unsafeAtomicAdd(p.grad + (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host ----
+bool dense_bwd_supported(int ks, int kw, int C) { return ks == 25 && kw == 9 && C == 3; }
+
+template <int KS, int KW, int C, int TY, int NCH>
+static int launch_one(const DenseBwdParams &p, hipStream_t st) {
+  using G = DenseBwdGeo<KS, KW, C, TY>;
+  (void)hipFuncSetAttribute((const void *)ssg_bwd_dense<KS, KW, C, TY, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)G::lds_bytes());
+  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH>), dim3((unsigned)p.max_tiles, (unsigned)p.qsplit), dim3(64),
+                     G::lds_bytes(), st, p);
+  return (int)hipGetLastError();
+}
+
+int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st) {
+  if (!dense_bwd_supported(ks, kw, C)) return -1;
+  if (p.max_tiles == 0) return 0;
+  int rc = launch_one<25, 9, 3, 8, 2>(p, st);
+  if (!rc) rc = launch_one<25, 9, 3, 8, 4>(p, st);
+  return rc;
+}
+
+}  // namespace ssg

@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace ssg {
 
 // F.pad(mode='reflect') index map (border sample not duplicated).
@@ -64,6 +67,14 @@ __device__ __forceinline__ void pin_row(float (&v)[N]) {
     asm volatile(""
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                    "+v"(v[8])::"memory");
+  } else if constexpr (N == 10) {
+    asm volatile(""
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                   "+v"(v[8]), "+v"(v[9])::"memory");
+  } else if constexpr (N == 11) {
+    asm volatile(""
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10])::"memory");
   } else if constexpr (N == 13) {
     asm volatile(""
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
@@ -144,6 +155,77 @@ struct BwdParams {
   float *partials;  // GRAD_LOSS: (gridDim.x, 2) per-workgroup sums of |a-b| and t'(log t' - log s')
   int ks, kw;       // generic kernel only
   int dbg;          // profiling ablations (0 in production): bit0 skip prologue math, bit1 skip pass A, bit2 skip pass B, bit3 skip atomics
+};
+
+// dL/dS of the two criteria at one element (a = s_sr, b = s_gt), and the
+// criteria's un-normalised terms.
+__device__ __forceinline__ float criteria_elem(float a, float b, float w1m, float w2m, float &l1, float &kl) {
+  const float cl = 1e-10f;
+  const float ac = fmaxf(a, cl), bc = fmaxf(b, cl);
+  l1 += fabsf(a - b);
+  // t (log t - log s) is evaluated as t log(t/s).  Both arguments are clamped to [1e-10, 1], so the ratio is a
+  // normal number and the hardware reciprocal / log2 apply without the range handling of logf() and operator/;
+  // v_log_f32 is relative-accurate (<= 1e-7) also next to 1 (profiles/r1_microbench_log.txt).  The KL sum
+  // cancels to second order where s ~ t, so a *systematic* relative error eps of the ratio would add eps to
+  // every row (v_rcp_f32 alone: 2e-5 of the loss on fixture F1): one Newton step makes the quotient correctly
+  // rounded, i.e. unbiased.
+  const float rc = __builtin_amdgcn_rcpf(ac);
+  const float r0 = bc * rc;
+  const float ratio = __builtin_fmaf(__builtin_fmaf(-r0, ac, bc), rc, r0);
+  kl += bc * (0.69314718056f * __builtin_amdgcn_logf(ratio));
+  float g = a > b ? w1m : (a < b ? -w1m : 0.f);
+  if (a >= cl) g -= w2m * ratio;
+  return g;
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), fully inlined
+// (a `#pragma unroll` over the dense kernels' offset loops was NOT honoured: hipcc kept them rolled and
+// indexed the register arrays through M0, s_set_gpr_idx_on)
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// sum over the 64 lanes, every lane gets the same bits (xor butterfly: a + b == b + a)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ssg_grad_rows (ssg_grow.hip): G = dL/dD rows for the backward kernels
+struct GrowParams {
+  int mode;           // GradMode
+  const float *gin;   // GRAD_D / GRAD_S
+  const float *ssg;   // GRAD_S / GRAD_LOSS
+  const float *ssg2;  // GRAD_LOSS
+  const int *n_dev;
+  int n_host;
+  int C;
+  float sigma;
+  int generalization;
+  float w_l1, w_kl;
+  const float *upstream;  // nullable device {dL/dl1, dL/dkl}
+  float *G;               // (n, P) out; nullable (loss only, or GRAD_D)
+  float *sum_b;           // (n) out; nullable: sum of G over the offsets with a truncated window
+  float *partials;        // (grid, 2), GRAD_LOSS
+};
+
+// ssg_bwd_dense (ssg_bwd_dense.hip)
+struct DenseBwdParams {
+  const float *img;    // (B,C,H,W)
+  float *grad;         // (B,C,H,W), accumulated with fp32 atomics
+  const float *G;      // (n, P) dL/dD rows
+  const float *sum_b;  // (n)
+  const int *rank;     // (B,H,W) row of every pixel, -1 if not an edge pixel
+  const int *n_dense;  // device count of dense tiles
+  const int *tiles;    // dense tile ids
+  int max_tiles;       // launch bound
+  const int *n_dev;    // rows computed at all (capacity clamp), nullable
+  int n_host;
+  int B, H, W;
+  int qsplit;          // waves per tile, each taking a contiguous range of offset rows
+  int dbg;
 };
 
 __device__ __forceinline__ int rows_to_do(const int *n_dev, int n_host) {

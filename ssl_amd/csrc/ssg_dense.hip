@@ -25,20 +25,9 @@
 // Cost: ~235 wave-instructions per (tile, offset) regardless of the number of edge pixels, against
 // 25 * 12.6 k lane-instructions per edge pixel for the direct kernels: break-even at ~27 edge
 // pixels per 256-pixel tile; the edge-list builder routes tiles above the threshold here.
-#include <type_traits>
-#include <utility>
-
 #include "ssg_common.hpp"
 
 namespace ssg {
-
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), fully inlined
-// (a `#pragma unroll` over the offset loop was NOT honoured for this body: hipcc kept it rolled and
-// indexed the register arrays through M0, s_set_gpr_idx_on)
-template <int... Is, class F>
-__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F &&f) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
 
 struct DenseParams {
   const float *img[2];

@@ -38,7 +38,7 @@ __device__ __forceinline__ bool edge_pred(const EdgeParams &p, int b, int y, int
   if (p.kind == 0) {
     return ((const float *)p.mask)[(size_t)b * p.mask_channels * plane + (size_t)y * p.W + x] == 1.0f;
   } else if (p.kind == 1) {
-    return ((const uint8_t *)p.mask)[(size_t)b * p.mask_channels * plane + (size_t)y * p.W + x] != 0;
+    return ((const uint8_t *)p.mask)[(size_t)b * p.mask_channels * plane + (size_t)y * p.W + x] == 1;
   }
   // cv2.Laplacian(L, CV_8U): [[0,1,0],[1,-4,1],[0,1,0]], BORDER_REFLECT_101, saturate
   const float *img = (const float *)p.mask + (size_t)b * 3 * plane;

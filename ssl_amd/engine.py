@@ -55,7 +55,7 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     L = _lib.lib()
     if mask is not None:
         _need_gpu(mask)
-        if mask.dtype == torch.uint8 or mask.dtype == torch.bool:
+        if mask.dtype == torch.uint8 or mask.dtype == torch.bool:   # edge pixel <=> value 1 (True), like `mask == 1`
             src, kind = mask.contiguous().view(torch.uint8), 1
         else:
             src, kind = _f32c(mask), 0
@@ -75,9 +75,10 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     order = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
     plan = torch.empty(L.ssg_forward_plan_bytes(B, H, W, capacity) // 4, dtype=torch.int32, device=dev)
     scratch = torch.empty(L.ssg_edge_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
-    _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold),
-                               _ptr(edges), capacity, _ptr(counts), _ptr(rank), _ptr(order), _ptr(plan),
-                               _ptr(scratch), _stream()))
+    with torch.cuda.device(dev):   # launches go to the tensors' GPU, whatever the current device is
+        _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold),
+                                   _ptr(edges), capacity, _ptr(counts), _ptr(rank), _ptr(order), _ptr(plan),
+                                   _ptr(scratch), _stream()))
     return EdgeList(edges, counts, rank, order, plan)
 
 
@@ -95,8 +96,9 @@ def edge_mask_laplacian(gt, lap_threshold=20.0, mask_stride=0):
     if C != 3:
         raise ValueError("Laplacian edge mask needs a 3-channel image")
     out = torch.empty((B, H, W), dtype=torch.uint8, device=g.device)
-    _lib.check(_lib.lib().ssg_edge_mask_laplacian(_ptr(g), B, H, W, float(lap_threshold), int(mask_stride or 0),
-                                                  _ptr(out), _stream()))
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().ssg_edge_mask_laplacian(_ptr(g), B, H, W, float(lap_threshold), int(mask_stride or 0),
+                                                      _ptr(out), _stream()))
     return out
 
 
@@ -109,11 +111,13 @@ class _SSGMapFn(torch.autograd.Function):
         f_order, f_rank, f_plan = fwd if fwd is not None else (order, None, None)
         B, C, H, W = x.shape
         ssg = torch.empty((n_rows, ks * ks), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().ssg_map_forward(_ptr(x), None, B, C, H, W, _ptr(edges), _ptr(f_order), _ptr(f_rank),
-                                              _ptr(f_plan), _ptr(counts), n_rows, ks, kw, float(sigma), float(eps),
-                                              int(bool(generalization)), _ptr(ssg), None, _stream()))
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ssg_map_forward(_ptr(x), None, B, C, H, W, _ptr(edges), _ptr(f_order), _ptr(f_rank),
+                                                  _ptr(f_plan), _ptr(counts), n_rows, ks, kw, float(sigma), float(eps),
+                                                  int(bool(generalization)), _ptr(ssg), None, _stream()))
         ctx.save_for_backward(x, edges, counts, ssg)
         ctx.order = order
+        ctx.split = (f_rank, f_plan)
         ctx.cfg = (n_rows, ks, kw, float(sigma), int(bool(generalization)))
         return ssg
 
@@ -125,8 +129,15 @@ class _SSGMapFn(torch.autograd.Function):
         B, C, H, W = x.shape
         g = _f32c(grad_ssg)
         grad = torch.zeros_like(x)
-        _lib.check(_lib.lib().ssg_map_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(ctx.order), _ptr(counts), n_rows,
-                                               ks, kw, sigma, gen, _ptr(ssg), _ptr(g), _ptr(grad), _stream()))
+        L = _lib.lib()
+        rank, plan = ctx.split
+        scratch = None
+        if rank is not None and plan is not None:
+            scratch = torch.empty(L.ssg_backward_scratch_bytes(n_rows, ks), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ssg_map_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(ctx.order), _ptr(rank), _ptr(plan),
+                                          _ptr(counts), n_rows, ks, kw, sigma, gen, _ptr(ssg), _ptr(g), _ptr(grad),
+                                          _ptr(scratch), _stream()))
         return grad, None, None, None, None, None, None, None, None, None, None
 
 
@@ -139,46 +150,58 @@ def ssg_map(img, edges, counts, n_rows, ks, kw, sigma, eps=1e-10, generalization
 
 
 class _SSGLossFn(torch.autograd.Function):
-    """(l1, kl) of the caller loop realesrganssl_model.py:379-430 over a batch."""
+    """(l1, kl) of the caller loop realesrganssl_model.py:379-430 over a batch.
+
+    The SSG tensors live only inside forward(): when `sr` needs a gradient, d(l1 + kl)/d sr is produced by the
+    SAME launch sequence that produces the two losses (one ssg_loss_backward call) and is the only thing kept
+    for backward(), which scales it by the incoming gradient.  That is exact whenever both losses receive the
+    same upstream gradient (they are added into one total in every caller of the reference); if autograd hands
+    two different tensors, backward() recomputes the step with them (still no host synchronisation)."""
 
     @staticmethod
-    def forward(ctx, sr, gt, edges, counts, n_rows, ks, kw, sigma, eps, generalization, w_l1, w_kl, order, fwd):
+    def _run(x, y, edges, counts, n_rows, ks, kw, sigma, eps, gen, w_l1, w_kl, order, fwd, upstream, want_grad):
         L = _lib.lib()
         f_order, f_rank, f_plan = fwd if fwd is not None else (order, None, None)
-        x, y = _f32c(sr), _f32c(gt)
         B, C, H, W = x.shape
         dev = x.device
         P = ks * ks
         ssg_sr = torch.empty((max(n_rows, 1), P), dtype=torch.float32, device=dev)
         ssg_gt = torch.empty((max(n_rows, 1), P), dtype=torch.float32, device=dev)
         loss = torch.zeros(2, dtype=torch.float32, device=dev)
+        grad = torch.zeros_like(x) if want_grad else None
         scratch = torch.empty(L.ssg_loss_scratch_bytes(B, H, W, n_rows, ks), dtype=torch.uint8, device=dev)
-        gen = int(bool(generalization))
         _lib.check(L.ssg_map_forward(_ptr(x), _ptr(y), B, C, H, W, _ptr(edges), _ptr(f_order), _ptr(f_rank), _ptr(f_plan),
-                                     _ptr(counts), n_rows, ks, kw, float(sigma), float(eps), gen, _ptr(ssg_sr),
-                                     _ptr(ssg_gt), _stream()))
-        _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(order), _ptr(counts), n_rows, ks, kw,
-                                       float(sigma), gen, _ptr(ssg_sr), _ptr(ssg_gt), float(w_l1), float(w_kl), None,
-                                       _ptr(loss), None, _ptr(scratch), _stream()))
-        ctx.order = order
-        ctx.save_for_backward(x, edges, counts, ssg_sr, ssg_gt, scratch)
-        ctx.cfg = (n_rows, ks, kw, float(sigma), gen, float(w_l1), float(w_kl))
-        ctx.ssg = (ssg_sr, ssg_gt)
+                                     _ptr(counts), n_rows, ks, kw, sigma, eps, gen, _ptr(ssg_sr), _ptr(ssg_gt),
+                                     _stream()))
+        _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(order), _ptr(f_rank), _ptr(f_plan),
+                                       _ptr(counts), n_rows, ks, kw, sigma, gen, _ptr(ssg_sr), _ptr(ssg_gt), w_l1,
+                                       w_kl, _ptr(upstream), _ptr(loss), _ptr(grad), _ptr(scratch), _stream()))
+        return loss, grad
+
+    @staticmethod
+    def forward(ctx, sr, gt, edges, counts, n_rows, ks, kw, sigma, eps, generalization, w_l1, w_kl, order, fwd):
+        x, y = _f32c(sr), _f32c(gt)
+        cfg = (n_rows, ks, kw, float(sigma), float(eps), int(bool(generalization)), float(w_l1), float(w_kl))
+        want_grad = bool(ctx.needs_input_grad[0])
+        with torch.cuda.device(x.device):
+            loss, grad = _SSGLossFn._run(x, y, edges, counts, *cfg, order, fwd, None, want_grad)
+        ctx.cfg, ctx.order, ctx.fwd = cfg, order, fwd
+        if want_grad:
+            ctx.save_for_backward(x, y, edges, counts, grad)
         return loss[0], loss[1]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_l1, g_kl):
-        x, edges, counts, ssg_sr, ssg_gt, scratch = ctx.saved_tensors
-        n_rows, ks, kw, sigma, gen, w_l1, w_kl = ctx.cfg
-        B, C, H, W = x.shape
-        up = torch.stack([g_l1.to(torch.float32).reshape(()), g_kl.to(torch.float32).reshape(())]).contiguous()
-        grad = torch.zeros_like(x)
-        dummy = torch.empty(2, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(ctx.order), _ptr(counts), n_rows,
-                                                ks, kw, sigma, gen, _ptr(ssg_sr), _ptr(ssg_gt), w_l1, w_kl, _ptr(up),
-                                                _ptr(dummy), _ptr(grad), _ptr(scratch), _stream()))
-        return (grad,) + (None,) * 13
+        x, y, edges, counts, grad = ctx.saved_tensors
+        same = (g_l1.data_ptr() == g_kl.data_ptr() and g_l1.numel() == 1 and g_kl.numel() == 1)
+        if same:
+            out = grad * g_l1.to(torch.float32).reshape(())
+        else:
+            up = torch.stack([g_l1.to(torch.float32).reshape(()), g_kl.to(torch.float32).reshape(())]).contiguous()
+            with torch.cuda.device(x.device):
+                _, out = _SSGLossFn._run(x, y, edges, counts, *ctx.cfg, ctx.order, ctx.fwd, up, True)
+        return (out,) + (None,) * 13
 
 
 def ssg_loss(sr, gt, edges, counts, n_rows, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0,
@@ -233,8 +256,8 @@ class LossStep:
         assert sr.dtype == torch.float32 and gt.dtype == torch.float32 and sr.is_contiguous() and gt.is_contiguous()
         if mask is None:
             kind, mc, mp = 2, 3, None
-        elif mask.dtype == torch.uint8:
-            kind, mc, mp = 1, mask.shape[1], mask
+        elif mask.dtype == torch.uint8 or mask.dtype == torch.bool:
+            kind, mc, mp = 1, mask.shape[1], mask.view(torch.uint8)
         else:
             kind, mc, mp = 0, mask.shape[1], mask
             assert mask.dtype == torch.float32
@@ -243,10 +266,12 @@ class LossStep:
 
         def launch():
             self.grad.zero_()
-            _lib.check(_lib.lib().ssg_loss_fwd_bwd(_ptr(sr), _ptr(gt), _ptr(mp), kind, mc, B, C, H, W, ks, kw, sigma,
-                                                   eps, gen, w_l1, w_kl, stride, thr, self.capacity, _ptr(self.ssg_sr),
-                                                   _ptr(self.ssg_gt), _ptr(self.counts), _ptr(self.loss),
-                                                   _ptr(self.grad), _ptr(self.ws), self.ws_bytes, _stream()))
+            with torch.cuda.device(self.grad.device):
+                _lib.check(_lib.lib().ssg_loss_fwd_bwd(_ptr(sr), _ptr(gt), _ptr(mp), kind, mc, B, C, H, W, ks, kw,
+                                                       sigma, eps, gen, w_l1, w_kl, stride, thr, self.capacity,
+                                                       _ptr(self.ssg_sr), _ptr(self.ssg_gt), _ptr(self.counts),
+                                                       _ptr(self.loss), _ptr(self.grad), _ptr(self.ws), self.ws_bytes,
+                                                       _stream()))
 
         if not self.use_graph:
             launch()

@@ -64,29 +64,71 @@ class SSGLoss(nn.Module):
     """Batched Self-Similarity-Graph loss: returns (l_selfsim, l_selfsim_kl).
 
     forward(sr, gt, mask=None): sr, gt (B,C,H,W) on the GPU; mask (B,1|3,H,W)
-    float {0,1} / uint8, or None to generate the reference's offline Laplacian
+    float {0,1} / uint8 {0,1} / bool, or None to generate the reference's offline Laplacian
     edge mask of `gt` on the device (generate_mask.py:22-31).  Semantics of the
     reference loop: images whose mask is empty are skipped, the means run over
     sum_i N_i * k_s^2 elements of the LOCAL batch, both terms are 0 when every
-    mask is empty.  `capacity` bounds the number of edge pixels per call
-    without a host round trip (default: every pixel, B*H*W).
+    mask is empty.
+
+    Memory: one call holds 2 * capacity * k_s^2 * 4 bytes of SSG rows (+ the same again / 2 of
+    backward scratch) while it runs -- 0.5 GB per 100 k edge pixels at k_s = 25 -- and keeps only
+    the (B,C,H,W) gradient for backward.  `capacity` bounds the number of edge pixels of a call
+    without a host round trip.  Default: a quarter of the pixels (edge masks are ~7 % dense),
+    doubled automatically when a step turns out to have more: the edge count of every step is
+    copied to pinned host memory asynchronously and looked at one step later, so nothing stalls;
+    the step that overflowed used the first `capacity` edge pixels only and is reported with a
+    warning (on_overflow='grow', default) or a RuntimeError (on_overflow='raise').
     """
 
     def __init__(self, kernel_size_search=25, kernel_size_window=9, sigma=0.004, generalization=True,
                  loss_weight_l1=1e3, loss_weight_kl=1e3, mask_stride=0, eps=1e-10, lap_threshold=20.0,
-                 capacity=None):
+                 capacity=None, on_overflow='grow'):
         super().__init__()
+        if on_overflow not in ('grow', 'raise'):
+            raise ValueError(f"on_overflow must be 'grow' or 'raise', got {on_overflow!r}")
         self.ks, self.kw = kernel_size_search, kernel_size_window
         self.sigma, self.generalization, self.eps = sigma, generalization, eps
         self.w_l1, self.w_kl = loss_weight_l1, loss_weight_kl
         self.mask_stride, self.lap_threshold = mask_stride, lap_threshold
         self.capacity = capacity
+        self.on_overflow = on_overflow
+        self._pending = None       # (event, pinned count, capacity used) of the previous call
+
+    def _check_previous(self, wait=False):
+        """Look at the edge count of an earlier call if its copy has landed (never blocks unless wait)."""
+        if self._pending is None:
+            return
+        ev, host, cap = self._pending
+        if not (wait or ev.query()):
+            return
+        if wait:
+            ev.synchronize()
+        self._pending = None
+        n = int(host[0])
+        if n > cap:
+            msg = (f"SSGLoss: a step had {n} edge pixels but capacity {cap}; it used the first {cap} only. "
+                   f"capacity is now {max(2 * cap, n + n // 8)}.")
+            if self.capacity is None or self.capacity < n:
+                self.capacity = max(2 * cap, n + n // 8)
+            if self.on_overflow == 'raise':
+                raise RuntimeError(msg)
+            import warnings
+            warnings.warn(msg)
 
     def forward(self, sr, gt, mask=None):
         B, C, H, W = sr.shape
-        cap = self.capacity if self.capacity is not None else B * H * W
+        self._check_previous()
+        cap = self.capacity if self.capacity is not None else max(1024, (B * H * W) // 4)
+        cap = min(cap, B * H * W)
+        self.capacity = cap
         el = engine.edge_list(mask=mask, gt=gt if mask is None else None, mask_stride=self.mask_stride,
                               lap_threshold=self.lap_threshold, capacity=cap)
         self.last_counts = el.counts
+        if self._pending is None:      # one outstanding copy at a time
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(el.counts[:1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (ev, host, cap)
         return engine.ssg_loss(sr, gt.detach(), el.edges, el.counts, cap, self.ks, self.kw, self.sigma, self.eps,
                                self.generalization, self.w_l1, self.w_kl, order=el.order, fwd=el.fwd)
