@@ -79,7 +79,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters):
     p = engine._ptr
 
     def f_edges():
-        _lib.check(L.ssg_edge_list(p(mask), 0, 1, B, H, W, 0, 20.0, p(edges), step.capacity, p(step.counts),
+        _lib.check(L.ssg_edge_list(p(mask), 0, 1, B, H, W, 0, 20.0, KS, p(edges), step.capacity, p(step.counts),
                                    p(rank), p(order), p(plan), p(scratch), st))
 
     def f_fwd():

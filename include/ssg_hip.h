@@ -122,6 +122,7 @@ size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
 int ssg_set_dense_threshold(int edge_pixels_per_tile);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int H, int W, int mask_stride, float lap_threshold,
+                  int plan_ks /* k_s the fwd_plan is built for (tile rows: 8, or 4 for k_s = 49); 0 = 25 */,
                   int *edges, int capacity, int *counts,
                   int *rank_map /* nullable */, int *tile_order /* nullable */,
                   int *fwd_plan /* nullable */, void *scratch,

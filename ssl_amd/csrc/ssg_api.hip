@@ -19,7 +19,7 @@ const char *bwd_kernel_name(int ks, int kw);
 size_t edge_scratch_bytes(int B, int H, int W);
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
                      int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
-                     void *scratch, hipStream_t st);
+                     int plan_tile_rows, void *scratch, hipStream_t st);
 size_t fwd_plan_bytes(int B, int H, int W, int capacity);
 int fwd_plan_order_offset(int B, int H, int W);
 struct DenseParams {
@@ -38,7 +38,8 @@ struct DenseParams {
   int dbg;
 };
 bool dense_supported(int ks, int kw, int C);
-int dense_max_tiles(int B, int H, int W);
+int dense_max_tiles(int B, int H, int W, int ks);
+int dense_tile_rows(int ks);
 int launch_fwd_dense(const DenseParams &p, int ks, int kw, int C, hipStream_t st);
 int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride, uint8_t *out, hipStream_t st);
 bool grow_supported(int ks, int kw);
@@ -138,7 +139,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   d.rank = rank;
   d.n_dense = plan + 1;
   d.tiles = plan + 4;
-  d.max_tiles = dense_max_tiles(p.B, p.H, p.W);
+  d.max_tiles = dense_max_tiles(p.B, p.H, p.W, p.ks);
   d.n_dev = p.n_dev;
   d.n_host = p.n_host;
   d.B = p.B;
@@ -235,15 +236,16 @@ size_t ssg_edge_scratch_bytes(int B, int H, int W) { return edge_scratch_bytes(B
 size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity) { return fwd_plan_bytes(B, H, W, capacity); }
 
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
-                  float lap_threshold, int *edges, int capacity, int *counts, int *rank_map, int *tile_order,
-                  int *fwd_plan, void *scratch, ssg_stream_t stream) {
+                  float lap_threshold, int plan_ks, int *edges, int capacity, int *counts, int *rank_map,
+                  int *tile_order, int *fwd_plan, void *scratch, ssg_stream_t stream) {
   if (!mask || !edges || !counts || !scratch || B <= 0 || H <= 0 || W <= 0 || capacity < 0 || mask_kind < 0 ||
       mask_kind > 2 || mask_channels <= 0 || ((tile_order || fwd_plan) && !rank_map))
     return SSG_E_BADARG;
   // (the plan is always built when asked for -- with threshold 0 it lists no dense tile and every row in its
   // direct order -- so that the kernels consuming it never depend on the process-wide threshold)
   return launch_edge_list(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, edges, capacity,
-                          counts, rank_map, tile_order, fwd_plan, dense_threshold(), scratch, (hipStream_t)stream);
+                          counts, rank_map, tile_order, fwd_plan, dense_threshold(), dense_tile_rows(plan_ks), scratch,
+                          (hipStream_t)stream);
 }
 
 int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_threshold, int mask_stride,
@@ -293,7 +295,7 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
     d.rank = rank_map;
     d.n_dense = fwd_plan + 1;
     d.tiles = fwd_plan + 4;
-    d.max_tiles = dense_max_tiles(B, H, W);
+    d.max_tiles = dense_max_tiles(B, H, W, ks);
     d.n_dev = n_edges_dev;
     d.n_host = n_rows;
     d.B = B;
@@ -425,7 +427,7 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   ws += align_up(edge_scratch_bytes(B, H, W), 256);
   void *lscratch = ws;
   int rc = ssg_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
-                         W, mask_stride, lap_threshold, edges, capacity, counts, rank, order, plan, escratch, stream);
+                         W, mask_stride, lap_threshold, ks, edges, capacity, counts, rank, order, plan, escratch, stream);
   if (rc) return rc;
   rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
                        generalization, ssg_sr, ssg_gt, stream);

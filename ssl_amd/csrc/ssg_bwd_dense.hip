@@ -81,7 +81,7 @@ struct DenseBwdGeo {
 // whose tile needs another count leaves at once (every instantiation is launched over the same tile list), so
 // the offset loop is free of control flow.
 template <int KS, int KW, int C, int TY, int NCH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_bwd_dense(DenseBwdParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* <= 5 waves per CU fit the LDS anyway; 512 registers: no scratch */ void ssg_bwd_dense(DenseBwdParams p) {
   using G = DenseBwdGeo<KS, KW, C, TY>;
   constexpr int TX = G::TX, HP = G::HP, HK = G::HK, HALO = G::HALO, P = G::P;
   constexpr int UW = G::UW, NPX = G::NPX, NPXP = G::NPXP, RW = G::RW, RH = G::RH, RWS = G::RWS;
@@ -456,13 +456,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // ------------------------------------------------------------------ host ----
-bool dense_bwd_supported(int ks, int kw, int C) { return ks == 25 && kw == 9 && C == 3; }
+bool dense_bwd_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }
 
 template <int KS, int KW, int C, int TY, int NCH>
 static int launch_one(const DenseBwdParams &p, hipStream_t st) {
   using G = DenseBwdGeo<KS, KW, C, TY>;
-  (void)hipFuncSetAttribute((const void *)ssg_bwd_dense<KS, KW, C, TY, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)G::lds_bytes());
+  const hipError_t e = hipFuncSetAttribute((const void *)ssg_bwd_dense<KS, KW, C, TY, NCH>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes());
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH>), dim3((unsigned)p.max_tiles, (unsigned)p.qsplit), dim3(64),
                      G::lds_bytes(), st, p);
   return (int)hipGetLastError();
@@ -471,6 +472,7 @@ static int launch_one(const DenseBwdParams &p, hipStream_t st) {
 int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st) {
   if (!dense_bwd_supported(ks, kw, C)) return -1;
   if (p.max_tiles == 0) return 0;
+  if (ks == 49) return launch_one<49, 13, 3, 4, 2>(p, st);  // 4 x 32 tiles: at most 128 edge pixels
   int rc = launch_one<25, 9, 3, 8, 2>(p, st);
   if (!rc) rc = launch_one<25, 9, 3, 8, 4>(p, st);
   return rc;

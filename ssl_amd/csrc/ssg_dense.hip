@@ -45,11 +45,11 @@ struct DenseParams {
   int dbg;  // profiling ablations: bit0 no stores, bit1 no edge stage, bit3 no rescale, bit6 no main loop
 };
 
-constexpr int DT_Y = 8, DT_X = 32;  // centres per tile
+constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1) (8 for k_w = 9, 4 for k_w = 13)
 
 template <int KS, int KW, int C>
 __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
-  constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK;
+  constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK, DT_Y = 16 - 2 * HK;
   constexpr int RH = DT_Y + 2 * HALO, RWD = DT_X + 2 * HALO, RS = RWD + 1;  // image region
   constexpr int UH = DT_Y + 2 * HK, UW = DT_X + 2 * HK;                      // window halo U
   constexpr int LW = 8 + KW - 1;                                             // U columns per lane
@@ -63,8 +63,9 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   float *Hb = HF + UH * DT_X;              // [4][UH][DT_X] per-wave horizontal sums of E_q
   // per-wave partial row sums (fp64, see ssg_fwd.hip): wave w's NE_MAX doubles reuse ITS OWN H buffer once its
   // offset rows are done (same size, wave-private, so no other wave is still reading it)
-  double *rsum = (double *)Hb;                    // [4][NE_MAX]
-  static_assert(NE_MAX * sizeof(double) == UH * DT_X * sizeof(float), "row sums alias the wave's H buffer");
+  double *rsum = (double *)Hb;                    // [4][RSTR], RSTR = one H buffer in doubles
+  constexpr int RSTR = UH * DT_X / 2;
+  static_assert(NE_MAX <= RSTR, "row sums alias the wave's H buffer");
   int *elist = (int *)(Hb + 4 * UH * DT_X);       // [NE_MAX][3] (ey, ex, row)
   int *misc = elist + NE_MAX * 3;          // [8]: wave counts, n_e
 
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   {
     const int ey = tid / DT_X, ex = tid % DT_X;
     const int y = ty0 + ey, x = tx0 + ex;
-    int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+    int r = (ey < DT_Y && y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
     if (r >= nrows) r = -1;
     const unsigned long long bal = __ballot(r >= 0);
     if (lane == 0) misc[wv] = __popcll(bal);
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   // tiles that overhang a small image are never used, but must stay in bounds) ----
   {
     const float *src = p.img[which] + (size_t)b * C * H * W;
-    const int lx = tid % 16, lr = tid / 16;  // 16 lanes per row, 4 pixels each
+    constexpr int CPLF = (RWD + 15) / 16;    // 16 lanes per row, CPLF consecutive pixels each
+    const int lx = tid % 16, lr = tid / 16;
     for (int R0 = 0; R0 < C * RH; R0 += 16) {
       const int R = R0 + lr;
       if (R < C * RH) {
@@ -109,15 +111,16 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
         int gy = reflect_idx(ty0 - HALO + ry, H);
         gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
         const float *srow = src + ((size_t)c * H + gy) * W;
-        float v[4];
+        float v[CPLF];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          int gx = reflect_idx(tx0 - HALO + lx * 4 + k, W);
+        for (int k = 0; k < CPLF; ++k) {
+          int gx = reflect_idx(tx0 - HALO + lx * CPLF + k, W);
           gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
           v[k] = srow[gx];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) reg[(c * RH + ry) * RS + lx * 4 + k] = v[k];
+        for (int k = 0; k < CPLF; ++k)
+          if (lx * CPLF + k < RWD) reg[(c * RH + ry) * RS + lx * CPLF + k] = v[k];
       }
     }
   }
@@ -236,6 +239,17 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
         for (int i = 0; i < 13; ++i) p4[i] = p2[i] + p2[i + 2];
 #pragma unroll
         for (int j = 0; j < 8; ++j) Hs[j] = (p4[j] + p4[j + 4]) + E[j + 8];
+      } else if constexpr (xlo == -HK && xhi == HK && KW == 13) {
+        // full 13-tap windows: 13 = 8 + 4 + 1 from shared pair / quad / octet sums (53 additions instead of 96)
+        float p2[19], p4[17], p8[8];
+#pragma unroll
+        for (int i = 0; i < 19; ++i) p2[i] = E[i] + E[i + 1];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) p4[i] = p2[i] + p2[i + 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p8[j] = p4[j] + p4[j + 4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Hs[j] = (p8[j] + p4[j + 8]) + E[j + 12];
       } else
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   // ---- row sums over the four waves, then rescale the rows this workgroup wrote ----
 #pragma unroll
   for (int ck = 0; ck < NCHUNK; ++ck)
-    if (ck * 64 + lane < n_e) rsum[wv * NE_MAX + ck * 64 + lane] = rs[ck];
+    if (ck * 64 + lane < n_e) rsum[wv * RSTR + ck * 64 + lane] = rs[ck];
   __threadfence_block();
   __syncthreads();
   if (!p.generalization || (p.dbg & 8)) return;
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int e = wv; e < n_e; e += 4) {
-    const double tot = rsum[e] + rsum[NE_MAX + e] + rsum[2 * NE_MAX + e] + rsum[3 * NE_MAX + e];
+    const double tot = rsum[e] + rsum[RSTR + e] + rsum[2 * RSTR + e] + rsum[3 * RSTR + e];
     const double scale = 1.0 / (tot + (double)p.eps);
     float *o = outp + (size_t)elist[3 * e + 2] * P;
     constexpr int RPL = (P + 63) / 64;  // row elements per lane: all loads of the row in flight before the first store
@@ -324,27 +338,37 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
 // ------------------------------------------------------------------ host ----
 template <int KS, int KW, int C>
 static size_t dense_lds_bytes() {
+  constexpr int DT_Y = 16 - 2 * (KW / 2);
   constexpr int HALO = KS / 2 + KW / 2, RH = DT_Y + 2 * HALO, RS = DT_X + 2 * HALO + 1;
   constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X;
   return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_X + 4 * UH * DT_X) + sizeof(int) * (NE * 3 + 8);
 }
 
-bool dense_supported(int ks, int kw, int C) { return ks == 25 && kw == 9 && C == 3; }
+bool dense_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }
 
-int dense_max_tiles(int B, int H, int W) { return B * ((H + DT_Y - 1) / DT_Y) * ((W + DT_X - 1) / DT_X); }
+// rows of the dense kernels' tiles for a search size (the plan of ssg_edge_list is built for it)
+int dense_tile_rows(int ks) { return ks == 49 ? 4 : 8; }
+
+int dense_max_tiles(int B, int H, int W, int ks) {
+  const int ty = dense_tile_rows(ks);
+  return B * ((H + ty - 1) / ty) * ((W + DT_X - 1) / DT_X);
+}
+
+template <int KS, int KW, int C>
+static int launch_fwd_dense_t(const DenseParams &p, hipStream_t st) {
+  const size_t lds = dense_lds_bytes<KS, KW, C>();
+  // (set on every launch: the attribute is per device, and a launch is not where the time goes)
+  const hipError_t e = hipFuncSetAttribute((const void *)ssg_fwd_dense<KS, KW, C>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((ssg_fwd_dense<KS, KW, C>), dim3((unsigned)p.max_tiles * p.nimg), dim3(256), lds, st, p);
+  return (int)hipGetLastError();
+}
 
 int launch_fwd_dense(const DenseParams &p, int ks, int kw, int C, hipStream_t st) {
   if (!dense_supported(ks, kw, C)) return -1;
-  const size_t lds = dense_lds_bytes<25, 9, 3>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)ssg_fwd_dense<25, 9, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
   if (p.max_tiles == 0) return 0;
-  hipLaunchKernelGGL((ssg_fwd_dense<25, 9, 3>), dim3((unsigned)p.max_tiles * p.nimg), dim3(256), lds, st, p);
-  return (int)hipGetLastError();
+  return ks == 25 ? launch_fwd_dense_t<25, 9, 3>(p, st) : launch_fwd_dense_t<49, 13, 3>(p, st);
 }
 
 }  // namespace ssg

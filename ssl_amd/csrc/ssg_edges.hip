@@ -181,32 +181,47 @@ __device__ __forceinline__ int tile_rank(const int *rank, int B, int H, int W, i
   return (y < H && x < W) ? rank[((size_t)b * H + y) * W + x] : -1;
 }
 
-// super-tile (8 x 32 centres, the dense forward kernel's tile) that contains 8x8 tile `tile`
-__device__ __forceinline__ int super_tile_of(int tile, int H, int W) {
-  const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT, sx_n = (W + 31) / 32;
-  const int b = tile / (tx_n * ty_n), t = tile - b * tx_n * ty_n;
-  return (b * ty_n + t / tx_n) * sx_n + (t % tx_n) / 4;
+// super-tile (sty x 32 centres: the dense kernels' tile, sty = 8 for k_w = 9, 4 for k_w = 13) of pixel (b,y,x)
+__device__ __forceinline__ int super_tile_of(int b, int y, int x, int H, int W, int sty) {
+  const int sx_n = (W + 31) / 32, sy_n = (H + sty - 1) / sty;
+  return (b * sy_n + y / sty) * sx_n + x / 32;
 }
 
 
-// one lane per 8 x 32 super-tile (4 order tiles of a tile row): from the order tiles' counts, flag it dense at
-// >= thr edge pixels, append it to the dense list (plan[1] = count, zeroed by the caller) and zero the counts
-// of its tiles in place, so that the scan + scatter that follow build the order of the REMAINING rows
-__global__ __launch_bounds__(256) void plan_from_counts(int *tcnt, int B, int H, int W, int thr, int *dflag, int *plan,
-                                                        int *dense_ids) {
-  const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT, sx_n = (W + 31) / 32;
-  const int st = blockIdx.x * 256 + threadIdx.x;
-  if (st >= B * ty_n * sx_n) return;
-  const int row = st / sx_n, sx = st - row * sx_n;  // row = b * ty_n + tile row
-  const int t0 = row * tx_n + 4 * sx, nt = (4 * sx + 4 <= tx_n) ? 4 : tx_n - 4 * sx;
+// one wave per super-tile: count its edge pixels (rank map), flag it dense at >= thr and append it to the dense
+// list (plan[1] = count, zeroed by edge_scan)
+__global__ __launch_bounds__(256) void plan_count(const int *rank, int B, int H, int W, int sty, int thr, int *dflag,
+                                                  int *plan, int *dense_ids) {
+  const int sx_n = (W + 31) / 32, sy_n = (H + sty - 1) / sty;
+  const int st = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (st >= B * sy_n * sx_n) return;
+  const int b = st / (sy_n * sx_n), t = st - b * sy_n * sx_n;
+  const int y0 = (t / sx_n) * sty, x0 = (t % sx_n) * 32;
   int n = 0;
-  for (int k = 0; k < nt; ++k) n += tcnt[t0 + k];
-  const int dense = thr > 0 && n >= thr;
-  dflag[st] = dense;
-  if (dense) {
-    dense_ids[atomicAdd(&plan[1], 1)] = st;
-    for (int k = 0; k < nt; ++k) tcnt[t0 + k] = 0;
+  for (int i = lane; i < sty * 32; i += 64) {
+    const int y = y0 + i / 32, x = x0 + i % 32;
+    const bool on = y < H && x < W && rank[((size_t)b * H + y) * W + x] >= 0;
+    n += __popcll(__ballot(on));
   }
+  if (lane == 0) {
+    const int dense = thr > 0 && n >= thr;
+    dflag[st] = dense;
+    if (dense) dense_ids[atomicAdd(&plan[1], 1)] = st;
+    if (st == 0) plan[2] = sty;
+  }
+}
+
+// rows per 8x8 order tile that are NOT in a dense super-tile (one wave per order tile)
+__global__ __launch_bounds__(256) void tile_count_sparse(const int *rank, int B, int H, int W, int ntiles, int sty,
+                                                         const int *dflag, int *tcnt) {
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (tile >= ntiles) return;
+  const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT;
+  const int b = tile / (tx_n * ty_n), t = tile - b * tx_n * ty_n;
+  const int y = (t / tx_n) * OT + lane / OT, x = (t % tx_n) * OT + lane % OT;
+  const bool on = y < H && x < W && rank[((size_t)b * H + y) * W + x] >= 0 && !dflag[super_tile_of(b, y, x, H, W, sty)];
+  const unsigned long long bal = __ballot(on);
+  if (lane == 0) tcnt[tile] = __popcll(bal);
 }
 
 // exclusive scan of cnt[0..n) by one workgroup, 16 Ki entries per round: every lane keeps a run of 16
@@ -274,12 +289,16 @@ __global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int 
 }
 
 __global__ __launch_bounds__(256) void tile_scatter(const int *rank, int B, int H, int W, int ntiles, const int *off,
-                                                    int *order, int capacity, const int *skip) {
+                                                    int *order, int capacity, const int *skip, int sty) {
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (tile >= ntiles) return;
-  if (skip && skip[super_tile_of(tile, H, W)]) return;
   int nv;
-  const int r = tile_rank(rank, B, H, W, tile, lane, nv);
+  int r = tile_rank(rank, B, H, W, tile, lane, nv);
+  if (skip && r >= 0) {  // rows of dense super-tiles belong to the dense kernels
+    const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT;
+    const int b = tile / (tx_n * ty_n), t = tile - b * tx_n * ty_n;
+    if (skip[super_tile_of(b, (t / tx_n) * OT + lane / OT, (t % tx_n) * OT + lane % OT, H, W, sty)]) r = -1;
+  }
   const unsigned long long bal = __ballot(r >= 0);
   if (r >= 0) {
     const int pos = off[tile] + __popcll(bal & ((1ull << lane) - 1ull));
@@ -320,7 +339,8 @@ __global__ __launch_bounds__(256) void tile_group_flags(int *order_a, const int 
 
 // ------------------------------------------------------------------ host ----
 static size_t n_order_tiles(int B, int H, int W) { return (size_t)B * ((H + OT - 1) / OT) * ((W + OT - 1) / OT); }
-static size_t n_super_tiles(int B, int H, int W) { return (size_t)B * ((H + OT - 1) / OT) * ((W + 31) / 32); }
+// (sized for the smallest super-tile height, 4 rows)
+static size_t n_super_tiles(int B, int H, int W) { return (size_t)B * ((H + 3) / 4) * ((W + 31) / 32); }
 
 size_t edge_scratch_bytes(int B, int H, int W) {
   const size_t nblk = (size_t)B * (((size_t)H * W + CHUNK - 1) / CHUNK);
@@ -339,7 +359,7 @@ static void build_order(const int *rank, int B, int H, int W, int *order, int ca
                         const int *n_ptr, bool flags, int *tcnt, int *toff, hipStream_t st) {
   const int nt = (int)n_order_tiles(B, H, W);
   hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, nullptr);
-  hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity, nullptr);
+  hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order, capacity, nullptr, 8);
   const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
   if (flags && ngroups > 0)
     hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256, 1), dim3(256), 0, st, order, n_ptr, nullptr, nullptr,
@@ -348,7 +368,7 @@ static void build_order(const int *rank, int B, int H, int W, int *order, int ca
 
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
                      int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
-                     void *scratch, hipStream_t st) {
+                     int plan_tile_rows, void *scratch, hipStream_t st) {
   EdgeParams p{mask, kind, mask_channels, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
   const int nblk = B * p.nblk_img;
   const int nt = (int)n_order_tiles(B, H, W);
@@ -362,12 +382,15 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   // (with a forward plan the group flags of both orders are set by one launch at the end)
   if (order) build_order(rank, B, H, W, order, capacity, edges, counts, !plan, tcnt, toff, st);
   if (plan) {
-    const int ns = (int)n_super_tiles(B, H, W);
-    int *dflag = toff + nt, *order2 = plan + 4 + ns;
-    hipLaunchKernelGGL(plan_from_counts, dim3((ns + 255) / 256), dim3(256), 0, st, tcnt, B, H, W, dense_thr, dflag, plan,
+    const int sty = plan_tile_rows;
+    const int ns_max = (int)n_super_tiles(B, H, W), ns = B * ((H + sty - 1) / sty) * ((W + 31) / 32);
+    int *dflag = toff + nt, *order2 = plan + 4 + ns_max;
+    hipLaunchKernelGGL(plan_count, dim3((ns + 3) / 4), dim3(256), 0, st, rank, B, H, W, sty, dense_thr, dflag, plan,
                        plan + 4);
+    hipLaunchKernelGGL(tile_count_sparse, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, sty, dflag, tcnt);
     hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, plan);
-    hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order2, capacity, dflag);
+    hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order2, capacity, dflag,
+                       sty);
     const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
     if (ngroups > 0)
       hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256, order ? 2 : 1), dim3(256), 0, st, order2, plan, order,

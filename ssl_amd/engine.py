@@ -44,13 +44,14 @@ class EdgeList(tuple):
         return self
 
 
-def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=None):
+def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=None, ks=25):
     """Device-side edge list of a batch.
 
     mask: (B,c1,H,W) float32 or uint8 (channel 0 is used) -- or None with
     gt (B,3,H,W) float32 in [0,1] to generate the reference's Laplacian mask
     on the fly.  Returns (edges (capacity,3) int32 [b,y,x], counts (B+2) int32
-    on device: counts[0] = N).  No host synchronisation.
+    on device: counts[0] = N).  No host synchronisation.  `ks` is the search size the dense/direct
+    work split (`.plan`) is built for: pass the k_s the list will be used with.
     """
     L = _lib.lib()
     if mask is not None:
@@ -76,7 +77,7 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     plan = torch.empty(L.ssg_forward_plan_bytes(B, H, W, capacity) // 4, dtype=torch.int32, device=dev)
     scratch = torch.empty(L.ssg_edge_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):   # launches go to the tensors' GPU, whatever the current device is
-        _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold),
+        _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold), int(ks),
                                    _ptr(edges), capacity, _ptr(counts), _ptr(rank), _ptr(order), _ptr(plan),
                                    _ptr(scratch), _stream()))
     return EdgeList(edges, counts, rank, order, plan)

@@ -122,7 +122,7 @@ class SSGLoss(nn.Module):
         cap = min(cap, B * H * W)
         self.capacity = cap
         el = engine.edge_list(mask=mask, gt=gt if mask is None else None, mask_stride=self.mask_stride,
-                              lap_threshold=self.lap_threshold, capacity=cap)
+                              lap_threshold=self.lap_threshold, capacity=cap, ks=self.ks)
         self.last_counts = el.counts
         if self._pending is None:      # one outstanding copy at a time
             host = torch.empty(1, dtype=torch.int32, pin_memory=True)

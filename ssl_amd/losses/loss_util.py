@@ -48,20 +48,26 @@ class similarity_map():
         if img.shape[0] != 1:
             raise ValueError("similarity_map takes one image at a time (1,C,H,W); use ssl_amd.SSGLoss for batches")
         eps = getattr(self, "eps", 1e-10)
-        el = engine.edge_list(mask=mask, capacity=img.shape[-1] * img.shape[-2])
+        el = engine.edge_list(mask=mask, capacity=img.shape[-1] * img.shape[-2], ks=kernel_size_search)
         num = int(el.counts[0].item())    # the reference synchronises here too (torch.where / nonzero)
         s = engine.ssg_map(img, el.edges, el.counts, num, kernel_size_search, kernel_size_window, sigma, eps,
                            generalization, order=el.order, fwd=el.fwd)
         self.s = s.unsqueeze(0)           # 1, num, k_s*k_s
 
     def ssl_pytorch(self, img, mask, kernel_size_search=25, kernel_size_window=9, sigma=1.0, generalization=False):
+        # torch.where over a c1-channel mask (loss_util.py:195-198) lists the edge pixels of channel 0, then those
+        # of channel 1, ...: one block of rows per channel.  The pair pool produces channels that are copies of
+        # each other (realesrganssl_model.py:339-341), i.e. the same block c1 times; channels that differ get
+        # their own edge lists.
         _, c1, _, _ = mask.shape
-        self.ssl_hip(img, mask[:, :1], kernel_size_search, kernel_size_window, sigma, generalization)
-        if c1 > 1:
-            # torch.where over a c1-channel mask visits every edge pixel c1 times, channel-major
-            # (loss_util.py:195-198): valid when the channels are copies of each other, which is
-            # how the pair pool produces them (realesrganssl_model.py:339-341).
-            self.s = self.s.repeat(1, c1, 1)
+        blocks = []
+        for c in range(c1):
+            if c > 0 and torch.equal(mask[:, c], mask[:, 0]):
+                blocks.append(blocks[0])
+                continue
+            self.ssl_hip(img, mask[:, c:c + 1], kernel_size_search, kernel_size_window, sigma, generalization)
+            blocks.append(self.s)
+        self.s = blocks[0] if c1 == 1 else torch.cat(blocks, dim=1)
 
     def ssl_cuda(self, img, mask, kernel_size_search=25, kernel_size_window=9, sigma=1.0, generalization=False):
         b, c, h, w = img.shape
