@@ -39,7 +39,13 @@ PROTOTYPES = {
     "ssg_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,
                               _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssg_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
+    # include/similarity.h: the reference operator's own (void, stream-less) interface
+    "ssg_ref_compute_similarity": (None, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "ssg_ref_compute_similarity_backward": (None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "ssg_last_status": (_i, []),
 }
+# C++-linkage symbols of include/similarity.h (Itanium mangling of the reference's declarations, similarity.h:2-23)
+CXX_SYMBOLS = ("_Z19_compute_similarityPKfPKiPfiiiiii", "_Z28_compute_similarity_backwardPKfS0_PKiPfiiiiii")
 
 
 def build(force=False, verbose=False):
@@ -75,6 +81,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is absent: loud by design
             fn.restype = res
             fn.argtypes = args
+        for name in CXX_SYMBOLS:
+            getattr(L, name)
         _lib = L
     return _lib
 

@@ -371,6 +371,79 @@ def f8_dm_strategies():
     save("f8_dm_strategies", **out)
 
 
+def f9_c4_dm_loop():
+    """F9 (BASELINE configs[3]-shaped, C4): the Diffusion fork's own caller loop (ddpmssl.py:438-513 `issl`) with
+    its configured options (configs/StableSRISSLStage1/*.yml:32-41,268-277): mask_stride 3 (eye pattern built
+    as in ddpmssl.py:47-56), simself_strategy areaarea_mask_nonlocalavg_cuda_v1 (eps 1e-20, DM loss_util.py:
+    1239-1252), kernel_size 25, kernel_size_center 9, scaling_factor 0.004, softmax True, L1 + KL weights 5e2 --
+    on a 2x3x128x128 crop pair (one image's mask emptied by the stride pattern is NOT forced; both are used).
+    The loop below follows `issl` statement by statement; `similarity_map` is the fork's class, its
+    `compute_similarity` backed by the fp64 oracle distance (see load_reference_dm)."""
+    import math
+    dm = load_reference_dm()
+    ks, kc, sigma, stride, w = 25, 9, 0.004, 3, 5e2
+    H = W = 128
+    gt = np.stack([synth.natural_like(900 + i, H, W) for i in range(2)])
+    sr = np.stack([synth.degrade(gt[i], 950 + i) for i in range(2)])
+    mask = np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(2)])[:, None].astype(np.float32)
+    eye = torch.eye(stride, stride, dtype=torch.float32).repeat(math.ceil(H / stride), math.ceil(W / stride))
+    eye = eye[:H, :W].unsqueeze(0).unsqueeze(0)
+    out = dict(sr=sr, gt=gt, mask=mask.astype(np.uint8), ks=ks, kc=kc, sigma=sigma, stride=stride, w=w)
+    for dt, dn in ((torch.float64, "f64"),):
+        S = torch.as_tensor(sr, dtype=dt).clone().requires_grad_(True)
+        G = torch.as_tensor(gt, dtype=dt)
+        M = torch.as_tensor(mask, dtype=dt)
+        b_sr_list, b_gt_list, n_per = [], [], []
+        for i in range(2):
+            b_mask_gt = M[i, :].unsqueeze(0)
+            b_mask_gt = eye.to(dt) * b_mask_gt
+            if b_mask_gt.sum() == 0:
+                continue
+            kw = dict(simself_strategy="areaarea_mask_nonlocalavg_cuda_v1", dh=64, dw=64, kernel_size=ks,
+                      scaling_factor=sigma, temperature=0, crossentropy=False, rearrange_back=True, stride=1,
+                      pix_num=1, index=None, kernel_size_center=kc, mean=False, var=False, gene_type="sum",
+                      largest_k=0)
+            a = dm.similarity_map(img=S[i, :].unsqueeze(0).clone(), mask=b_mask_gt.clone(), softmax=True, **kw).getitem()
+            with torch.no_grad():
+                b = dm.similarity_map(img=G[i, :].unsqueeze(0).clone(), mask=b_mask_gt.clone(), softmax=True, **kw).getitem()
+            b_sr_list.append(a)
+            b_gt_list.append(b)
+            n_per.append(a.shape[1])
+        A = torch.cat(b_sr_list, dim=1)
+        Bm = torch.cat(b_gt_list, dim=1)
+        l1 = l1_loss(A, Bm, w)
+        kl = kl_loss(A, Bm, w)
+        (l1 + kl).backward()
+        n = A.shape[1]
+        sel = np.unique(np.concatenate([[0, n - 1], np.random.default_rng(19).choice(n, 30, replace=False)]))
+        out.update(rows=sel, n_edges=n, n_per_image=np.array(n_per), l1=l1.detach().numpy(), kl=kl.detach().numpy(),
+                   ssg_sr=A.detach().numpy()[0][sel].astype(np.float32),
+                   ssg_gt=Bm.detach().numpy()[0][sel].astype(np.float32),
+                   grad=S.grad.numpy().astype(np.float32))
+        print(f"  f9: N={n} per image {n_per} l1={float(l1):.6g} kl={float(kl):.6g}")
+    save("f9_c4_dm_loop", **out)
+
+
+def f10_paper_cotangent():
+    """F10: d sum(SSG * cot)/d img at the paper's kernel sizes (k_s 25, k_w 9) under a fixed smooth cotangent,
+    sigma in {1.0, 0.004}, from the reference's ssl_pytorch in fp64 -- one 3x96x96 natural-like image whose
+    Laplacian mask touches the image border (reflect fold)."""
+    ks, kw = 25, 9
+    H = W = 96
+    img = synth.natural_like(1000, H, W)[None]
+    mask = synth.laplacian_edge_mask(img[0])
+    mask[0, 0] = mask[0, W - 1] = mask[H - 1, 0] = mask[H - 1, W - 1] = mask[0, 40] = mask[50, 0] = 1
+    n = int(mask.sum())
+    cot = smooth_cotangent((1, n, ks * ks), 23).astype(np.float32)
+    out = dict(img=img, mask=mask.astype(np.uint8), ks=ks, kw=kw, cot_seed=23, n_edges=n)   # cot = smooth_cotangent((1,n,ks*ks), 23) as float32
+    for sigma in (1.0, 0.004):
+        t, s = ref_ssg(img, mask[None, None], ks, kw, sigma, True, torch.float64, True)
+        (s * torch.as_tensor(cot, dtype=torch.float64)).sum().backward()
+        out[f"dimg_s{sigma}"] = t.grad.numpy()[0].astype(np.float32)
+        print(f"  f10: N={n} sigma={sigma} max|dimg|={np.abs(out[f'dimg_s{sigma}']).max():.4g}")
+    save("f10_paper_cotangent", **out)
+
+
 def cpu_reference_timing():
     """time the reference ssl_pytorch loss step on this
     container's cores (one 3x256x256 image of the C2 batch, like the reference's
@@ -398,7 +471,7 @@ def cpu_reference_timing():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8"]
+    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10"]
     torch.manual_seed(0)
     if "f1" in which:
         f1_c1()
@@ -416,5 +489,9 @@ if __name__ == "__main__":
         f7_mask_pil()
     if "f8" in which:
         f8_dm_strategies()
+    if "f9" in which:
+        f9_c4_dm_loop()
+    if "f10" in which:
+        f10_paper_cotangent()
     if "time" in which:
         cpu_reference_timing()

@@ -18,13 +18,25 @@ def test_library_builds_loads_and_exports_header_symbols():
     from ssl_amd import _lib
     _lib.build()
     assert os.path.exists(_lib.SO_PATH)
-    hdr = open(_lib.HEADER).read()
+    inc = os.path.dirname(_lib.HEADER)
+    hdr = open(_lib.HEADER).read() + open(os.path.join(inc, "similarity.h")).read()
     declared = set(re.findall(r"\b(ssg_[a-z_0-9]+)\s*\(", hdr))
     declared -= {"ssg_stream_t"}
-    assert len(declared) >= 14
+    assert len(declared) >= 18
     L = ctypes.CDLL(_lib.SO_PATH)
     for name in sorted(declared):
-        assert hasattr(L, name), f"{name} declared in include/ssg_hip.h but not exported"
+        assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
+    # the reference's own two functions (similarity.h:2-23, C++ linkage): declared in include/similarity.h,
+    # exported under the Itanium-mangled names the reference's similaritywrapper.cpp links against
+    ref_hdr = open(os.path.join(inc, "similarity.h")).read()
+    assert re.search(r"void _compute_similarity\(const float \*image, const int \*pos, float \*out,", ref_hdr)
+    assert re.search(r"void _compute_similarity_backward\(const float \*image, const float \*grads, const int \*pos,", ref_hdr)
+    for name in _lib.CXX_SYMBOLS:
+        assert hasattr(L, name), f"{name} not exported"
+    demangled = subprocess.run(["c++filt"] + list(_lib.CXX_SYMBOLS), stdout=subprocess.PIPE, text=True).stdout.split("\n")
+    assert demangled[0] == "_compute_similarity(float const*, int const*, float*, int, int, int, int, int, int)"
+    assert demangled[1] == ("_compute_similarity_backward(float const*, float const*, int const*, float*, int, int, int, "
+                            "int, int, int)")
     # every prototype the Python binding uses is declared in the header
     assert set(_lib.PROTOTYPES) <= declared
     lib = _lib.lib()

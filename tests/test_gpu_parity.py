@@ -768,3 +768,200 @@ print("dense ok")
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=600)
     assert out.returncode == 0 and "dense ok" in out.stdout, out.stdout[-3000:]
+
+
+# ------------------------------------------------------------------ round 2
+def test_f9_c4_dm_loop_golden_and_full_size(dev, golden):
+    """C4 (LDM-SR step): the Diffusion fork's own loop semantics -- mask_stride 3, eps 1e-20, sigma 0.004, weights 5e2
+    -- (a) against fixture F9 captured from the fork's similarity_map + issl loop, 2x3x128x128; (b) at the
+    config's full crop size 2x3x512x512 against the fp64 oracle's losses, gradient and 32 rows."""
+    from ssl_amd import SSGLoss, engine, synth
+    g = golden("f9_c4_dm_loop")
+    ks, kc, sigma, stride, w = int(g["ks"]), int(g["kc"]), float(g["sigma"]), int(g["stride"]), float(g["w"])
+    sr, gt, mask = g["sr"], g["gt"], g["mask"].astype(np.float32)
+    step = engine.LossStep(2, 3, 128, 128, ks, kc, sigma, 1e-20, True, w, w, mask_stride=stride, device=dev)
+    loss, grad = step(T(sr, dev), T(gt, dev), T(mask, dev))
+    n = int(step.counts[0])
+    assert n == int(g["n_edges"])
+    l = loss.cpu().numpy()
+    assert abs(l[0] - float(g["l1"])) <= 1e-5 * float(g["l1"]) and abs(l[1] - float(g["kl"])) <= 1e-5 * float(g["kl"])
+    rows = torch.as_tensor(g["rows"], device=dev)
+    assert maxerr(step.ssg_sr[rows].cpu(), g["ssg_sr"]) <= 1e-5 and maxerr(step.ssg_gt[rows].cpu(), g["ssg_gt"]) <= 1e-5
+    masks_s = np.stack([orc.mask_stride(g["mask"][i, 0], stride) for i in range(2)])
+    ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), masks_s, ks, kc, sigma, w, w, eps=1e-20)
+    gref, nflip = ref_grad_with_gpu_signs(sr, masks_s, ks, kc, sigma, ref, step.ssg_sr[:n].cpu().numpy(),
+                                          step.ssg_gt[:n].cpu().numpy(), w_l1=w)
+    # (grad_tol_from_oracle evaluates with weights 1e3; the gradient is linear in the weights)
+    assert maxerr(grad.cpu(), gref) <= grad_tol_from_oracle(sr, gt, masks_s, ks, kc, sigma, ref) * (w / 1e3)
+    if nflip == 0:
+        assert maxerr(grad.cpu(), g["grad"]) <= grad_tol_from_oracle(sr, gt, masks_s, ks, kc, sigma, ref) * (w / 1e3)
+    # the drop-in module (the DM fork's configuration: eps 1e-20, stride 3) gives the same numbers through autograd
+    x = T(sr, dev).clone().requires_grad_(True)
+    a, b = SSGLoss(ks, kc, sigma, True, w, w, mask_stride=stride, eps=1e-20)(x, T(gt, dev), T(mask, dev))
+    (a + b).backward()
+    assert abs(float(a) - l[0]) <= 1e-6 * l[0] and abs(float(b) - l[1]) <= 1e-6 * l[1]
+    assert float((x.grad - grad).abs().max()) <= 2e-6 * float(grad.abs().max())
+
+    # (b) full crop size of the config
+    B, H, W = 2, 512, 512
+    gtf = np.stack([synth.natural_like(2000 + i, H, W) for i in range(B)])
+    srf = np.stack([synth.degrade(gtf[i], 2100 + i) for i in range(B)])
+    mf = np.stack([synth.laplacian_edge_mask(gtf[i]) for i in range(B)]).astype(np.float32)[:, None]
+    ms = np.stack([orc.mask_stride(mf[i, 0], stride) for i in range(B)])
+    step = engine.LossStep(B, 3, H, W, ks, kc, sigma, 1e-20, True, w, w, mask_stride=stride, device=dev)
+    loss, grad = step(T(srf, dev), T(gtf, dev), T(mf, dev))
+    n = int(step.counts[0])
+    ref = orc.ssg_loss(srf.astype(np.float64), gtf.astype(np.float64), ms, ks, kc, sigma, w, w, eps=1e-20)
+    assert n == ref["n_edges"] == int(ms.sum())
+    l = loss.cpu().numpy()
+    assert abs(l[0] - ref["l1"]) <= 1e-5 * ref["l1"] and abs(l[1] - ref["kl"]) <= 1e-5 * ref["kl"]
+    s_sr = step.ssg_sr[:n]
+    assert float((s_sr.sum(1) - 1).abs().max()) < 1e-5 and bool((s_sr.argmax(1) == (ks * ks) // 2).all())
+    sel = np.random.default_rng(4).choice(n, 32, replace=False)
+    assert maxerr(s_sr[torch.as_tensor(sel, device=dev)].cpu(), ref["s_sr"][sel]) <= 1e-5
+    gref, _ = ref_grad_with_gpu_signs(srf, ms, ks, kc, sigma, ref, s_sr.cpu().numpy(), step.ssg_gt[:n].cpu().numpy(), w_l1=w)
+    r32 = orc.ssg_loss(srf.astype(np.float32), gtf.astype(np.float32), ms, ks, kc, sigma, w, w, eps=1e-20)
+    mx = np.abs(ref["grad"]).max()
+    tol = max(1e-5, 4.0 * np.abs(r32["grad"].astype(np.float64) - ref["grad"]).max() / mx) * mx
+    assert maxerr(grad.cpu(), gref) <= tol
+
+
+@pytest.mark.parametrize("sigma", [1.0, 0.004])
+@pytest.mark.parametrize("thr", [0, 1, 28])
+def test_f10_smooth_cotangent_vjp_paper_sizes(dev, golden, sigma, thr):
+    """dSSG/dimg at (25, 9) under a smooth cotangent vs the reference's fp64 autograd (fixture F10): <= 1e-5 max|grad|
+    through the tile-major direct backward (threshold 0), the dense-tile backward for every tile (1) and the
+    production split (28)."""
+    from ssl_amd import engine
+    g = golden("f10_paper_cotangent")
+    ks, kw, n = int(g["ks"]), int(g["kw"]), int(g["n_edges"])
+    cot = np.random.default_rng(int(g["cot_seed"])).standard_normal((1, n, ks * ks)).astype(np.float32)[0]
+    prev = engine.set_dense_threshold(thr)
+    try:
+        x = T(g["img"], dev).clone().requires_grad_(True)
+        el = engine.edge_list(mask=T(g["mask"][None, None].astype(np.float32), dev), ks=ks)
+        assert int(el.counts[0]) == n
+        s = engine.ssg_map(x, el.edges, el.counts, n, ks, kw, sigma, order=el.order, fwd=el.fwd)
+        (s * T(cot, dev)).sum().backward()
+        ref = g[f"dimg_s{sigma}"]
+        assert maxerr(x.grad[0].cpu(), ref) <= 1e-5 * np.abs(ref).max()
+    finally:
+        engine.set_dense_threshold(prev)
+
+
+def test_c5_full_size_dense_mask(dev):
+    """BASELINE configs[4] at full size: 1x3x512x512, k_s 49, k_w 13, every pixel an edge pixel (N = 262,144).
+    Size-independent properties + 32 rows and the losses of a 64-row strip against the fp64 oracle."""
+    from ssl_amd import engine, synth
+    ks, kw, P, H, W = 49, 13, 49 * 49, 512, 512
+    gt = synth.natural_like(300, H, W)[None]
+    sr = synth.degrade(gt[0], 7)[None]
+    step = engine.LossStep(1, 3, H, W, ks, kw, 1.0, 1e-10, True, 1e3, 1e3, device=dev)
+    loss, grad = step(T(sr, dev), T(gt, dev), torch.ones((1, 1, H, W), device=dev))
+    n = int(step.counts[0])
+    assert n == H * W
+    s_sr, s_gt = step.ssg_sr[:n], step.ssg_gt[:n]
+    assert float((s_sr.sum(1) - 1).abs().max()) < 1e-5 and float((s_gt.sum(1) - 1).abs().max()) < 1e-5
+    assert bool((s_sr.argmax(1) == P // 2).all()) and bool(torch.isfinite(grad).all())
+    l1 = 1e3 * (s_sr - s_gt).abs().double().mean()
+    kl = 1e3 * torch.nn.functional.kl_div(s_sr.clamp(min=1e-10).double().log(), s_gt.clamp(min=1e-10).double(),
+                                          reduction="mean")
+    assert abs(float(loss[0]) - float(l1)) <= 1e-5 * float(l1) and abs(float(loss[1]) - float(kl)) <= 1e-5 * float(kl) + 2e-8
+    sel = np.unique(np.concatenate([[0, W - 1, (H - 1) * W, H * W - 1], np.random.default_rng(2).choice(n, 28, replace=False)]))
+    pos = np.stack([sel // W, sel % W], 1).astype(np.int32)
+    for img, s in ((sr, s_sr), (gt, s_gt)):
+        ref = orc.ssg_epilogue(orc.distance(img[0].astype(np.float64), pos, ks, kw), kw, 3, 1.0, True)
+        assert maxerr(s[torch.as_tensor(sel, device=dev)].cpu(), ref) <= 1e-5
+    # direct kernels (threshold 0) agree with the dense-tile kernels on the same input
+    prev = engine.set_dense_threshold(0)
+    try:
+        step0 = engine.LossStep(1, 3, H, W, ks, kw, 1.0, 1e-10, True, 1e3, 1e3, device=dev)
+        loss0, grad0 = step0(T(sr, dev), T(gt, dev), torch.ones((1, 1, H, W), device=dev))
+        assert abs(float(loss0[0]) - float(loss[0])) <= 1e-5 * float(loss[0])
+        assert float((step0.ssg_sr[:n] - s_sr).abs().max()) <= 1e-6
+        assert float((grad0 - grad).abs().max()) <= 1e-3 * float(grad.abs().max())
+    finally:
+        engine.set_dense_threshold(prev)
+
+
+def test_reference_exact_operator_interface(dev):
+    """include/similarity.h: the reference's own void, stream-less functions (similarity.h:2-23), through the
+    extern "C" aliases and through the C++-mangled symbols the reference's similaritywrapper.cpp links against."""
+    import ctypes
+    from ssl_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(12)
+    C, H, W, ks, kw = 3, 30, 37, 11, 5
+    hp = ks // 2
+    img = rng.random((C, H, W), dtype=np.float32)
+    m = rng.random((H, W)) < 0.1
+    pad = np.pad(img, ((0, 0), (hp, hp), (hp, hp)), mode="reflect")
+    pos = (orc.mask_to_pos(m.astype(np.uint8)) + hp).astype(np.int32)
+    n = len(pos)
+    Dref = orc.compute_similarity_padded(pad.astype(np.float64), pos, ks, kw)
+    gD = rng.standard_normal((n, ks, ks)).astype(np.float32)
+    gref = orc.compute_similarity_backward_padded(pad.astype(np.float64), gD.astype(np.float64), pos, ks, kw)
+    tp, tpos, tg = T(pad, dev), torch.as_tensor(pos, device=dev), T(gD, dev)
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    fwd_cxx, bwd_cxx = (getattr(L, s) for s in _lib.CXX_SYMBOLS)
+    fwd_cxx.restype = bwd_cxx.restype = None
+    fwd_cxx.argtypes = [vp, vp, vp, i, i, i, i, i, i]
+    bwd_cxx.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i]
+    for fwd, bwd in ((L.ssg_ref_compute_similarity, L.ssg_ref_compute_similarity_backward), (fwd_cxx, bwd_cxx)):
+        out = torch.zeros((n, ks, ks), device=dev)
+        gi = torch.zeros_like(tp)
+        torch.cuda.synchronize()          # these entry points use the legacy default stream, like the reference
+        fwd(tp.data_ptr(), tpos.data_ptr(), out.data_ptr(), n, ks, kw, H + 2 * hp, W + 2 * hp, C)
+        assert L.ssg_last_status() == 0
+        bwd(tp.data_ptr(), tg.data_ptr(), tpos.data_ptr(), gi.data_ptr(), n, ks, kw, H + 2 * hp, W + 2 * hp, C)
+        assert L.ssg_last_status() == 0
+        torch.cuda.synchronize()
+        assert maxerr(out.cpu(), Dref) <= 2e-6 * np.abs(Dref).max()
+        assert maxerr(gi.cpu(), gref) <= 1e-5 * np.abs(gref).max()
+    fwd_cxx(tp.data_ptr(), tpos.data_ptr(), out.data_ptr(), n, 4, kw, H, W, C)     # even size: status, no launch
+    assert L.ssg_last_status() == -1
+
+
+def test_ssl_pytorch_mode_with_differing_mask_channels(dev):
+    """torch.where over a 3-channel mask lists channel 0's edge pixels, then channel 1's, ... (loss_util.py:195-198);
+    with channels that differ each block has its own rows."""
+    from ssl_amd import similarity_map
+    rng = np.random.default_rng(31)
+    img = rng.random((1, 3, 28, 33), dtype=np.float32)
+    m3 = (rng.random((1, 3, 28, 33)) < 0.08).astype(np.float32)
+    s = similarity_map(T(img, dev), T(m3, dev), ssl_mode="pytorch", kernel_size_search=7, kernel_size_window=3,
+                       sigma=0.5, generalization=True).getitem()
+    blocks = [orc.ssg_map(img[0].astype(np.float64), m3[0, c], 7, 3, 0.5, True) for c in range(3)]
+    ref = np.concatenate(blocks, 0)
+    assert s.shape == (1, ref.shape[0], 49)
+    assert maxerr(s[0].cpu(), ref) <= 1e-5
+
+
+def test_ssgloss_capacity_growth_and_uint8_semantics(dev):
+    """SSGLoss: an under-sized capacity is detected one step later without a host stall and grown; a uint8 mask means
+    `== 1` like the reference's `mask == 1` (a 0/255 mask selects nothing)."""
+    import warnings
+    from ssl_amd import SSGLoss, engine
+    rng = np.random.default_rng(5)
+    sr, gt = rng.random((1, 3, 40, 40), dtype=np.float32), rng.random((1, 3, 40, 40), dtype=np.float32)
+    m = (rng.random((1, 1, 40, 40)) < 0.5).astype(np.float32)
+    crit = SSGLoss(7, 3, 0.5, True, 1.0, 1.0, capacity=100)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        crit(T(sr, dev), T(gt, dev), T(m, dev))
+        torch.cuda.synchronize()
+        a, b = crit(T(sr, dev), T(gt, dev), T(m, dev))      # looks at the first call's count
+    assert any("capacity" in str(w.message) for w in wlist) and crit.capacity >= int(m.sum())
+    crit._check_previous(wait=True)
+    a, b = crit(T(sr, dev), T(gt, dev), T(m, dev))
+    ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), m[:, 0], 7, 3, 0.5, 1.0, 1.0)
+    assert abs(float(a) - ref["l1"]) <= 1e-5 * ref["l1"] and abs(float(b) - ref["kl"]) <= 1e-5 * ref["kl"] + 1e-9
+    with pytest.raises(RuntimeError):
+        strict = SSGLoss(7, 3, 0.5, capacity=50, on_overflow="raise")
+        strict(T(sr, dev), T(gt, dev), T(m, dev))
+        torch.cuda.synchronize()
+        strict(T(sr, dev), T(gt, dev), T(m, dev))
+    u8 = torch.as_tensor((m * 255).astype(np.uint8), device=dev)
+    assert int(engine.edge_list(mask=u8).counts[0]) == 0
+    assert int(engine.edge_list(mask=(u8 // 255)).counts[0]) == int(m.sum())
+    assert int(engine.edge_list(mask=u8 > 0).counts[0]) == int(m.sum())

@@ -185,3 +185,33 @@ def test_backward_matches_finite_differences():
         b = img.copy(); b[i] -= h
         num[i] = (f(a) - f(b)) / (2 * h)
     assert np.abs(num - g).max() < 1e-7
+
+
+def test_f9_c4_dm_caller_loop(golden):
+    """C4-shaped: the Diffusion fork's loop (mask_stride 3, eps 1e-20, w 5e2) vs the oracle's batch loss."""
+    g = golden("f9_c4_dm_loop")
+    ks, kc, sigma, stride, w = int(g["ks"]), int(g["kc"]), float(g["sigma"]), int(g["stride"]), float(g["w"])
+    masks = np.stack([orc.mask_stride(g["mask"][i, 0], stride) for i in range(2)])
+    assert [int(m.sum()) for m in masks] == list(g["n_per_image"])
+    r = orc.ssg_loss(g["sr"].astype(np.float64), g["gt"].astype(np.float64), masks, ks, kc, sigma, w, w, eps=1e-20)
+    assert r["n_edges"] == int(g["n_edges"])
+    assert abs(r["l1"] - float(g["l1"])) <= 1e-9 * abs(float(g["l1"]))
+    assert abs(r["kl"] - float(g["kl"])) <= 1e-7 * abs(float(g["kl"]))
+    _close(r["s_sr"][g["rows"]], g["ssg_sr"], 2e-7)
+    _close(r["s_gt"][g["rows"]], g["ssg_gt"], 2e-7)
+    _close(r["grad"], g["grad"], 2e-7 * np.abs(g["grad"]).max())
+
+
+@pytest.mark.parametrize("sigma", [1.0, 0.004])
+def test_f10_paper_sizes_vjp(golden, sigma):
+    """d sum(SSG * cot)/d img at (25, 9) with border edge pixels: the oracle's analytic backward + reflect fold."""
+    g = golden("f10_paper_cotangent")
+    ks, kw, n = int(g["ks"]), int(g["kw"]), int(g["n_edges"])
+    cot = np.random.default_rng(int(g["cot_seed"])).standard_normal((1, n, ks * ks)).astype(np.float32)[0]
+    img = g["img"][0].astype(np.float64)
+    pos = orc.mask_to_pos(g["mask"])
+    assert pos.shape[0] == n
+    S = orc.ssg_epilogue(orc.distance(img, pos, ks, kw), kw, 3, sigma, True)
+    gI = orc.distance_backward(img, pos, ks, kw, orc.ssg_epilogue_backward(S, cot.astype(np.float64), ks, kw, 3, sigma, True))
+    ref = g[f"dimg_s{sigma}"]
+    _close(gI, ref, 2e-7 * np.abs(ref).max())
