@@ -1,59 +1,100 @@
 #!/usr/bin/env python
 """bench.py -- SSG-loss edge-pixels/sec (fwd+bwd) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c5] [--scaling weak|strong]
 
-Workload = BASELINE.json configs[1]: a batch of 16 synthetic 3x256x256 crops PER GPU
-(weak scaling; image i of rank r uses seed 100 + 16 r + i), Laplacian edge mask (~7.5 %),
-k_s = 25, k_w = 9, sigma = 1.0, generalization, L1 + KL (weights 1e3).  One step = the whole
-loss step through the C ABI (ssg_loss_fwd_bwd): edge list from the fp32 mask, SSG(sr), SSG(gt)
-materialised once each, both criteria and d(l1+kl)/d sr.  Inputs are resident in HBM.
-Unit of work: one edge pixel through that step.
+N > 1: either launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env), or plain `python bench.py --gpus N`, which spawns the
+N ranks itself (one process per GPU, 127.0.0.1 rendezvous, RCCL through torch.distributed's "nccl" backend).
+
+Workload (config c2, default) = BASELINE.json configs[1]: a batch of 16 synthetic 3x256x256 crops PER GPU (weak
+scaling; image i of rank r uses seed 100 + 16 r + i) -- or the 16 images split N-ways (--scaling strong, SURVEY
+8e) -- Laplacian edge mask (~7.5 %), k_s = 25, k_w = 9, sigma = 1.0, generalization, L1 + KL (weights 1e3).
+One step = the whole loss step through the C ABI (ssg_loss_fwd_bwd): edge list from the fp32 mask, SSG(sr),
+SSG(gt) materialised once each, both criteria and d(l1+kl)/d sr.  Inputs are resident in HBM.  Unit of work: one
+edge pixel through that step.  Config c5 = BASELINE configs[4]: 1x3x512x512, dense mask,
+k_s = 49, k_w = 13 (one image per GPU).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
-  roofline      for the dominant kernel: algorithmic HBM bytes of the step (5,500 B per edge
-                pixel at this config, SURVEY 8d: 8 k_s^2 + (12C+4) HW/N) x edge pixels per
-                launch / that kernel's mean launch time measured with HIP events on the launch
-                stream; `step` repeats it over the whole step's GPU time; `valu` prices the
-                same time against the fp32 vector peak (the path is VALU-bound).
-  cpu_baseline  the C/OpenMP oracle ("port") on the host cores over a bounded sample of the
-                same workload (rank 0, N = 1 only).
+  roofline      for the dominant kernel: algorithmic HBM bytes of the step (8 k_s^2 + (12C+4) HW/N per
+                edge pixel) x edge pixels per launch / that kernel's mean duration, measured here with HIP events
+                on the launch stream while the step's other launches are masked out (ssg_set_profile_mask);
+                `kernel_ms` lists every kernel of the step measured that way, `step` repeats the figure over the
+                whole step's GPU time, `valu` prices the same time against the fp32 vector peak.
+  module        the same step through the drop-in nn.Module (ssl_amd.SSGLoss: autograd forward + backward).
+  cpu_baseline  the C/OpenMP oracle ("port") on the host cores over a bounded sample of the same workload
+                (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-KS, KW, SIGMA, EPS = 25, 9, 1.0, 1e-10
+CONFIGS = {
+    "c2": dict(ks=25, kw=9, sigma=1.0, batch=16, H=256, W=256, dense_mask=False,
+               name="C2: batch 16 x 3x256x256 per GPU, Laplacian mask, k_s=25 k_w=9 sigma=1.0, L1+KL w=1e3, SSGs materialised"),
+    "c5": dict(ks=49, kw=13, sigma=1.0, batch=1, H=512, W=512, dense_mask=True,
+               name="C5: 1 x 3x512x512 per GPU, dense (100 %) mask, k_s=49 k_w=13 sigma=1.0, L1+KL w=1e3, SSGs materialised"),
+}
+EPS, C = 1e-10, 3
 W_L1 = W_KL = 1e3
-BATCH, C, H, W = 16, 3, 256, 256
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
 
-def alg_bytes_per_edge_px(n_edges, batch):
+def alg_bytes_per_edge_px(cfg, n_edges, batch):
     """read SR+GT (2*C*H*W*4) + fp32 mask (H*W*4) + write both SSGs
     (2*N*k_s^2*4) + write dL/dsr (C*H*W*4), per image; per edge pixel = 8 k_s^2 + (12C+4) HW/N."""
-    return 8.0 * KS * KS + (12.0 * C + 4.0) * H * W * batch / max(n_edges, 1)
+    return 8.0 * cfg["ks"] ** 2 + (12.0 * C + 4.0) * cfg["H"] * cfg["W"] * batch / max(n_edges, 1)
 
 
-def alg_flops_per_edge_px():
+def alg_flops_per_edge_px(cfg):
     """3*C*k_w^2*k_s^2 per SSG pass, ~4 pass-equivalents per loss step."""
-    return 4.0 * 3.0 * C * KW * KW * KS * KS
+    return 4.0 * 3.0 * C * cfg["kw"] ** 2 * cfg["ks"] ** 2
+
+
+def shard_images(total, rank, world):
+    """Strong scaling: images [lo, hi) of the `total`-image batch for this rank (contiguous, sizes differ by <= 1)."""
+    return total * rank // world, total * (rank + 1) // world
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and relay rank 0's
+    JSON line.  Same environment contract as torch.distributed.run."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SSG_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench ranks exited with {rcs}")
 
 
 def event_time_ms(fn, iters):
     """Mean duration of fn() on torch's current stream (HIP events)."""
+    import torch
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
     for _ in range(iters):
@@ -63,10 +104,18 @@ def event_time_ms(fn, iters):
     return st.elapsed_time(en) / iters
 
 
-def stage_times(step, sr, gt, mask, n_edges, iters):
-    """Per-kernel mean launch durations of one step, each stage launched separately through
-    the same C entry points the fused call uses (HIP events on the launch stream)."""
+# launches of the step that ssg_set_profile_mask can skip: name -> bit
+SKIP_BITS = {"fwd_dense": 25, "fwd_direct": 26, "bwd_dense": 27, "bwd_direct": 28, "grad_rows": 29}
+
+
+def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
+    """Mean duration of every kernel of one step: the three C entry points the fused call uses are launched
+    separately, and inside the forward / backward entry points all launches but one are masked out
+    (HIP events on the launch stream; results are not used)."""
+    import torch
     from ssl_amd import _lib, engine
+    cfg = cfg or CONFIGS["c2"]
+    KS, KW, SIGMA, H, W = cfg["ks"], cfg["kw"], cfg["sigma"], cfg["H"], cfg["W"]
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
     B = sr.shape[0]
@@ -87,38 +136,86 @@ def stage_times(step, sr, gt, mask, n_edges, iters):
                                      n_edges, KS, KW, SIGMA, EPS, 1, p(step.ssg_sr), p(step.ssg_gt), st))
 
     def f_bwd():
-        _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts), n_edges, KS, KW, SIGMA, 1,
-                                       p(step.ssg_sr), p(step.ssg_gt), W_L1, W_KL, None, p(step.loss), p(step.grad),
-                                       p(lscratch), st))
+        _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts), n_edges,
+                                       KS, KW, SIGMA, 1, p(step.ssg_sr), p(step.ssg_gt), W_L1, W_KL, None, p(step.loss),
+                                       p(step.grad), p(lscratch), st))
 
-    out = {}
-    for name, f in (("edge_list+order+plan", f_edges), (L.ssg_kernel_name(KS, KW, 0).decode(), f_fwd),
-                    (L.ssg_kernel_name(KS, KW, 1).decode() + "+finalize", f_bwd)):
-        f()
-        torch.cuda.synchronize()
-        out[name] = event_time_ms(f, iters)
+    def only(fn, keep, group):
+        mask_bits = sum(1 << SKIP_BITS[k] for k in group if k != keep)
+        prev = L.ssg_set_profile_mask(mask_bits)
+        try:
+            fn()
+            torch.cuda.synchronize()
+            return event_time_ms(fn, iters)
+        finally:
+            L.ssg_set_profile_mask(prev)
+
+    f_edges()
+    torch.cuda.synchronize()
+    out = {"edge_list+order+plan (13 launches)": event_time_ms(f_edges, iters)}
+    f_fwd()
+    f_bwd()
+    torch.cuda.synchronize()
+    fwd_group, bwd_group = ("fwd_dense", "fwd_direct"), ("grad_rows", "bwd_dense", "bwd_direct")
+    dense = f"<{KS},{KW},3>"
+    out[f"ssg_fwd_dense{dense}"] = only(f_fwd, "fwd_dense", fwd_group)
+    out[f"ssg_fwd_tiled<{KS},{KW}> merged+single (2 launches)"] = only(f_fwd, "fwd_direct", fwd_group)
+    out[f"ssg_grad_rows<{KS},{KW}>+finalize"] = only(f_bwd, "grad_rows", bwd_group)
+    out[f"ssg_bwd_dense{dense}"] = only(f_bwd, "bwd_dense", bwd_group)
+    out[f"ssg_bwd_tiled<{KS},{KW}>"] = only(f_bwd, "bwd_direct", bwd_group)
+    # the masked runs of the backward still launch the 6 us finalize kernel; it is part of the grad_rows line only
+    fin = 0.006
+    for k in (f"ssg_bwd_dense{dense}", f"ssg_bwd_tiled<{KS},{KW}>"):
+        out[k] = max(out[k] - fin, 0.0)
+    out["forward (all launches)"] = event_time_ms(f_fwd, iters)
+    out["backward (all launches)"] = event_time_ms(f_bwd, iters)
     return out
 
 
-def cpu_baseline(sr, gt, mask, budget_s=20.0):
+def module_time_ms(cfg, sr, gt, mask, n_edges, iters):
+    """The step through the drop-in module: SSGLoss forward (edge list, SSGs, criteria, gradient) + autograd backward."""
+    import torch
+    from ssl_amd import SSGLoss
+    crit = SSGLoss(cfg["ks"], cfg["kw"], cfg["sigma"], True, W_L1, W_KL, capacity=n_edges + 1024)
+    x = sr.clone().requires_grad_(True)
+
+    def one():
+        x.grad = None
+        a, b = crit(x, gt, mask)
+        (a + b).backward()
+
+    one()
+    torch.cuda.synchronize()
+    return event_time_ms(one, iters)
+
+
+def cpu_baseline(cfg, sr, gt, mask, budget_s=20.0):
     """Oracle (C + OpenMP) timed on the host cores over a bounded sample of the batch
-    (about budget_s seconds of wall time: whole images, as many as fit)."""
+    (about budget_s seconds of wall time: whole images, as many as fit; C5: a strip of edge pixels)."""
     from oracle import ssg_oracle as orc
+    KS, KW, SIGMA = cfg["ks"], cfg["kw"], cfg["sigma"]
     cores = os.cpu_count() or 1
     orc.ssg_loss(sr[:1, :, :64, :64], gt[:1, :, :64, :64], mask[:1, 0, :64, :64], KS, KW, SIGMA, W_L1, W_KL)  # warm up
-    t0 = time.time()
-    r = orc.ssg_loss(sr[:1], gt[:1], mask[:1, 0], KS, KW, SIGMA, W_L1, W_KL)     # calibrate on image 0
-    per_img = max(time.time() - t0, 1e-3)
-    nimg = int(min(sr.shape[0], max(1, round(budget_s / per_img))))
-    if nimg > 1:
+    if cfg["dense_mask"]:
+        m = mask[:1, 0].copy()
+        m[:, 64:] = 0                                   # 64 rows of edge pixels of the dense image
         t0 = time.time()
-        r = orc.ssg_loss(sr[:nimg], gt[:nimg], mask[:nimg, 0], KS, KW, SIGMA, W_L1, W_KL)
+        r = orc.ssg_loss(sr[:1], gt[:1], m, KS, KW, SIGMA, W_L1, W_KL)
         dt = time.time() - t0
+        what = f"{r['n_edges']} of {mask[0, 0].size} edge px (rows 0-63 of the image)"
     else:
+        t0 = time.time()
+        r = orc.ssg_loss(sr[:1], gt[:1], mask[:1, 0], KS, KW, SIGMA, W_L1, W_KL)     # calibrate on image 0
+        per_img = max(time.time() - t0, 1e-3)
+        nimg = int(min(sr.shape[0], max(1, round(budget_s / per_img))))
         dt = per_img
+        if nimg > 1:
+            t0 = time.time()
+            r = orc.ssg_loss(sr[:nimg], gt[:nimg], mask[:nimg, 0], KS, KW, SIGMA, W_L1, W_KL)
+            dt = time.time() - t0
+        what = f"first {nimg} of {sr.shape[0]} images ({r['n_edges']} edge px)"
     return {"value": r["n_edges"] / dt, "unit": "edge-px/s", "cores": cores, "kind": "port",
-            "sample": f"first {nimg} of {sr.shape[0]} images ({r['n_edges']} edge px), fp32 C oracle, OpenMP over "
-                      f"edge pixels on all {cores} host cores, {dt:.1f} s",
+            "sample": f"{what}, fp32 C oracle, OpenMP over edge pixels on all {cores} host cores, {dt:.1f} s",
             "l1": r["l1"], "kl": r["kl"]}
 
 
@@ -129,12 +226,29 @@ def pmc_traffic(kernel_name):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
+        key = kernel_name.split("<")[0].split(" ")[0]
         for k, v in t.get("kernels", {}).items():
-            if k.split("<")[0] in kernel_name and ("bwd" in k) == ("bwd" in kernel_name):
+            if k.split("<")[0] == key:
                 return v.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
     return None
+
+
+def make_inputs(cfg, rank, world, scaling):
+    """Synthetic batch of this rank (numpy): weak = `batch` images per rank, strong = the rank's share of ONE batch."""
+    import numpy as np
+    from ssl_amd import synth
+    B, H, W = cfg["batch"], cfg["H"], cfg["W"]
+    if cfg["dense_mask"]:
+        gt = np.stack([synth.natural_like(300 + rank * B + i, H, W) for i in range(B)])
+        sr = np.stack([synth.degrade(gt[i], 7 + rank * B + i) for i in range(B)])
+        return sr, gt, np.ones((B, 1, H, W), np.float32)
+    if scaling == "strong":
+        lo, hi = shard_images(B, rank, world)
+        sr, gt, mask = synth.make_batch(B, H, W, seed0=100)
+        return sr[lo:hi], gt[lo:hi], mask[lo:hi]
+    return synth.make_batch(B, H, W, seed0=100 + B * rank)
 
 
 def main():
@@ -142,90 +256,133 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 16 images per GPU; strong: the 16 images split over the GPUs (SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-module", action="store_true", help="skip the SSGLoss (nn.Module) timing")
     ap.add_argument("--graph", action="store_true", help="replay the step as a recorded HIP graph instead of "
                     "launching its kernels one by one (measured: no difference, the step is not launch-bound)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launcher / sharding / "
+                    "reduction plumbing on CPU with the gloo backend (used by the CPU test-suite)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)               # self-launch: one process per GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ    # launched by torch.distributed.run (also with 1 rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    cfg = CONFIGS[args.config]
+    use_dist = world > 1 or "RANK" in os.environ    # launched by torch.distributed.run / self-spawned (also 1 rank)
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL on ROCm
+        dist.init_process_group("gloo" if args.dry_run else "nccl", rank=rank, world_size=world)   # nccl = RCCL on ROCm
+    if args.dry_run:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
-    from ssl_amd import engine, synth
-
-    sr_np, gt_np, mask_np = synth.make_batch(BATCH, H, W, seed0=100 + BATCH * rank)
-    sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
+    from ssl_amd import synth
+    sr_np, gt_np, mask_np = make_inputs(cfg, rank, world, args.scaling)
+    B = sr_np.shape[0]
     n_edges = int(mask_np.sum())
-    step = engine.LossStep(BATCH, C, H, W, KS, KW, SIGMA, EPS, True, W_L1, W_KL, device=dev,
-                           capacity=n_edges + 1024, graph=args.graph)
 
     def sync_all():
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not args.dry_run:
+                torch.cuda.synchronize()
+
+    if args.dry_run:
+        step = None
+
+        def run_step():
+            return None
+    else:
+        from ssl_amd import engine
+        sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
+        step = engine.LossStep(max(B, 1), C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1,
+                               W_KL, device=dev, capacity=n_edges + 1024, graph=args.graph) if B else None
+
+        def run_step():
+            if step is not None:
+                step(sr, gt, mask)
 
     for _ in range(args.warmup):
-        step(sr, gt, mask)
+        run_step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(sr, gt, mask)
+        run_step()
     sync_all()
     elapsed = time.perf_counter() - t0
 
     tot_edges = torch.tensor([float(n_edges)], device=dev, dtype=torch.float64)
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    ranks_seen = 1
     if use_dist:
         dist.all_reduce(tot_edges, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ranks_seen = dist.get_world_size()
     elapsed = float(tmax)
     total_edges = float(tot_edges)
 
-    assert int(step.counts[0]) == n_edges
-    loss = step.loss.cpu().numpy()
-
     if rank == 0:
         value = total_edges * args.steps / elapsed
-        b_alg = alg_bytes_per_edge_px(n_edges, BATCH)
-        # per-kernel durations on this rank (HIP events on the launch stream)
-        stages = stage_times(step, sr, gt, mask, n_edges, max(3, min(args.steps, 10)))
-        step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), max(3, min(args.steps, 10)))
-        dom = max((k for k in stages if "ssg_" in k), key=lambda k: stages[k])
-        ach = b_alg * n_edges / (stages[dom] * 1e-3) / 1e9
-        ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
-        tflops = alg_flops_per_edge_px() * n_edges / (step_gpu_ms * 1e-3) / 1e12
         res = {
-            "metric": "SSG-loss edge-pixels/sec (fwd+bwd) 3x256x256 k_s=25 k_w=9",
+            "metric": "SSG-loss edge-pixels/sec (fwd+bwd) 3x256x256 k_s=25 k_w=9" if args.config == "c2" else
+                      "SSG-loss edge-pixels/sec (fwd+bwd) 3x512x512 k_s=49 k_w=13 dense mask",
             "value": value, "unit": "edge-px/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: batch 16 x 3x256x256 per GPU, Laplacian mask, k_s=25 k_w=9 sigma=1.0, "
-                                   "L1+KL w=1e3, SSGs materialised",
-                       "launch": "HIP graph replay" if args.graph else "per-kernel",
-                       "edge_px_per_gpu": n_edges, "mask_density": n_edges / (BATCH * H * W),
-                       "input_checksum": synth.checksum(sr_np, gt_np, mask_np), "parallelism": f"images sharded x{world}",
-                       "l1": float(loss[0]), "kl": float(loss[1])},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
-                         "alg_bytes_per_edge_px": b_alg, "kernel_ms": stages,
-                         "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS},
-                         "valu": {"achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": tflops / FP32_PEAK_TFLOPS,
-                                  "alg_flops_per_edge_px": alg_flops_per_edge_px(),
-                                  "note": "binding roofline: fp32 VALU (~330 flop/B), see DESIGN.md"}},
+            "config": {"workload": cfg["name"] + (" (16 images split over the GPUs)" if args.scaling == "strong" else ""),
+                       "launch": "HIP graph replay" if args.graph else "per-kernel", "ranks_seen": ranks_seen,
+                       "edge_px_rank0": n_edges, "edge_px_total": total_edges, "images_rank0": B,
+                       "mask_density": n_edges / max(B * cfg["H"] * cfg["W"], 1),
+                       "input_checksum": synth.checksum(sr_np, gt_np, mask_np),
+                       "parallelism": f"images sharded x{world}, no data-path collective"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sr_np, gt_np, mask_np)
-            res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        if args.dry_run:
+            res["dry_run"] = True
+            res["value"] = None
+        elif step is not None:
+            assert int(step.counts[0]) == n_edges
+            loss = step.loss.cpu().numpy()
+            res["config"]["l1"], res["config"]["kl"] = float(loss[0]), float(loss[1])
+            b_alg = alg_bytes_per_edge_px(cfg, n_edges, B)
+            it = max(3, min(args.steps, 10))
+            stages = stage_times(step, sr, gt, mask, n_edges, it, cfg)
+            step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), it)
+            dom = max((k for k in stages if k.startswith("ssg_") and "launches" not in k and "+" not in k),
+                      key=lambda k: stages[k])
+            ach = b_alg * n_edges / (stages[dom] * 1e-3) / 1e9
+            ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
+            tflops = alg_flops_per_edge_px(cfg) * n_edges / (step_gpu_ms * 1e-3) / 1e12
+            res["roofline"] = {
+                "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "alg_bytes_per_edge_px": b_alg,
+                "kernel_ms": stages,
+                "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS},
+                "valu": {"achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / FP32_PEAK_TFLOPS, "alg_flops_per_edge_px": alg_flops_per_edge_px(cfg),
+                         "note": "SURVEY's DIRECT flop count over the step's GPU time; the dense-tile kernels do "
+                                 "fewer real flops, so this is throughput in reference-equivalent flops, not "
+                                 "VALU utilisation (see profiles/ for SQ_INSTS_VALU)"}}
+            if not args.no_module:
+                mm = module_time_ms(cfg, sr, gt, mask, n_edges, it)
+                res["module"] = {"what": "ssl_amd.SSGLoss forward + autograd backward (drop-in path)",
+                                 "ms_per_step": mm, "value": n_edges / (mm * 1e-3), "unit": "edge-px/s"}
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(cfg, sr_np, gt_np, mask_np)
+                res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res))
     if use_dist:
         dist.barrier()

@@ -22,6 +22,8 @@
  *   (D) ssg_loss_*                          <- the caller loop realesrganssl_model.py:379-430
  *                                              with L1Loss (basic_loss.py:41-66) and
  *                                              KLDistanceLoss (basic_loss.py:269-282)
+ *   (E) ssg_augment_crop / ssg_pool_swap    <- basicsr/data/transforms.py:93-219 (joint flip/rot90 + crop of
+ *                                              image and mask), realesrganssl_model.py:327-367 (pair pool)
  *
  * Return value of every int function: 0 on success, a positive hipError_t
  * from the launch, or a negative SSG_E_* code.  ssg_status_string() maps both.
@@ -210,6 +212,28 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask,
                      float lap_threshold, int capacity, float *ssg_sr,
                      float *ssg_gt, int *counts, float *loss_out, float *grad_sr,
                      void *workspace, size_t workspace_bytes, ssg_stream_t stream);
+
+/* ---------------------------------------------------------------- (E) ----
+ * The step before the loss, on the GPU (minimal slice): joint augmentation + crop of image and mask, and the
+ * training pair pool.  Byte moves only, bit exact.
+ *
+ * ssg_augment_crop <- basicsr/data/transforms.py:152-219 `augment` (hflip, then vflip, then rot90 = transpose,
+ * the same draw for image and mask) followed by transforms.py:93-149 `paired_random_crop_img_mask`: dst
+ * (B,C,Ho,Wo) = crop at (top,left) of the augmented src (B,C,Hs,Ws); params (B,5) int32 on device:
+ * top, left, hflip, vflip, rot90 per sample (top/left index the AUGMENTED image; the caller draws them like the
+ * reference does and scales them for the GT side).  elem_bytes 4 (fp32 images / masks) or 1 (uint8 masks).
+ *
+ * ssg_pool_swap <- realesrganssl_model.py:327-367 `_dequeue_and_enqueue` for one tensor of the pool: samples
+ * `slots[k]` of `queue` (Q samples of sample_bytes each) and sample k of `batch` change places, k < b. */
+int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,
+                     const int *params, ssg_stream_t stream);
+int ssg_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, ssg_stream_t stream);
+
+/* Profiling only (results are WRONG while a mask is set): skip kernel phases or whole launches so that one
+ * kernel of a multi-kernel entry point can be timed with events on its stream.  Bits: 25 dense-tile forward,
+ * 26 direct forward, 27 dense-tile backward, 28 direct backward (split mode), 29 G rows; lower bits ablate
+ * phases inside kernels (ssg_api.hip).  Returns the previous mask; 0 restores production behaviour. */
+int ssg_set_profile_mask(int mask);
 
 /* Host helper for profiling builds: name of the HIP kernel a configuration
  * dispatches to ("ssg_fwd<25,9,5>", "ssg_fwd_generic", ...). */

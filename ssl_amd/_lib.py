@@ -38,6 +38,9 @@ PROTOTYPES = {
     "ssg_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ssg_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,
                               _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssg_augment_crop": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ssg_pool_swap": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
+    "ssg_set_profile_mask": (_i, [_i]),
     "ssg_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
     # include/similarity.h: the reference operator's own (void, stream-less) interface
     "ssg_ref_compute_similarity": (None, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),

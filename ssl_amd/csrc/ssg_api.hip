@@ -3,6 +3,7 @@
 // and the reference interface it replaces.
 #include "../../include/ssg_hip.h"
 
+#include <atomic>
 #include <cstdlib>
 
 #include "ssg_common.hpp"
@@ -47,6 +48,9 @@ unsigned grow_grid(int n_host);
 int launch_grad_rows(const GrowParams &p, int ks, int kw, hipStream_t st);
 bool dense_bwd_supported(int ks, int kw, int C);
 int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st);
+int launch_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,
+                        const int *params, hipStream_t st);
+int launch_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, hipStream_t st);
 }  // namespace ssg
 
 using namespace ssg;
@@ -57,31 +61,43 @@ using namespace ssg;
 // density; below ~16 pixels per tile the direct kernels win.  Default 28; ssg_set_dense_threshold(n) or the
 // environment variable SSG_DENSE_THR (read at first use) override it.
 constexpr int DENSE_THR_DEFAULT = 28;
-static int g_dense_thr = -1;
+static std::atomic<int> g_dense_thr{-1};   // (atomic: the ABI may be called from several host threads)
 static int dense_threshold() {
-  if (g_dense_thr < 0) {
+  int v = g_dense_thr.load(std::memory_order_relaxed);
+  if (v < 0) {
     const char *e = getenv("SSG_DENSE_THR");
-    g_dense_thr = e ? atoi(e) : DENSE_THR_DEFAULT;
-    if (g_dense_thr < 0) g_dense_thr = 0;
+    v = e ? atoi(e) : DENSE_THR_DEFAULT;
+    if (v < 0) v = 0;
+    g_dense_thr.store(v, std::memory_order_relaxed);
   }
-  return g_dense_thr;
+  return v;
 }
 
 extern "C" int ssg_set_dense_threshold(int edge_pixels_per_tile) {
   const int prev = dense_threshold();
-  g_dense_thr = edge_pixels_per_tile > 0 ? edge_pixels_per_tile : 0;
+  g_dense_thr.store(edge_pixels_per_tile > 0 ? edge_pixels_per_tile : 0, std::memory_order_relaxed);
   return prev;
 }
 
-// SSG_DEBUG_SKIP=<bitmask> ablates kernel phases for profiling (results are then WRONG);
-// read once, 0 in production.
+// SSG_DEBUG_SKIP=<bitmask> (or ssg_set_profile_mask) ablates kernel phases / skips whole launches for
+// profiling (results are then WRONG); 0 in production.  Bits 0-7 direct forward phases, 8-15 backward phases,
+// 16-23 dense forward phases, 24 no split backward; launches skipped: 25 dense forward, 26 direct forward,
+// 27 dense backward, 28 direct backward (split mode), 29 G rows.
+static std::atomic<int> g_dbg{-1};
 static int dbg_mask() {
-  static int v = -1;
+  int v = g_dbg.load(std::memory_order_relaxed);
   if (v < 0) {
     const char *e = getenv("SSG_DEBUG_SKIP");
     v = e ? atoi(e) : 0;
+    if (v < 0) v = 0;
+    g_dbg.store(v, std::memory_order_relaxed);
   }
   return v;
+}
+extern "C" int ssg_set_profile_mask(int mask) {
+  const int prev = dbg_mask();
+  g_dbg.store(mask > 0 ? mask : 0, std::memory_order_relaxed);
+  return prev;
 }
 
 static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (kw & 1) && kw <= ks; }
@@ -128,7 +144,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   g.G = p.grad ? G : nullptr;
   g.sum_b = p.grad ? sum_b : nullptr;
   g.partials = p.partials;
-  int rc = launch_grad_rows(g, p.ks, p.kw, st);
+  int rc = (dbg_mask() & (1 << 29)) ? 0 : launch_grad_rows(g, p.ks, p.kw, st);
   if (rc || !p.grad) return rc;
   const float *grows = p.mode == GRAD_D ? p.gin : G;
   DenseBwdParams d{};
@@ -147,8 +163,9 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   d.W = p.W;
   d.qsplit = bwd_qsplit();
   d.dbg = p.dbg;
-  rc = launch_bwd_dense(d, p.ks, p.kw, p.C, st);
+  rc = (dbg_mask() & (1 << 27)) ? 0 : launch_bwd_dense(d, p.ks, p.kw, p.C, st);
   if (rc) return rc;
+  if (dbg_mask() & (1 << 28)) return 0;
   BwdParams s = p;
   s.mode = GRAD_D;
   s.gin = grows;
@@ -305,10 +322,11 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
     d.eps = eps;
     d.generalization = generalization;
     d.dbg = (dbg_mask() >> 16) & 0xff;
-    const int rc = launch_fwd_dense(d, ks, kw, C, (hipStream_t)stream);
+    const int rc = (dbg_mask() & (1 << 25)) ? 0 : launch_fwd_dense(d, ks, kw, C, (hipStream_t)stream);
     if (rc) return rc;
     p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
     p.n_dev = fwd_plan;  // n_sparse
+    if (dbg_mask() & (1 << 26)) return 0;
   }
   return launch_fwd(p, (hipStream_t)stream);
 }
@@ -434,6 +452,19 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   if (rc) return rc;
   return ssg_loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
                            ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);
+}
+
+int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,
+                     const int *params, ssg_stream_t stream) {
+  if (!src || !dst || !params || B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 ||
+      (elem_bytes != 1 && elem_bytes != 4))
+    return SSG_E_BADARG;
+  return launch_augment_crop(src, dst, elem_bytes, B, C, Hs, Ws, Ho, Wo, params, (hipStream_t)stream);
+}
+
+int ssg_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, ssg_stream_t stream) {
+  if (!queue || !batch || !slots || b < 0) return SSG_E_BADARG;
+  return launch_pool_swap(queue, batch, sample_bytes, slots, b, (hipStream_t)stream);
 }
 
 const char *ssg_kernel_name(int ks, int kw, int backward) {

@@ -444,6 +444,87 @@ def f10_paper_cotangent():
     save("f10_paper_cotangent", **out)
 
 
+def f11_datapath():
+    """F11: the reference's own data-path code on seeded inputs.
+    (a) basicsr/data/transforms.py `augment` + `paired_random_crop_img_mask` -- imported by path with `cv2`
+        stubbed: its only use there is cv2.flip(src, flipCode, dst) in place, whose semantics (flipCode 1 =
+        horizontal, 0 = vertical) are restated with numpy in the stub;
+    (b) basicsr/models/realesrganssl_model.py `_dequeue_and_enqueue` -- the method's source is read from the
+        reference at generation time, `.cuda()` dropped (no GPU here), and executed on a bare object.
+    Stored: inputs, the python `random` / torch seeds, the draws and the outputs."""
+    import inspect
+    import random
+    import re
+    cv2 = types.ModuleType("cv2")
+
+    def flip(src, flipCode, dst=None):
+        out = src[:, ::-1].copy() if flipCode == 1 else src[::-1].copy()
+        if dst is not None:
+            dst[...] = out
+            return dst
+        return out
+
+    cv2.flip = flip
+    saved = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+    spec = importlib.util.spec_from_file_location("ref_transforms", "/root/reference/GAN-Based-SR/basicsr/data/transforms.py")
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    if saved is not None:
+        sys.modules["cv2"] = saved
+    else:
+        del sys.modules["cv2"]
+    rng = np.random.default_rng(77)
+    B, Hs, Ws, scale, gt_size = 4, 48, 48, 4, 32
+    gts = rng.random((B, Hs, Ws, 3), dtype=np.float32)
+    masks = (rng.random((B, Hs, Ws, 1)) < 0.1).astype(np.float32)
+    out = dict(gt_src=gts, mask_src=masks, scale=scale, gt_size=gt_size, seed=1234)
+    random.seed(1234)
+    aug_gt, aug_mask, status = [], [], []
+    for b in range(B):                                   # dataset side: my_realesrgan_image_mask_dataset.py:86
+        (g, m), st = tr.augment([gts[b].copy(), masks[b].copy()], True, True, return_status=True)
+        aug_gt.append(np.ascontiguousarray(g))
+        aug_mask.append(np.ascontiguousarray(m))
+        status.append([int(bool(v)) for v in st])
+    out["flips"] = np.array(status, np.int32)
+    G = torch.as_tensor(np.stack(aug_gt)).permute(0, 3, 1, 2).contiguous()
+    M = torch.as_tensor(np.stack(aug_mask)).permute(0, 3, 1, 2).contiguous()
+    LQ = torch.as_tensor(rng.random((B, 3, Hs // scale, Ws // scale), dtype=np.float32))
+    out["lq_src"] = LQ.numpy()
+    state = random.getstate()
+    g2, l2, m2 = tr.paired_random_crop_img_mask(img_gts=G, img_lqs=LQ, masks=M, gt_patch_size=gt_size, scale=scale)
+    random.setstate(state)
+    out["top_left_lq"] = np.array([random.randint(0, Hs // scale - gt_size // scale),
+                                   random.randint(0, Ws // scale - gt_size // scale)], np.int32)
+    out["gt_out"], out["lq_out"], out["mask_out"] = g2.numpy(), l2.numpy(), m2.numpy()
+
+    # (b) the pair pool
+    src = open("/root/reference/GAN-Based-SR/basicsr/models/realesrganssl_model.py").read()
+    m = re.search(r"    def _dequeue_and_enqueue\(self\):.*?(?=\n    def |\n    @)", src, re.S)
+    body = inspect.cleandoc("\n" + m.group(0)).replace(".cuda()", "")
+    ns = {"torch": torch}
+    exec(body, ns)
+    pool = types.SimpleNamespace(queue_size=8)
+    torch.manual_seed(4321)
+    b = 2
+    steps = 9
+    lq_in = rng.random((steps, b, 3, 4, 4), dtype=np.float32)
+    gt_in = rng.random((steps, b, 3, 8, 8), dtype=np.float32)
+    mk_in = (rng.random((steps, b, 1, 8, 8)) < 0.3).astype(np.float32)
+    lq_o, gt_o, mk_o = [], [], []
+    for t in range(steps):
+        pool.lq, pool.gt, pool.gt_mask = (torch.as_tensor(a[t]) for a in (lq_in, gt_in, mk_in))
+        ns["_dequeue_and_enqueue"](pool)
+        lq_o.append(pool.lq.numpy().copy())
+        gt_o.append(pool.gt.numpy().copy())
+        mk_o.append(pool.gt_mask.numpy().copy())     # (b,3,h,w) once the pool is full: GT-channel copies (:339-341)
+    out.update(pool_seed=4321, pool_size=8, pool_lq_in=lq_in, pool_gt_in=gt_in, pool_mask_in=mk_in.astype(np.uint8),
+               pool_lq_out=np.stack(lq_o), pool_gt_out=np.stack(gt_o),
+               pool_mask_out=np.stack([a[:, :1] for a in mk_o]).astype(np.uint8),
+               pool_mask_channels_equal=all(bool((a == a[:, :1]).all()) for a in mk_o))
+    save("f11_datapath", **out)
+
+
 def cpu_reference_timing():
     """time the reference ssl_pytorch loss step on this
     container's cores (one 3x256x256 image of the C2 batch, like the reference's
@@ -471,7 +552,7 @@ def cpu_reference_timing():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10"]
+    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11"]
     torch.manual_seed(0)
     if "f1" in which:
         f1_c1()
@@ -493,5 +574,7 @@ if __name__ == "__main__":
         f9_c4_dm_loop()
     if "f10" in which:
         f10_paper_cotangent()
+    if "f11" in which:
+        f11_datapath()
     if "time" in which:
         cpu_reference_timing()

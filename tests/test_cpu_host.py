@@ -202,3 +202,26 @@ def test_mask_files_roundtrip_and_density_report_format(tmp_path):
                      "Average of grad is 450.00, percentage is 0.3000", "Maximum of mask is 100.00, percentage is 0.050000",
                      "Minium of grad is 80.00, percentage is 0.0400", "Average of grad is 90.00, percentage is 0.0600"]
     assert text.endswith("\n".join(lines) + "\n")
+
+
+def test_bench_self_launch_two_ranks_strong_scaling_dry_run():
+    """`python bench.py --gpus 2` with no launcher spawns its own ranks (one process per GPU on the box; here the
+    --dry-run plumbing on CPU/gloo): 127.0.0.1 rendezvous, the 16-image batch split 2-ways, edge pixels summed and
+    the step time max-reduced across ranks, ONE JSON line from rank 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--scaling", "strong", "--dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["ranks_seen"] == 2 and r["scaling"] == "strong" and r["dry_run"] is True
+    assert r["config"]["images_rank0"] == 8
+    from ssl_amd import synth
+    _, _, mask = synth.make_batch(16, 256, 256)
+    assert r["config"]["edge_px_total"] == float(mask.sum())
+    assert r["config"]["edge_px_rank0"] == int(mask[:8].sum())
+    import bench
+    assert [bench.shard_images(16, k, 3) for k in range(3)] == [(0, 5), (5, 10), (10, 16)]

@@ -965,3 +965,43 @@ def test_ssgloss_capacity_growth_and_uint8_semantics(dev):
     assert int(engine.edge_list(mask=u8).counts[0]) == 0
     assert int(engine.edge_list(mask=(u8 // 255)).counts[0]) == int(m.sum())
     assert int(engine.edge_list(mask=u8 > 0).counts[0]) == int(m.sum())
+
+
+def test_f11_datapath_kernels_bit_exact(dev, golden):
+    """SURVEY 8 row f3 (minimal slice): joint flip / rot90 + crop of GT, mask and LQ (ssg_augment_crop) and the pair
+    pool with 1-channel uint8 masks (ssg_pool_swap), seeded like the reference run that produced fixture F11 --
+    bit exact -- and feeding the loss."""
+    import random
+    from ssl_amd import SSGLoss, datapath
+    g = golden("f11_datapath")
+    scale, gt_size = int(g["scale"]), int(g["gt_size"])
+    gt_src = T(g["gt_src"].transpose(0, 3, 1, 2), dev)
+    mk_src = T(g["mask_src"].transpose(0, 3, 1, 2), dev)
+    B = gt_src.shape[0]
+    random.seed(int(g["seed"]))
+    flips = [datapath.draw_augment(True, True) for _ in range(B)]
+    assert np.array_equal(np.array(flips, np.int32), g["flips"])
+    lq_src = T(g["lq_src"], dev)
+    # the crop origin is drawn on the augmented GT's LQ grid (square sources here, so rot90 keeps the shape)
+    gt, lq, mk = datapath.paired_random_crop_img_mask(gt_src, lq_src, mk_src, gt_size, scale, flips=flips)
+    assert torch.equal(gt.cpu(), torch.as_tensor(g["gt_out"])) and torch.equal(lq.cpu(), torch.as_tensor(g["lq_out"]))
+    assert torch.equal(mk.cpu(), torch.as_tensor(g["mask_out"]))
+    mk8 = datapath.augment_crop((mk_src == 1).to(torch.uint8), (gt_size, gt_size),
+                                [tuple(int(v) * scale for v in g["top_left_lq"])] * B, flips)
+    assert mk8.dtype == torch.uint8 and torch.equal(mk8.cpu().float(), torch.as_tensor(g["mask_out"]))
+    with pytest.raises(ValueError):
+        datapath.augment_crop(gt_src, (gt_size, gt_size), [(40, 0)] * B, flips)
+    # pair pool
+    torch.manual_seed(int(g["pool_seed"]))
+    pool = datapath.PairPool(int(g["pool_size"]))
+    for t in range(g["pool_lq_in"].shape[0]):
+        lq, gt, mk = pool.exchange(T(g["pool_lq_in"][t], dev), T(g["pool_gt_in"][t], dev),
+                                   T(g["pool_mask_in"][t], dev))
+        assert torch.equal(lq.cpu(), torch.as_tensor(g["pool_lq_out"][t]))
+        assert torch.equal(gt.cpu(), torch.as_tensor(g["pool_gt_out"][t]))
+        assert mk.dtype == torch.uint8 and torch.equal(mk.cpu(), torch.as_tensor(g["pool_mask_out"][t]))
+    # the pooled (gt, uint8 mask) pair goes straight into the loss
+    a, b = SSGLoss(5, 3, 0.5, True, 1.0, 1.0)(torch.rand_like(gt), gt, mk)
+    ref = orc.ssg_loss(np.zeros((2, 3, 8, 8)), np.zeros((2, 3, 8, 8)), mk[:, 0].cpu().numpy(), 5, 3, 0.5, 1.0, 1.0,
+                       want_grad=False)
+    assert bool(torch.isfinite(a)) and bool(torch.isfinite(b)) and int(mk.sum()) == ref["n_edges"]

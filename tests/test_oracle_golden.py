@@ -215,3 +215,27 @@ def test_f10_paper_sizes_vjp(golden, sigma):
     gI = orc.distance_backward(img, pos, ks, kw, orc.ssg_epilogue_backward(S, cot.astype(np.float64), ks, kw, 3, sigma, True))
     ref = g[f"dimg_s{sigma}"]
     _close(gI, ref, 2e-7 * np.abs(ref).max())
+
+
+def test_f11_datapath_oracle_vs_reference(golden):
+    """Data-path slice: the numpy restatement of augment + joint crop and of the pair pool against
+    the outputs of the reference's own transforms.py / _dequeue_and_enqueue (fixture F11).  Bit exact."""
+    import torch
+    from oracle import datapath_oracle as dp
+    g = golden("f11_datapath")
+    scale, gt_size = int(g["scale"]), int(g["gt_size"])
+    flips = [tuple(int(v) for v in f) for f in g["flips"]]
+    top, left = (int(v) for v in g["top_left_lq"])
+    gt_src = g["gt_src"].transpose(0, 3, 1, 2)
+    mk_src = g["mask_src"].transpose(0, 3, 1, 2)
+    assert np.array_equal(dp.augment_crop_nchw(gt_src, top * scale, left * scale, (gt_size, gt_size), flips), g["gt_out"])
+    assert np.array_equal(dp.augment_crop_nchw(mk_src, top * scale, left * scale, (gt_size, gt_size), flips), g["mask_out"])
+    assert np.array_equal(dp.crop_nchw(g["lq_src"], top, left, gt_size // scale), g["lq_out"])
+    assert bool(g["pool_mask_channels_equal"])
+    torch.manual_seed(int(g["pool_seed"]))
+    pool = dp.PairPool(int(g["pool_size"]))
+    for t in range(g["pool_lq_in"].shape[0]):
+        lq, gt, mk = pool.exchange([g["pool_lq_in"][t], g["pool_gt_in"][t], g["pool_mask_in"][t]],
+                                   lambda: torch.randperm(int(g["pool_size"])).numpy())
+        assert np.array_equal(lq, g["pool_lq_out"][t]) and np.array_equal(gt, g["pool_gt_out"][t])
+        assert np.array_equal(mk, g["pool_mask_out"][t])
