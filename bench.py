@@ -138,7 +138,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     def f_bwd():
         _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts), n_edges,
                                        KS, KW, SIGMA, 1, p(step.ssg_sr), p(step.ssg_gt), W_L1, W_KL, None, p(step.loss),
-                                       p(step.grad), p(lscratch), st))
+                                       p(step.grad), p(lscratch), None, st))
 
     def only(fn, keep, group):
         mask_bits = sum(1 << SKIP_BITS[k] for k in group if k != keep)
@@ -348,6 +348,7 @@ def main():
                        "edge_px_rank0": n_edges, "edge_px_total": total_edges, "images_rank0": B,
                        "mask_density": n_edges / max(B * cfg["H"] * cfg["W"], 1),
                        "input_checksum": synth.checksum(sr_np, gt_np, mask_np),
+                       "gradient_accumulation": "fixed-point integer atomics (bit-reproducible, the shipped default)",
                        "parallelism": f"images sharded x{world}, no data-path collective"},
         }
         if args.dry_run:

@@ -171,7 +171,17 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W,
                      const int *n_edges_dev, int n_rows,
                      int ks, int kw, float sigma, int generalization,
                      const float *ssg, const float *grad_ssg, float *grad_img,
-                     void *scratch /* nullable */, ssg_stream_t stream);
+                     void *scratch /* nullable */, void *grad_fix /* nullable */,
+                     ssg_stream_t stream);
+
+/* Deterministic gradient accumulation.  By default the kernels add their per-pixel contributions to the image
+ * gradient with hardware fp32 atomics: the order of the additions, hence the last bits of the result, varies
+ * from run to run (as with the reference's atomicAdd, similarity.cu:123-128).  Passing `grad_fix` --
+ * ssg_grad_fix_bytes(B,C,H,W) bytes of device memory, contents irrelevant -- to the backward entry points makes
+ * the result bit-reproducible: contributions are rounded to multiples of 2^-40 and summed with 64-bit integer
+ * atomics (integer addition is associative), then folded into grad once per pixel.  Range +-2^23, absolute
+ * resolution 9e-13. */
+size_t ssg_grad_fix_bytes(int B, int C, int H, int W);
 
 /* ---------------------------------------------------------------- (D) ----
  * The whole loss step of the caller loop over a batch:
@@ -198,7 +208,8 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
                       const float *ssg_sr, const float *ssg_gt, float w_l1,
                       float w_kl, const float *upstream /* nullable */,
                       float *loss_out, float *grad_sr /* nullable */,
-                      void *scratch, ssg_stream_t stream);
+                      void *scratch, void *grad_fix /* nullable: deterministic mode */,
+                      ssg_stream_t stream);
 
 /* Everything in one call: edge list (from a mask or from GT's Laplacian),
  * SSG(sr), SSG(gt), both criteria and the gradient.  ssg_sr / ssg_gt
@@ -211,7 +222,8 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask,
                      int generalization, float w_l1, float w_kl, int mask_stride,
                      float lap_threshold, int capacity, float *ssg_sr,
                      float *ssg_gt, int *counts, float *loss_out, float *grad_sr,
-                     void *workspace, size_t workspace_bytes, ssg_stream_t stream);
+                     void *workspace, size_t workspace_bytes,
+                     void *grad_fix /* nullable: deterministic mode */, ssg_stream_t stream);
 
 /* ---------------------------------------------------------------- (E) ----
  * The step before the loss, on the GPU (minimal slice): joint augmentation + crop of image and mask, and the

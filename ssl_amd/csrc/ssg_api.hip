@@ -51,6 +51,7 @@ int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t
 int launch_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,
                         const int *params, hipStream_t st);
 int launch_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, hipStream_t st);
+int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st);
 }  // namespace ssg
 
 using namespace ssg;
@@ -150,6 +151,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   DenseBwdParams d{};
   d.img = p.img;
   d.grad = p.grad;
+  d.gfix = p.gfix;
   d.G = grows;
   d.sum_b = sum_b;
   d.rank = rank;
@@ -173,6 +175,18 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   s.n_dev = plan;  // n_sparse
   s.partials = nullptr;
   return launch_bwd(s, st);
+}
+
+// Deterministic mode: the kernels add into the caller's zeroed fixed-point buffer; one flush folds it into grad.
+static int det_begin(BwdParams &p, void *grad_fix, hipStream_t st) {
+  p.gfix = nullptr;
+  if (!grad_fix || !p.grad) return 0;
+  p.gfix = (long long *)grad_fix;
+  return (int)hipMemsetAsync(grad_fix, 0, sizeof(long long) * (size_t)p.B * p.C * p.H * p.W, st);
+}
+static int det_end(const BwdParams &p, hipStream_t st) {
+  if (!p.gfix) return 0;
+  return launch_grad_fix_flush(p.gfix, p.grad, (size_t)p.B * p.C * p.H * p.W, st);
 }
 
 static bool split_ok(int ks, int kw, int C, const int *rank, const int *plan, const void *scratch) {
@@ -336,7 +350,7 @@ size_t ssg_backward_scratch_bytes(int n_rows, int ks) { return split_scratch_byt
 int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *edges, const int *tile_order,
                      const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
                      float sigma, int generalization, const float *ssg, const float *grad_ssg, float *grad_img,
-                     void *scratch, ssg_stream_t stream) {
+                     void *scratch, void *grad_fix, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -361,9 +375,14 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *ed
   p.ks = ks;
   p.kw = kw;
   p.dbg = (dbg_mask() >> 8) & 0xff;
-  if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) return split_backward(p, rank_map, fwd_plan, scratch, (hipStream_t)stream);
-  return launch_bwd(p, (hipStream_t)stream);
+  int rc = det_begin(p, grad_fix, (hipStream_t)stream);
+  if (rc) return rc;
+  rc = split_ok(ks, kw, C, rank_map, fwd_plan, scratch) ? split_backward(p, rank_map, fwd_plan, scratch, (hipStream_t)stream)
+                                                         : launch_bwd(p, (hipStream_t)stream);
+  return rc ? rc : det_end(p, (hipStream_t)stream);
 }
+
+size_t ssg_grad_fix_bytes(int B, int C, int H, int W) { return sizeof(long long) * (size_t)B * C * H * W; }
 
 static size_t partials_bytes(int B, int H, int W, int n_rows) {
   return align_up(2 * sizeof(float) * bwd_max_partials(B, H, W, n_rows) + 64, 256);
@@ -377,7 +396,7 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
                       const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
                       float sigma, int generalization,
                       const float *ssg_sr, const float *ssg_gt, float w_l1, float w_kl, const float *upstream,
-                      float *loss_out, float *grad_sr, void *scratch, ssg_stream_t stream) {
+                      float *loss_out, float *grad_sr, void *scratch, void *grad_fix, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
@@ -407,14 +426,19 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
   p.ks = ks;
   p.kw = kw;
   p.dbg = (dbg_mask() >> 8) & 0xff;
-  if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
-    const int rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st);
-    if (rc) return rc;
-    return launch_loss_finalize(p.partials, (int)grow_grid(n_rows), n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
-  }
-  int rc = launch_bwd(p, st);
+  int rc = det_begin(p, grad_fix, st);
   if (rc) return rc;
-  return launch_loss_finalize(p.partials, (int)bwd_grid(p), n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
+  int nparts;
+  if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
+    rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st);
+    nparts = (int)grow_grid(n_rows);
+  } else {
+    rc = launch_bwd(p, st);
+    nparts = (int)bwd_grid(p);
+  }
+  if (!rc) rc = det_end(p, st);
+  if (rc) return rc;
+  return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
 }
 
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
@@ -428,7 +452,7 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
                      int C, int H, int W, int ks, int kw, float sigma, float eps, int generalization, float w_l1,
                      float w_kl, int mask_stride, float lap_threshold, int capacity, float *ssg_sr, float *ssg_gt,
                      int *counts, float *loss_out, float *grad_sr, void *workspace, size_t workspace_bytes,
-                     ssg_stream_t stream) {
+                     void *grad_fix, ssg_stream_t stream) {
   if (!sr || !gt || !ssg_sr || !ssg_gt || !counts || !loss_out || !workspace || capacity <= 0) return SSG_E_BADARG;
   if (mask_kind != 2 && !mask) return SSG_E_BADARG;
   if (workspace_bytes < ssg_loss_workspace_bytes(B, H, W, capacity, ks)) return SSG_E_WORKSPACE;
@@ -451,7 +475,7 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
                        generalization, ssg_sr, ssg_gt, stream);
   if (rc) return rc;
   return ssg_loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
-                           ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, stream);
+                           ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix, stream);
 }
 
 int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,

@@ -18,8 +18,6 @@
 // reference operator's backward), dL/dS + saved S (similarity_map autograd), or
 // S_sr/S_gt for the fused L1 + KL criteria, whose partial sums are also
 // produced here (L1Loss basic_loss.py:66, KLDistanceLoss basic_loss.py:281).
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
-
 #include "ssg_common.hpp"
 
 namespace ssg {
@@ -514,7 +512,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
               v += in ? g : 0.f;
             }
             if (v != 0.f)
-              unsafeAtomicAdd(p.grad + cb0 + (size_t)reflect_idx(my0 - HP + ry, H) * W + reflect_idx(mx0 - HP + rx, W), v);
+              grad_add(p.grad, p.gfix, cb0 + (size_t)reflect_idx(my0 - HP + ry, H) * W + reflect_idx(mx0 - HP + rx, W), v);
           }
         }
         lds_barrier();
@@ -526,7 +524,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
             const int e = m + k * LPJ;
             if (e < P) {
               const int ty = e / KS, tx = e - ty * KS;
-              unsafeAtomicAdd(p.grad + cbase + img_off(ty, tx), gst[e]);
+              grad_add(p.grad, p.gfix, cbase + img_off(ty, tx), gst[e]);
             }
           }
         }
@@ -622,8 +620,8 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
         if ((unsigned)py < (unsigned)ks && (unsigned)px < (unsigned)ks)
           acc = __builtin_fmaf(gt[py * ks + px], tile[(c * ks + hp + kh) * ks + hp + kx] - st, acc);
       }
-    unsafeAtomicAdd(p.grad + ibase + ((size_t)c * H + reflect_idx(e.y - hp + ty, H)) * W + reflect_idx(e.x - hp + tx, W),
-                    -2.f * acc);
+    grad_add(p.grad, p.gfix, ibase + ((size_t)c * H + reflect_idx(e.y - hp + ty, H)) * W + reflect_idx(e.x - hp + tx, W),
+             -2.f * acc);
   }
   // window positions: gA[c,k] = 2 ( A sum G - sum_p G[p] Sz[c,p+k] )
   for (int i = tid; i < C * K2; i += 256) {
@@ -638,8 +636,8 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
         if ((unsigned)xx < (unsigned)ks) acc = __builtin_fmaf(gt[py * ks + px], tile[(c * ks + yy) * ks + xx], acc);
       }
     }
-    unsafeAtomicAdd(p.grad + ibase + ((size_t)c * H + reflect_idx(e.y + kh, H)) * W + reflect_idx(e.x + kx, W),
-                    2.f * (a * sumG - acc));
+    grad_add(p.grad, p.gfix, ibase + ((size_t)c * H + reflect_idx(e.y + kh, H)) * W + reflect_idx(e.x + kx, W),
+             2.f * (a * sumG - acc));
   }
 }
 
@@ -679,6 +677,24 @@ __global__ __launch_bounds__(1024) void ssg_loss_finalize(const float *partials,
   }
 }
 
+// deterministic mode: grad += fixed-point sums (one rounding per pixel), buffer cleared for the next call
+__global__ __launch_bounds__(256) void grad_fix_flush(long long *gfix, float *grad, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const long long v = gfix[i];
+    if (v) {
+      grad[i] += (float)((double)v * (1.0 / (double)GRAD_FIX_SCALE));
+      gfix[i] = 0;
+    }
+  }
+}
+
+int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st) {
+  if (!n) return 0;
+  const unsigned grid = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  hipLaunchKernelGGL(grad_fix_flush, dim3(grid), dim3(256), 0, st, gfix, grad, n);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------ host ----
 template <class G, int KHC>
 static size_t bwd_lds_bytes(int C) {
@@ -693,12 +709,8 @@ template <class G, int KHC>
 static int launch_bwd_tiled(const BwdParams &p, hipStream_t st) {
   const size_t lds = bwd_lds_bytes<G, KHC>(p.C);
   if (lds > 160 * 1024) return -2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)ssg_bwd_tiled<G, KHC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (const int rc = ensure_dynamic_lds(ssg_bwd_tiled<G, KHC>, 160 * 1024, lds_set)) return rc;
   const unsigned grid = bwd_grid(p);
   if (p.n_host == 0) return 0;
   hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(grid), dim3(G::WG), lds, st, p);
@@ -731,11 +743,8 @@ int launch_bwd(const BwdParams &p, hipStream_t st) {
     return launch_bwd_tiled<Geo<49, 13, 7, 256>, 4>(p, st);
   const size_t lds = sizeof(float) * ((size_t)(p.C + 1) * p.ks * p.ks + 256);
   if (lds > 160 * 1024) return -2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)ssg_bwd_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (const int rc = ensure_dynamic_lds(ssg_bwd_generic, 160 * 1024, lds_set)) return rc;
   if (p.n_host == 0) return 0;
   hipLaunchKernelGGL(ssg_bwd_generic, dim3((unsigned)p.n_host), dim3(256), lds, st, p);
   return (int)hipGetLastError();

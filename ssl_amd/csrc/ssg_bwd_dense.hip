@@ -29,8 +29,6 @@
 // pixel and the image band advances by one row.  Cost per (tile, offset): ~200 wave instructions
 // whatever the number of edge pixels, against ~19 k lane-instructions per edge pixel and offset row
 // in the direct kernel.
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
-
 #include "ssg_common.hpp"
 
 namespace ssg {
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
         for (int c = 0; c < C; ++c) {
           const float v = brow[c * RWS + col];
           brow[c * RWS + col] = 0.f;
-          if (ok && v != 0.f && !(p.dbg & 8)) unsafeAtomicAdd(p.grad + (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v);
+          if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v);
         }
       }
     }
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float v = __builtin_fmaf(iu[c][i], vt, gu[c][i]);
-        if (ok && v != 0.f && !(p.dbg & 8)) unsafeAtomicAdd(p.grad + (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v);
+        if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v);
       }
     }
   }
@@ -461,9 +459,8 @@ bool dense_bwd_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 &&
 template <int KS, int KW, int C, int TY, int NCH>
 static int launch_one(const DenseBwdParams &p, hipStream_t st) {
   using G = DenseBwdGeo<KS, KW, C, TY>;
-  const hipError_t e = hipFuncSetAttribute((const void *)ssg_bwd_dense<KS, KW, C, TY, NCH>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes());
-  if (e != hipSuccess) return (int)e;
+  static std::atomic<unsigned long long> lds_set{0};
+  if (const int rc = ensure_dynamic_lds(ssg_bwd_dense<KS, KW, C, TY, NCH>, (int)G::lds_bytes(), lds_set)) return rc;
   hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH>), dim3((unsigned)p.max_tiles, (unsigned)p.qsplit), dim3(64),
                      G::lds_bytes(), st, p);
   return (int)hipGetLastError();

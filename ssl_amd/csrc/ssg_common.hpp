@@ -12,8 +12,10 @@
 // clock per CU).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -138,6 +140,7 @@ enum GradMode : int {
 struct BwdParams {
   const float *img;  // (B,C,H,W)
   float *grad;       // (B,C,H,W), accumulated with fp32 atomics (may be null in GRAD_LOSS: loss only)
+  long long *gfix;   // nullable (B,C,H,W): deterministic mode, the same sums in 2^-40 fixed point (integer atomics)
   const int *edges;
   int estride;
   const int *order;  // nullable (n) int32: job k works on row order[k] (tile-major permutation of the rows)
@@ -178,6 +181,35 @@ __device__ __forceinline__ float criteria_elem(float a, float b, float w1m, floa
   return g;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel,
+// device) -- `done` is the caller's per-kernel bit set of devices -- from any host thread, and report a failure
+// instead of launching into it.
+template <class K>
+inline int ensure_dynamic_lds(K kernel, int bytes, std::atomic<unsigned long long> &done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+
+// One contribution to the image gradient.  Default: hardware fp32 atomic (the order of the additions, hence the
+// last bits of the result, varies from run to run -- like the reference's atomicAdd, similarity.cu:123-128).
+// Deterministic mode (gfix != nullptr): the contribution is rounded to a multiple of 2^-40 and added with a 64-bit
+// INTEGER atomic; integer addition is associative, so the sum does not depend on the order and two runs agree bit
+// for bit.  Range +-2^23, resolution 9e-13 absolute (gradients of this loss are O(1e-3 .. 1)).
+constexpr float GRAD_FIX_SCALE = 1099511627776.f;  // 2^40
+__device__ __forceinline__ void grad_add(float *grad, long long *gfix, size_t idx, float v) {
+  if (gfix)
+    atomicAdd((unsigned long long *)gfix + idx, (unsigned long long)__float2ll_rn(v * GRAD_FIX_SCALE));
+  else
+    unsafeAtomicAdd(grad + idx, v);
+}
+
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), fully inlined
 // (a `#pragma unroll` over the dense kernels' offset loops was NOT honoured: hipcc kept them rolled and
 // indexed the register arrays through M0, s_set_gpr_idx_on)
@@ -215,6 +247,7 @@ struct GrowParams {
 struct DenseBwdParams {
   const float *img;    // (B,C,H,W)
   float *grad;         // (B,C,H,W), accumulated with fp32 atomics
+  long long *gfix;     // nullable: deterministic mode (see grad_add)
   const float *G;      // (n, P) dL/dD rows
   const float *sum_b;  // (n)
   const int *rank;     // (B,H,W) row of every pixel, -1 if not an edge pixel

@@ -357,10 +357,8 @@ int dense_max_tiles(int B, int H, int W, int ks) {
 template <int KS, int KW, int C>
 static int launch_fwd_dense_t(const DenseParams &p, hipStream_t st) {
   const size_t lds = dense_lds_bytes<KS, KW, C>();
-  // (set on every launch: the attribute is per device, and a launch is not where the time goes)
-  const hipError_t e = hipFuncSetAttribute((const void *)ssg_fwd_dense<KS, KW, C>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  static std::atomic<unsigned long long> lds_set{0};
+  if (const int rc = ensure_dynamic_lds(ssg_fwd_dense<KS, KW, C>, (int)lds, lds_set)) return rc;
   hipLaunchKernelGGL((ssg_fwd_dense<KS, KW, C>), dim3((unsigned)p.max_tiles * p.nimg), dim3(256), lds, st, p);
   return (int)hipGetLastError();
 }

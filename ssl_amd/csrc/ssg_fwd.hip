@@ -425,12 +425,8 @@ template <class G, bool MERGED>
 static int launch_fwd_tiled(const FwdParams &p, hipStream_t st) {
   const size_t lds = fwd_lds_bytes<G, MERGED>(p.C);
   if (lds > 160 * 1024) return -2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)ssg_fwd_tiled<G, MERGED>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (const int rc = ensure_dynamic_lds(ssg_fwd_tiled<G, MERGED>, 160 * 1024, lds_set)) return rc;
   // tile order pads every image's jobs to a multiple of JOBS
   const long per_img = p.order ? ((long)p.n_host + G::JOBS - 1) / G::JOBS * G::JOBS : (long)p.n_host;
   const long njobs = per_img * p.nimg;
@@ -466,11 +462,8 @@ int launch_fwd(const FwdParams &p_in, hipStream_t st) {
     return launch_fwd_tiled<Geo<49, 13, 7, 128>, false>(p, st);
   const size_t lds = sizeof(float) * ((size_t)p.C * p.ks * p.ks + 2 + 512);
   if (lds > 160 * 1024) return -2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)ssg_fwd_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (const int rc = ensure_dynamic_lds(ssg_fwd_generic, 160 * 1024, lds_set)) return rc;
   const long njobs = (long)p.n_host * p.nimg;
   if (njobs == 0) return 0;
   hipLaunchKernelGGL(ssg_fwd_generic, dim3((unsigned)njobs), dim3(256), lds, st, p);

@@ -78,11 +78,14 @@ class SSGLoss(nn.Module):
     copied to pinned host memory asynchronously and looked at one step later, so nothing stalls;
     the step that overflowed used the first `capacity` edge pixels only and is reported with a
     warning (on_overflow='grow', default) or a RuntimeError (on_overflow='raise').
+
+    deterministic=True makes the gradient bit-reproducible from run to run (fixed-point integer
+    accumulation instead of fp32 atomics; include/ssg_hip.h `ssg_grad_fix_bytes`).
     """
 
     def __init__(self, kernel_size_search=25, kernel_size_window=9, sigma=0.004, generalization=True,
                  loss_weight_l1=1e3, loss_weight_kl=1e3, mask_stride=0, eps=1e-10, lap_threshold=20.0,
-                 capacity=None, on_overflow='grow'):
+                 capacity=None, on_overflow='grow', deterministic=None):
         super().__init__()
         if on_overflow not in ('grow', 'raise'):
             raise ValueError(f"on_overflow must be 'grow' or 'raise', got {on_overflow!r}")
@@ -92,6 +95,7 @@ class SSGLoss(nn.Module):
         self.mask_stride, self.lap_threshold = mask_stride, lap_threshold
         self.capacity = capacity
         self.on_overflow = on_overflow
+        self.deterministic = deterministic   # None: SSG_DETERMINISTIC env; True: bit-reproducible gradients
         self._pending = None       # (event, pinned count, capacity used) of the previous call
 
     def _check_previous(self, wait=False):
@@ -131,4 +135,5 @@ class SSGLoss(nn.Module):
             ev.record()
             self._pending = (ev, host, cap)
         return engine.ssg_loss(sr, gt.detach(), el.edges, el.counts, cap, self.ks, self.kw, self.sigma, self.eps,
-                               self.generalization, self.w_l1, self.w_kl, order=el.order, fwd=el.fwd)
+                               self.generalization, self.w_l1, self.w_kl, order=el.order, fwd=el.fwd,
+                               deterministic=self.deterministic)

@@ -1005,3 +1005,47 @@ def test_f11_datapath_kernels_bit_exact(dev, golden):
     ref = orc.ssg_loss(np.zeros((2, 3, 8, 8)), np.zeros((2, 3, 8, 8)), mk[:, 0].cpu().numpy(), 5, 3, 0.5, 1.0, 1.0,
                        want_grad=False)
     assert bool(torch.isfinite(a)) and bool(torch.isfinite(b)) and int(mk.sum()) == ref["n_edges"]
+
+
+def test_deterministic_backward_is_bit_reproducible(dev):
+    """deterministic=True: two runs of the same step give torch.equal gradients (fixed-point integer accumulation),
+    and the gradient stays within 1e-6 max|grad| of the default fp32-atomic accumulation; the default mode is the
+    reference's behaviour (atomicAdd order, similarity.cu:123-128)."""
+    from ssl_amd import SSGLoss, engine, synth
+    sr, gt, mask = synth.make_batch(4, 128, 128)
+    tsr, tgt, tm = T(sr, dev), T(gt, dev), T(mask, dev)
+    n = int(mask.sum())
+    for thr in (28, 0):                          # split (dense + direct kernels) and direct-only backward
+        prev = engine.set_dense_threshold(thr)
+        try:
+            grads = []
+            for rep in range(3):
+                step = engine.LossStep(4, 3, 128, 128, 25, 9, 0.004, 1e-10, True, 1e3, 1e3, device=dev, capacity=n + 64,
+                                       deterministic=True)
+                loss, grad = step(tsr, tgt, tm)
+                grads.append(grad.clone())
+            assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+            ref = engine.LossStep(4, 3, 128, 128, 25, 9, 0.004, 1e-10, True, 1e3, 1e3, device=dev, capacity=n + 64,
+                                  deterministic=False)
+            _, g0 = ref(tsr, tgt, tm)
+            assert float((g0 - grads[0]).abs().max()) <= 1e-6 * float(g0.abs().max())
+        finally:
+            engine.set_dense_threshold(prev)
+    # through autograd (module and map)
+    outs = []
+    for rep in range(2):
+        x = tsr.clone().requires_grad_(True)
+        a, b = SSGLoss(25, 9, 0.004, True, 1e3, 1e3, capacity=n + 64, deterministic=True)(x, tgt, tm)
+        (a + b).backward()
+        outs.append(x.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+    el = engine.edge_list(mask=tm[:1])
+    n1 = int(el.counts[0])
+    cot = torch.randn((n1, 625), device=dev)
+    outs = []
+    for rep in range(2):
+        x = tsr[:1].clone().requires_grad_(True)
+        s = engine.ssg_map(x, el.edges, el.counts, n1, 25, 9, 1.0, order=el.order, fwd=el.fwd, deterministic=True)
+        (s * cot).sum().backward()
+        outs.append(x.grad.clone())
+    assert torch.equal(outs[0], outs[1])
