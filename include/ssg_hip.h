@@ -178,9 +178,9 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W,
  * gradient with hardware fp32 atomics: the order of the additions, hence the last bits of the result, varies
  * from run to run (as with the reference's atomicAdd, similarity.cu:123-128).  Passing `grad_fix` --
  * ssg_grad_fix_bytes(B,C,H,W) bytes of device memory, contents irrelevant -- to the backward entry points makes
- * the result bit-reproducible: contributions are rounded to multiples of 2^-40 and summed with 64-bit integer
- * atomics (integer addition is associative), then folded into grad once per pixel.  Range +-2^23, absolute
- * resolution 9e-13. */
+ * the result bit-reproducible: contributions are rounded to multiples of a power of two chosen on the device
+ * from the largest |dL/dD| of the call (2^-38 of it: 14 bits finer than an fp32 sum of the same terms) and summed
+ * with 64-bit integer atomics (integer addition is associative), then folded into grad once per pixel. */
 size_t ssg_grad_fix_bytes(int B, int C, int H, int W);
 
 /* ---------------------------------------------------------------- (D) ----

@@ -52,6 +52,8 @@ int launch_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C
                         const int *params, hipStream_t st);
 int launch_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, hipStream_t st);
 int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st);
+int launch_grad_fix_bound(const BwdParams &p, hipStream_t st);
+int launch_grad_fix_reduce(const float *part, int n, long long *gfix, size_t n_fix, hipStream_t st);
 }  // namespace ssg
 
 using namespace ssg;
@@ -121,7 +123,7 @@ static int bwd_qsplit() {
 // Scratch of the split backward (ssg_grad_rows -> dense-tile kernel + direct kernel): G (n, k_s^2), sum_b (n).
 static size_t split_scratch_bytes(int n_rows, int ks) {
   const size_t n = (size_t)(n_rows > 0 ? n_rows : 1);
-  return align_up(sizeof(float) * n * ks * ks, 256) + align_up(sizeof(float) * n, 256);
+  return align_up(sizeof(float) * n * ks * ks, 256) + 2 * align_up(sizeof(float) * n, 256);   // G, sum_b, max|G| parts
 }
 
 // Backward over a forward plan: G rows (+ criteria sums) by ssg_grad_rows, the dense tiles by the shared-term
@@ -129,6 +131,7 @@ static size_t split_scratch_bytes(int n_rows, int ks) {
 static int split_backward(BwdParams p, const int *rank, const int *plan, void *scratch, hipStream_t st) {
   float *G = (float *)scratch;
   float *sum_b = (float *)((char *)scratch + align_up(sizeof(float) * (size_t)p.n_host * p.ks * p.ks, 256));
+  float *gmax_part = (float *)((char *)sum_b + align_up(sizeof(float) * (size_t)(p.n_host > 0 ? p.n_host : 1), 256));
   GrowParams g{};
   g.mode = p.mode;
   g.gin = p.gin;
@@ -145,8 +148,13 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   g.G = p.grad ? G : nullptr;
   g.sum_b = p.grad ? sum_b : nullptr;
   g.partials = p.partials;
+  g.gmax_part = p.gfix ? gmax_part : nullptr;
   int rc = (dbg_mask() & (1 << 29)) ? 0 : launch_grad_rows(g, p.ks, p.kw, st);
   if (rc || !p.grad) return rc;
+  if (p.gfix) {
+    rc = launch_grad_fix_reduce(gmax_part, (int)grow_grid(p.n_host), p.gfix, (size_t)p.B * p.C * p.H * p.W, st);
+    if (rc) return rc;
+  }
   const float *grows = p.mode == GRAD_D ? p.gin : G;
   DenseBwdParams d{};
   d.img = p.img;
@@ -182,7 +190,7 @@ static int det_begin(BwdParams &p, void *grad_fix, hipStream_t st) {
   p.gfix = nullptr;
   if (!grad_fix || !p.grad) return 0;
   p.gfix = (long long *)grad_fix;
-  return (int)hipMemsetAsync(grad_fix, 0, sizeof(long long) * (size_t)p.B * p.C * p.H * p.W, st);
+  return (int)hipMemsetAsync(grad_fix, 0, sizeof(long long) * ((size_t)p.B * p.C * p.H * p.W + 8), st);
 }
 static int det_end(const BwdParams &p, hipStream_t st) {
   if (!p.gfix) return 0;
@@ -377,12 +385,16 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W, const int *ed
   p.dbg = (dbg_mask() >> 8) & 0xff;
   int rc = det_begin(p, grad_fix, (hipStream_t)stream);
   if (rc) return rc;
-  rc = split_ok(ks, kw, C, rank_map, fwd_plan, scratch) ? split_backward(p, rank_map, fwd_plan, scratch, (hipStream_t)stream)
-                                                         : launch_bwd(p, (hipStream_t)stream);
+  if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
+    rc = split_backward(p, rank_map, fwd_plan, scratch, (hipStream_t)stream);
+  } else {
+    if (p.gfix) rc = launch_grad_fix_bound(p, (hipStream_t)stream);
+    if (!rc) rc = launch_bwd(p, (hipStream_t)stream);
+  }
   return rc ? rc : det_end(p, (hipStream_t)stream);
 }
 
-size_t ssg_grad_fix_bytes(int B, int C, int H, int W) { return sizeof(long long) * (size_t)B * C * H * W; }
+size_t ssg_grad_fix_bytes(int B, int C, int H, int W) { return sizeof(long long) * ((size_t)B * C * H * W + 8); }
 
 static size_t partials_bytes(int B, int H, int W, int n_rows) {
   return align_up(2 * sizeof(float) * bwd_max_partials(B, H, W, n_rows) + 64, 256);
@@ -433,7 +445,8 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
     rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st);
     nparts = (int)grow_grid(n_rows);
   } else {
-    rc = launch_bwd(p, st);
+    if (p.gfix) rc = launch_grad_fix_bound(p, st);
+    if (!rc) rc = launch_bwd(p, st);
     nparts = (int)bwd_grid(p);
   }
   if (!rc) rc = det_end(p, st);

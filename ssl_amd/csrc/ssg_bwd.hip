@@ -128,6 +128,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   const float *zrow = zero + HK;
   float l1p = 0.f, klp = 0.f;
   const bool need_grad = p.grad != nullptr;
+  const float gsc = grad_fix_scale(p.gfix, (size_t)p.B * p.C * p.H * p.W);
 
   // Barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global
   // atomics (a __syncthreads() would drain vmcnt and stall every barrier behind the atomics'
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
               v += in ? g : 0.f;
             }
             if (v != 0.f)
-              grad_add(p.grad, p.gfix, cb0 + (size_t)reflect_idx(my0 - HP + ry, H) * W + reflect_idx(mx0 - HP + rx, W), v);
+              grad_add(p.grad, p.gfix, cb0 + (size_t)reflect_idx(my0 - HP + ry, H) * W + reflect_idx(mx0 - HP + rx, W), v, gsc);
           }
         }
         lds_barrier();
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
             const int e = m + k * LPJ;
             if (e < P) {
               const int ty = e / KS, tx = e - ty * KS;
-              grad_add(p.grad, p.gfix, cbase + img_off(ty, tx), gst[e]);
+              grad_add(p.grad, p.gfix, cbase + img_off(ty, tx), gst[e], gsc);
             }
           }
         }
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
   __syncthreads();
   if (tid == 0) gt[hp * ks + hp] = 0.f;  // exact: the centre offset has A - B == 0 (see the tiled kernel)
   const size_t ibase = (size_t)e.b * C * H * W;
+  const float gsc = grad_fix_scale(p.gfix, (size_t)p.B * p.C * p.H * p.W);
   for (int i = tid; i < C * P; i += 256) {
     const int c = i / P, r = i - c * P, ry = r / ks, rx = r - ry * ks;
     tile[i] = p.img[ibase + ((size_t)c * H + reflect_idx(e.y - hp + ry, H)) * W + reflect_idx(e.x - hp + rx, W)];
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
           acc = __builtin_fmaf(gt[py * ks + px], tile[(c * ks + hp + kh) * ks + hp + kx] - st, acc);
       }
     grad_add(p.grad, p.gfix, ibase + ((size_t)c * H + reflect_idx(e.y - hp + ty, H)) * W + reflect_idx(e.x - hp + tx, W),
-             -2.f * acc);
+             -2.f * acc, gsc);
   }
   // window positions: gA[c,k] = 2 ( A sum G - sum_p G[p] Sz[c,p+k] )
   for (int i = tid; i < C * K2; i += 256) {
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
       }
     }
     grad_add(p.grad, p.gfix, ibase + ((size_t)c * H + reflect_idx(e.y + kh, H)) * W + reflect_idx(e.x + kx, W),
-             2.f * (a * sumG - acc));
+             2.f * (a * sumG - acc), gsc);
   }
 }
 
@@ -677,15 +679,70 @@ __global__ __launch_bounds__(1024) void ssg_loss_finalize(const float *partials,
   }
 }
 
-// deterministic mode: grad += fixed-point sums (one rounding per pixel), buffer cleared for the next call
-__global__ __launch_bounds__(256) void grad_fix_flush(long long *gfix, float *grad, size_t n) {
+// deterministic mode: grad += fixed-point sums (one rounding per pixel)
+__global__ __launch_bounds__(256) void grad_fix_flush(const long long *gfix, float *grad, size_t n) {
+  const double inv = 1.0 / (double)grad_fix_scale(gfix, n);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const long long v = gfix[i];
-    if (v) {
-      grad[i] += (float)((double)v * (1.0 / (double)GRAD_FIX_SCALE));
-      gfix[i] = 0;
-    }
+    if (v) grad[i] += (float)((double)v * inv);
   }
+}
+
+// deterministic mode on the direct-only path (no ssg_grad_rows pass): an upper bound of |G| before the backward
+// kernel runs.  GRAD_D: max|gin|; GRAD_S: G = -(s kfac)(g - sum g s) with 0 <= s <= 1, sum s <= 1 -> 2 kfac max|g|;
+// GRAD_LOSS: |s g| <= w1m + w2m (s, t <= 1) -> 4 kfac (w1m + w2m).
+__global__ __launch_bounds__(256) void grad_fix_bound_kernel(BwdParams p, size_t n_fix) {
+  const int nrows = rows_to_do(p.n_dev, p.n_host);
+  const int P = p.ks * p.ks;
+  const float kfac = 1.f / (p.sigma * (float)(p.C * p.kw * p.kw));
+  if (p.mode == GRAD_LOSS) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const float invM = 1.f / ((float)(nrows > 0 ? nrows : 1) * (float)P);
+      const float u1 = p.upstream ? fabsf(p.upstream[0]) : 1.f, u2 = p.upstream ? fabsf(p.upstream[1]) : 1.f;
+      grad_fix_bound(p.gfix, n_fix, 4.f * kfac * (fabsf(p.w_l1) * u1 + fabsf(p.w_kl) * u2) * invM);
+    }
+    return;
+  }
+  const size_t n = (size_t)nrows * P;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(p.gin[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one atomic per workgroup, at most 512 of them
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    grad_fix_bound(p.gfix, n_fix, p.mode == GRAD_S ? 2.f * kfac * m : m);
+  }
+}
+
+// max over the per-workgroup maxima of ssg_grad_rows -> the bound word (one workgroup)
+__global__ __launch_bounds__(1024) void grad_fix_reduce(const float *part, int n, long long *gfix, size_t n_fix) {
+  __shared__ float sm[16];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, sm[k]);
+    *(unsigned *)(gfix + n_fix) = __float_as_uint(m);
+  }
+}
+
+int launch_grad_fix_reduce(const float *part, int n, long long *gfix, size_t n_fix, hipStream_t st) {
+  hipLaunchKernelGGL(grad_fix_reduce, dim3(1), dim3(1024), 0, st, part, n, gfix, n_fix);
+  return (int)hipGetLastError();
+}
+
+int launch_grad_fix_bound(const BwdParams &p, hipStream_t st) {
+  const size_t n = (size_t)p.n_host * p.ks * p.ks;
+  const unsigned grid = p.mode == GRAD_LOSS ? 1u : (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL(grad_fix_bound_kernel, dim3(grid), dim3(256), 0, st, p, (size_t)p.B * p.C * p.H * p.W);
+  return (int)hipGetLastError();
 }
 
 int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st) {

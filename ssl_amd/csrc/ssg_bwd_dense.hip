@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
   const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
   const int ty0 = (tr / tx_n) * TY, tx0 = (tr % tx_n) * TX;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
+  const float gsc = grad_fix_scale(p.gfix, (size_t)p.B * C * H * W);
   const int qy0 = (KS * (int)blockIdx.y) / p.qsplit, qy1 = (KS * ((int)blockIdx.y + 1)) / p.qsplit;
 
   // ---- census of the tile's edge pixels (row-major inside the tile) ----
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
         for (int c = 0; c < C; ++c) {
           const float v = brow[c * RWS + col];
           brow[c * RWS + col] = 0.f;
-          if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v);
+          if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
         }
       }
     }
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float v = __builtin_fmaf(iu[c][i], vt, gu[c][i]);
-        if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v);
+        if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
       }
     }
   }

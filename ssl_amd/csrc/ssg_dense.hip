@@ -46,6 +46,11 @@ struct DenseParams {
 };
 
 constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1) (8 for k_w = 9, 4 for k_w = 13)
+// Row stride of the H buffers (horizontal sums on the 16 x 32 centre columns of U).  The tile's edge pixels read
+// them at (row ey + k, column ex): with stride 32 every pixel of a VERTICAL edge line falls on one LDS bank (half of
+// the kernel's LDS cycles were conflict replays, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.49); with 44 two
+// pixels collide only if dx = -12 dy (mod 32), which no edge curve does inside an 8-row tile.
+constexpr int DT_HS = 44;
 
 template <int KS, int KW, int C>
 __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
@@ -59,14 +64,14 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *reg = smem;                       // [C][RH][RS]
   float *F = reg + C * RH * RS;            // [UH][UW]   sum_c I^2 on U
-  float *HF = F + UH * UW;                 // [UH][DT_X] full-window horizontal sums of F
-  float *Hb = HF + UH * DT_X;              // [4][UH][DT_X] per-wave horizontal sums of E_q
+  float *HF = F + UH * UW;                 // [UH][DT_HS] full-window horizontal sums of F
+  float *Hb = HF + UH * DT_HS;             // [4][UH][DT_HS] per-wave horizontal sums of E_q
   // per-wave partial row sums (fp64, see ssg_fwd.hip): wave w's NE_MAX doubles reuse ITS OWN H buffer once its
   // offset rows are done (same size, wave-private, so no other wave is still reading it)
   double *rsum = (double *)Hb;                    // [4][RSTR], RSTR = one H buffer in doubles
-  constexpr int RSTR = UH * DT_X / 2;
+  constexpr int RSTR = UH * DT_HS / 2;
   static_assert(NE_MAX <= RSTR, "row sums alias the wave's H buffer");
-  int *elist = (int *)(Hb + 4 * UH * DT_X);       // [NE_MAX][3] (ey, ex, row)
+  int *elist = (int *)(Hb + 4 * UH * DT_HS);      // [NE_MAX][3] (ey, ex, row)
   int *misc = elist + NE_MAX * 3;          // [8]: wave counts, n_e
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     float t = 0.f;
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) t += F[ur * UW + tc + kx];
-    HF[i] = t;
+    HF[ur * DT_HS + tc] = t;
   }
   __syncthreads();
 
@@ -156,8 +161,8 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   float Fr[LW];  // |I|^2 of the lane's LW pixels (complement of the columns that leave the area)
 #pragma unroll
   for (int i = 0; i < LW; ++i) Fr[i] = F[r * UW + 8 * g + i];
-  float *hb = Hb + wv * UH * DT_X;
-  float *hrow = hb + r * DT_X + 8 * g;
+  float *hb = Hb + wv * UH * DT_HS;
+  float *hrow = hb + r * DT_HS + 8 * g;
   // exp(x) = 2^(x log2 e), constant folded (see ssg_fwd.hip)
   const float nk = (float)(-1.4426950408889634 / ((double)(C * KW * KW) * (double)p.sigma));
   double rs[NCHUNK];
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     eon[ck] = e < n_e;
     const int ec = eon[ck] ? e : 0;
     const int ey = elist[3 * ec], ex = elist[3 * ec + 1];
-    hoff[ck] = ey * DT_X + ex;  // window row k of the centre is U-row ey + k
+    hoff[ck] = ey * DT_HS + ex;  // window row k of the centre is U-row ey + k
     orow[ck] = (size_t)elist[3 * ec + 2] * P;
   }
 
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
       if (ck * 64 < n_e && (ylo > -HK || yhi < HK)) {
         const float *fc = HF + hoff[ck];
 #pragma unroll
-        for (int k = 0; k < KW; ++k) av[ck] = __builtin_fmaf(1.f - wgt[k], fc[k * DT_X], av[ck]);
+        for (int k = 0; k < KW; ++k) av[ck] = __builtin_fmaf(1.f - wgt[k], fc[k * DT_HS], av[ck]);
       }
     }
     const float *rq = reg + (r + qyi) * RS + 8 * g;  // + c*RH*RS + column (i + qxi)
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
           const float *hc = hb + hoff[ck];
           float hv[KW];
 #pragma unroll
-          for (int k = 0; k < KW; ++k) hv[k] = hc[k * DT_X];
+          for (int k = 0; k < KW; ++k) hv[k] = hc[k * DT_HS];
           float d = av[ck];
 #pragma unroll
           for (int k = 0; k < KW; ++k) d = __builtin_fmaf(wgt[k], hv[k], d);
@@ -341,7 +346,7 @@ static size_t dense_lds_bytes() {
   constexpr int DT_Y = 16 - 2 * (KW / 2);
   constexpr int HALO = KS / 2 + KW / 2, RH = DT_Y + 2 * HALO, RS = DT_X + 2 * HALO + 1;
   constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X;
-  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_X + 4 * UH * DT_X) + sizeof(int) * (NE * 3 + 8);
+  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_HS + 4 * UH * DT_HS) + sizeof(int) * (NE * 3 + 8);
 }
 
 bool dense_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }

@@ -20,11 +20,11 @@ namespace ssg {
 template <int KS, int KW>
 __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
   constexpr int P = KS * KS, HP = KS / 2, HK = KW / 2, EPL = (P + 63) / 64;
-  __shared__ float sred[8];
+  __shared__ float sred[12];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
   const int n = blockIdx.x * 4 + wv;
-  float l1p = 0.f, klp = 0.f;
+  float l1p = 0.f, klp = 0.f, gmax = 0.f;
   if (n < nrows) {
     const size_t base = (size_t)n * P;
     float va[EPL], vg[EPL];
@@ -58,13 +58,14 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
 #pragma unroll
       for (int k = 0; k < EPL; ++k) va[k] = -(va[k] * kfac) * (vg[k] - dot);
     }
-    float sb = 0.f;
+    float sb = 0.f, gm = 0.f;
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const int e = lane + 64 * k;
       if (e < P) {
         const int py = e / KS, px = e - py * KS;
         if (e == HP * KS + HP) va[k] = 0.f;
+        gm = fmaxf(gm, fabsf(va[k]));
         const bool border = py < HK || py > KS - 1 - HK || px < HK || px > KS - 1 - HK;
         if (border) sb += va[k];
         if (p.G && p.mode != GRAD_D) p.G[base + e] = va[k];
@@ -74,6 +75,14 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
       sb = wave_sum(sb);
       if (lane == 0) p.sum_b[n] = sb;
     }
+    gmax = gm;
+  }
+  if (p.gmax_part) {  // deterministic mode: the fixed-point scale follows from the largest |G| (ssg_common.hpp)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+    if (lane == 0) sred[8 + wv] = gmax;
+    __syncthreads();
+    if (threadIdx.x == 0) p.gmax_part[blockIdx.x] = fmaxf(fmaxf(sred[8], sred[9]), fmaxf(sred[10], sred[11]));
   }
   if (p.mode == GRAD_LOSS) {
     l1p = wave_sum(l1p);
