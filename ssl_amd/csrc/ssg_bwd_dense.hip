@@ -47,14 +47,24 @@ __device__ __forceinline__ void step_fence() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int KS, int KW, int C, int TY>
+// RG = column groups of the lane map: 4 -> one wave covers the 16 U-rows (16 x 4 lanes); 8 -> a wave covers 8 U-rows
+// (8 x 8 lanes) and TWO waves (blockIdx.z = which half) share a tile: half the bands (8 rows) per wave, so that 8
+// waves fit a CU's LDS and every SIMD holds two -- a lone wave issues a VALU instruction only every ~4 cycles.
+template <int KS, int KW, int C, int TY, int RG = 4>
 struct DenseBwdGeo {
   static constexpr int TX = 32, HP = KS / 2, HK = KW / 2, HALO = HP + HK, P = KS * KS;
   static constexpr int UH = TY + 2 * HK, UW = TX + 2 * HK;    // tile grown by the window halo
-  static constexpr int NPX = UW / 4, NPXP = (NPX + 1) & ~1;   // pixels per lane (and padded)
+  static constexpr int NPX = UW / RG;                         // pixels per lane
+  // (padded) pixels per lane in a prefix row; RG = 8: no pad and 40-float rows -- the half-wave's 4 rows x 8 groups
+  // then fall on different banks (48-float rows of 6-float groups: 41 % of the LDS cycles were conflict replays)
+  static constexpr int NPXP = RG == 8 ? NPX : ((NPX + 1) & ~1);
+  static constexpr int RR = 64 / RG, NHALF = UH / RR;         // U-rows per wave, waves per tile
   static constexpr int RW = UW + KS - 1, RH = UH + KS - 1;    // gradient / image region
-  static constexpr int RWS = RW | 1;                          // odd row stride: rows fall on distinct banks
-  static constexpr int BR = 16;                               // band rows
+  static constexpr int RWS = RW | 1;                          // channel stride inside a band row
+  // band row stride: RG = 4: C odd strides; RG = 8: = 8 (mod 16), the 4 slots x 8 groups (5 floats apart) of a
+  // half-wave on 32 different banks
+  static constexpr int BRS = RG == 8 ? ((C * RWS - 8 + 15) / 16 * 16 + 8) : C * RWS;
+  static constexpr int BR = RR;                               // band rows
   static constexpr int HG = 64 / TY, HOUT = (UW + HG - 1) / HG;
   // padded G field row.  The horizontal-sum lanes (tile row hty, group hg) read dword hty*GQS + HOUT*hg + m: with
   // GQS = 20 (mod 32) for (TY 8, HOUT 5) / 8 (mod 32) for (TY 4, HOUT 3) the 32 lanes of a half-wave fall on 32
@@ -62,25 +72,26 @@ struct DenseBwdGeo {
   static constexpr int GQS_MIN = (HG * HOUT > UW ? HG * HOUT : UW) + 2 * HK;
   static constexpr int GQS_RES = TY == 8 ? 20 : 8;
   static constexpr int GQS = GQS_MIN + ((GQS_RES - GQS_MIN % 32) + 32) % 32;
-  static constexpr int PS = 4 * NPXP;                         // prefix row
+  static constexpr int PS = RG * NPXP;                        // prefix row
   static constexpr int FSZ = TY * GQS + (TY + 1) * PS;        // one field + its prefix rows (two copies: steps alternate)
   static constexpr int NE_MAX = TY * TX, NCHUNK = NE_MAX / 64;
   static constexpr int NG = KS / 4;                           // full groups of 4 offsets per offset row
   static constexpr int CPL = (RW + 63) / 64;                  // region columns per lane (row loads / flushes)
-  static_assert(UH == 16 && UW % 4 == 0, "lane map: 16 U-rows x 4 column groups");
+  static_assert(UH == 16 && UW % RG == 0 && (RG == 4 || RG == 8), "lane map: 16 x 4 or 2 x (8 x 8)");
   static_assert(KS % 4 == 1, "offset rows are consumed as groups of 4 + 1");
   static_assert(64 % TY == 0 && TY <= 8, "prefix lanes: tile row in the low lane bits");
   static constexpr size_t lds_bytes() {
-    return sizeof(float) * (size_t)(2 * BR * C * RWS + 2 * FSZ + 4);
+    return sizeof(float) * (size_t)(2 * BR * BRS + 2 * FSZ + 4);
   }
 };
 
 // NCH = 64-pixel chunks of the tile's edge-pixel list this instantiation carries per offset step; a wave
 // whose tile needs another count leaves at once (every instantiation is launched over the same tile list), so
 // the offset loop is free of control flow.
-template <int KS, int KW, int C, int TY, int NCH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* <= 5 waves per CU fit the LDS anyway; 512 registers: no scratch */ void ssg_bwd_dense(DenseBwdParams p) {
-  using G = DenseBwdGeo<KS, KW, C, TY>;
+template <int KS, int KW, int C, int TY, int NCH, int RG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 : 1, RG == 8 ? 2 : 1))) void ssg_bwd_dense(DenseBwdParams p) {
+  using G = DenseBwdGeo<KS, KW, C, TY, RG>;
+  constexpr int RR = G::RR, RMASK = RR - 1, BRS = G::BRS;
   constexpr int TX = G::TX, HP = G::HP, HK = G::HK, HALO = G::HALO, P = G::P;
   constexpr int UW = G::UW, NPX = G::NPX, NPXP = G::NPXP, RW = G::RW, RH = G::RH, RWS = G::RWS;
   constexpr int HOUT = G::HOUT, GQS = G::GQS, PS = G::PS, NCHUNK = G::NCHUNK, NG = G::NG, CPL = G::CPL;
@@ -91,12 +102,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *imgb = smem;                       // [16][C][RWS] image band: region rows q_y .. q_y+15
-  float *grb = imgb + 16 * C * RWS;         // [16][C][RWS] gradient band, same rows
+  float *grb = imgb + RR * BRS;             // [RR][BRS >= C*RWS] gradient band, same rows
   // two copies (offset steps alternate) of { [TY][GQS] G[.,q] on the tile, 2*HK zeros left of every row;
   //                                          [TY+1][PS] vertical prefix of the horizontal sums (row 0 = 0) }
-  float *fld = grb + 16 * C * RWS;
+  float *fld = grb + RR * BRS;
   int *elist = (int *)imgb;  // [NE_MAX][2] (field offset, row): prologue only, the image band is filled afterwards
-  static_assert(2 * G::NE_MAX <= 16 * C * RWS, "edge list aliases the image band");
+  static_assert(2 * G::NE_MAX <= 2 * RR * BRS, "edge list aliases the bands");
 
   const int lane = threadIdx.x;
   const int tslot = blockIdx.x;
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
   }
   if (n_e <= 64 * NCH_LO || n_e > 64 * NCH) return;
   for (int i = lane; i < 2 * FSZ + 4; i += 64) fld[i] = 0.f;  // fields (pads stay 0) and prefix rows 0
-  for (int i = lane; i < 16 * C * RWS; i += 64) grb[i] = 0.f;
+  for (int i = lane; i < RR * BRS; i += 64) grb[i] = 0.f;
   __builtin_amdgcn_wave_barrier();
 
   int epos[NCH];
@@ -140,11 +151,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
     const bool on = e < n_e;
     epos[ck] = on ? elist[2 * e] : DUMMY;
     erow[ck] = on ? elist[2 * e + 1] : elist[1];
-    gp[ck] = p.G + (size_t)erow[ck] * P;
+    gp[ck] = p.G + ((p.dbg & 16) ? (size_t)0 : (size_t)erow[ck] * P);   // (profiling: bit 4 = every lane streams row 0)
   }
 
   // lane roles: main (U-row r, column group g); prefix (tile row hty, column group hg)
-  const int r = lane >> 2, g = lane & 3;
+  const int g = lane % RG, r = RR * (int)blockIdx.z + lane / RG;  // U-row r of the tile, column group g
   const int hty = lane % TY, hg = lane / TY;
   const float m1 = hty >= 1 ? 1.f : 0.f, m2 = hty >= 2 ? 1.f : 0.f, m4 = hty >= 4 ? 1.f : 0.f;
   const int hsrc = hty * GQS + HOUT * hg;  // (offsets relative to a copy's base)
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
     }
   };
   auto store_img_row = [&](int rho, const float (&v)[C][CPL]) {
-    float *dst = imgb + (rho & 15) * C * RWS;
+    float *dst = imgb + (rho & RMASK) * BRS;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       const int col = lane + 64 * k;
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
   };
   // one finished row of the gradient band -> HBM (reflect fold by index mirroring), band row cleared
   auto flush_row = [&](int rho) {
-    float *brow = grb + (rho & 15) * C * RWS;
+    float *brow = grb + (rho & RMASK) * BRS;
     const int py = ty0 - HALO + rho;
     const int gy = reflect_idx(py, H);
     const bool yok = gy >= 0 && gy < H;
@@ -258,7 +269,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
     }
   };
 
-  for (int rho = qy0; rho < qy0 + 16; ++rho) {
+  const int r0 = RR * (int)blockIdx.z;  // first U-row of this wave: its bands hold region rows r0 + q_y .. + RR - 1
+  for (int rho = r0 + qy0; rho < r0 + qy0 + RR; ++rho) {
     float v[C][CPL];
     load_img_row(rho, v);
     store_img_row(rho, v);
@@ -317,15 +329,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
     // (next row's prefetches run unconditionally on clamped rows: the offset loop stays branch-free)
     const int qyn = qyi + 1 < KS ? qyi + 1 : KS - 1;
     float nrow[C][CPL];
-    load_img_row(qyi + 16 < RH ? qyi + 16 : RH - 1, nrow);
+    load_img_row(r0 + qyi + RR < RH ? r0 + qyi + RR : RH - 1, nrow);
     const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
     const float ymask = (ylo > -HK || yhi < HK) ? 1.f : 0.f;
     int pa, pb;
     prefix_rows(ylo, yhi, pa, pb);
     float *fe = fld + (qyi & 1) * FSZ, *fo = fld + ((qyi & 1) ^ 1) * FSZ;  // copies of the even / odd q_x of this row
-    const int slr = (r + qyi) & 15;
-    const float *ib = imgb + slr * C * RWS + NPX * g;
-    float *gb = grb + slr * C * RWS + NPX * g;
+    const int slr = (r + qyi) & RMASK;
+    const float *ib = imgb + slr * BRS + NPX * g;
+    float *gb = grb + slr * BRS + NPX * g;
     float w[C][NPX], gr[C][NPX];
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -416,11 +428,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
 #pragma unroll
       for (int c = 0; c < C; ++c) gb[c * RWS + KS - 1 + i] += gr[c][(i + KS - 1) % NPX];
     __builtin_amdgcn_wave_barrier();
-    flush_row(qyi);
-    store_img_row(qyi + 16, nrow);
+    flush_row(r0 + qyi);
+    store_img_row(r0 + qyi + RR, nrow);
     __builtin_amdgcn_wave_barrier();
   }
-  for (int rho = qy1; rho < qy1 + 15; ++rho) flush_row(rho);
+  for (int rho = r0 + qy1; rho < r0 + qy1 + RR - 1; ++rho) flush_row(rho);
 
   // ---- the lane's own pixels: + I * sum_q V_q (Box(sum_b) - sum of the border W_q), then to HBM ----
   float vbox[NPX];
@@ -457,22 +469,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))  /* 
 // ------------------------------------------------------------------ host ----
 bool dense_bwd_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }
 
-template <int KS, int KW, int C, int TY, int NCH>
+template <int KS, int KW, int C, int TY, int NCH, int RG>
 static int launch_one(const DenseBwdParams &p, hipStream_t st) {
-  using G = DenseBwdGeo<KS, KW, C, TY>;
+  using G = DenseBwdGeo<KS, KW, C, TY, RG>;
   static std::atomic<unsigned long long> lds_set{0};
-  if (const int rc = ensure_dynamic_lds(ssg_bwd_dense<KS, KW, C, TY, NCH>, (int)G::lds_bytes(), lds_set)) return rc;
-  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH>), dim3((unsigned)p.max_tiles, (unsigned)p.qsplit), dim3(64),
-                     G::lds_bytes(), st, p);
+  if (const int rc = ensure_dynamic_lds(ssg_bwd_dense<KS, KW, C, TY, NCH, RG>, (int)G::lds_bytes(), lds_set)) return rc;
+  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH, RG>), dim3((unsigned)p.max_tiles, (unsigned)p.qsplit, G::NHALF),
+                     dim3(64), G::lds_bytes(), st, p);
   return (int)hipGetLastError();
 }
 
 int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st) {
   if (!dense_bwd_supported(ks, kw, C)) return -1;
   if (p.max_tiles == 0) return 0;
-  if (ks == 49) return launch_one<49, 13, 3, 4, 2>(p, st);  // 4 x 32 tiles: at most 128 edge pixels
-  int rc = launch_one<25, 9, 3, 8, 2>(p, st);
-  if (!rc) rc = launch_one<25, 9, 3, 8, 4>(p, st);
+  if (ks == 49) return launch_one<49, 13, 3, 4, 2, 4>(p, st);  // 4 x 32 tiles: at most 128 edge pixels
+  int rc = launch_one<25, 9, 3, 8, 2, 8>(p, st);
+  if (!rc) rc = launch_one<25, 9, 3, 8, 4, 8>(p, st);
   return rc;
 }
 
