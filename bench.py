@@ -125,6 +125,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     rank = torch.empty((B, H, W), dtype=torch.int32, device=sr.device)
     order = torch.empty(step.capacity, dtype=torch.int32, device=sr.device)
     plan = torch.empty(L.ssg_forward_plan_bytes(B, H, W, step.capacity) // 4, dtype=torch.int32, device=sr.device)
+    rsc = torch.empty(2 * n_edges, dtype=torch.float64, device=sr.device)   # deferred normalisation, as in the fused call
     p = engine._ptr
 
     def f_edges():
@@ -133,12 +134,12 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
 
     def f_fwd():
         _lib.check(L.ssg_map_forward(p(sr), p(gt), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts),
-                                     n_edges, KS, KW, SIGMA, EPS, 1, p(step.ssg_sr), p(step.ssg_gt), st))
+                                     n_edges, KS, KW, SIGMA, EPS, 1, p(step.ssg_sr), p(step.ssg_gt), p(rsc), st))
 
     def f_bwd():
         _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts), n_edges,
                                        KS, KW, SIGMA, 1, p(step.ssg_sr), p(step.ssg_gt), W_L1, W_KL, None, p(step.loss),
-                                       p(step.grad), p(lscratch), None, st))
+                                       p(step.grad), p(lscratch), None, p(rsc), st))
 
     def only(fn, keep, group):
         mask_bits = sum(1 << SKIP_BITS[k] for k in group if k != keep)
@@ -220,15 +221,14 @@ def cpu_baseline(cfg, sr, gt, mask, budget_s=20.0):
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/pmc_traffic.json,
-    produced by tools/prof_pmc.sh + tools/pmc_to_json.py with the guide's unit / gfx950 corrections);
-    None if there is no entry for this kernel."""
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/pmc_traffic.json, produced by
+    tools/r2_final.sh with the guide's unit / gfx950 corrections); None if there is no entry for this kernel."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
-        key = kernel_name.split("<")[0].split(" ")[0]
+        key = kernel_name.replace(" ", "")
         for k, v in t.get("kernels", {}).items():
-            if k.split("<")[0] == key:
+            if k == key or k.startswith(key.rstrip(">") + ","):    # ssg_bwd_dense<25,9,3> ~ ssg_bwd_dense<25,9,3,8,2,8>
                 return v.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass

@@ -154,7 +154,9 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H,
                     const int *fwd_plan /* nullable */,
                     const int *n_edges_dev, int n_rows,
                     int ks, int kw, float sigma, float eps, int generalization,
-                    float *ssg, float *ssg2, ssg_stream_t stream);
+                    float *ssg, float *ssg2,
+                    double *row_scale /* nullable, 2*n_rows doubles: see ssg_loss_backward */,
+                    ssg_stream_t stream);
 
 /* Backward of the above: grad_img (B,C,H,W) += d/d img of sum(grad_ssg * ssg)
  * (reflect fold included).  `ssg` is the forward output (saved).
@@ -193,7 +195,13 @@ size_t ssg_grad_fix_bytes(int B, int C, int H, int W);
  * ssg_loss_backward consumes SSGs already computed by ssg_map_forward
  * (API-compatible mode: SSG tensors are materialised once each); rank_map and
  * fwd_plan (nullable, from ssg_edge_list) select the split backward described
- * at ssg_map_backward (its scratch is part of ssg_loss_scratch_bytes).  `upstream`
+ * at ssg_map_backward (its scratch is part of ssg_loss_scratch_bytes).
+ * Deferred normalisation (optional): when the SAME `row_scale` buffer (2*n_rows doubles) is passed to
+ * ssg_map_forward and then here, the rows the dense-tile forward produced are left un-normalised
+ * (e = exp(-d/sigma)) with their 1/(sum e + eps) in row_scale, and this call rescales them in place while it
+ * streams them anyway -- same arithmetic, same bits, one pass over the SSG tensors less.  Between the two calls
+ * ssg_sr / ssg_gt are NOT yet the SSG tensors.  Requires rank_map, fwd_plan and scratch (SSG_E_BADARG otherwise).
+ * `upstream`
  * (nullable) points at two DEVICE floats {dL/dl1, dL/dkl} that scale the two
  * criteria's gradients (autograd's incoming gradients, read on device so the
  * host never synchronises); null means {1,1}.
@@ -205,11 +213,11 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
                       const int *fwd_plan /* nullable */,
                       const int *n_edges_dev, int n_rows,
                       int ks, int kw, float sigma, int generalization,
-                      const float *ssg_sr, const float *ssg_gt, float w_l1,
+                      float *ssg_sr, float *ssg_gt, float w_l1,
                       float w_kl, const float *upstream /* nullable */,
                       float *loss_out, float *grad_sr /* nullable */,
                       void *scratch, void *grad_fix /* nullable: deterministic mode */,
-                      ssg_stream_t stream);
+                      const double *row_scale /* nullable */, ssg_stream_t stream);
 
 /* Everything in one call: edge list (from a mask or from GT's Laplacian),
  * SSG(sr), SSG(gt), both criteria and the gradient.  ssg_sr / ssg_gt

@@ -28,14 +28,14 @@ PROTOTYPES = {
     "ssg_edge_list": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssg_edge_mask_laplacian": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "ssg_map_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp,
-                             _vp]),
+                             _vp, _vp]),
     "ssg_backward_scratch_bytes": (_sz, [_i, _i]),
     "ssg_map_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp,
                               _vp, _vp]),
     "ssg_grad_fix_bytes": (_sz, [_i, _i, _i, _i]),
     "ssg_loss_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ssg_loss_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _f, _f,
-                               _vp, _vp, _vp, _vp, _vp, _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssg_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ssg_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,
                               _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -37,6 +37,7 @@ struct DenseParams {
   float sigma, eps;
   int generalization;
   int dbg;
+  double *row_scale;
 };
 bool dense_supported(int ks, int kw, int C);
 int dense_max_tiles(int B, int H, int W, int ks);
@@ -137,6 +138,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   g.gin = p.gin;
   g.ssg = p.ssg;
   g.ssg2 = p.ssg2;
+  g.row_scale = p.row_scale;
   g.n_dev = p.n_dev;
   g.n_host = p.n_host;
   g.C = p.C;
@@ -296,7 +298,7 @@ int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_thre
 int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, int W, const int *edges,
                     const int *tile_order, const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows,
                     int ks, int kw, float sigma, float eps, int generalization, float *ssg, float *ssg2,
-                    ssg_stream_t stream) {
+                    double *row_scale, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -344,6 +346,11 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
     d.eps = eps;
     d.generalization = generalization;
     d.dbg = (dbg_mask() >> 16) & 0xff;
+    d.row_scale = row_scale;
+    if (row_scale) {   // 0 = "this row is already normalised" (the rows of the direct kernels)
+      const int rc0 = (int)hipMemsetAsync(row_scale, 0, sizeof(double) * 2 * (size_t)n_rows, (hipStream_t)stream);
+      if (rc0) return rc0;
+    }
     const int rc = (dbg_mask() & (1 << 25)) ? 0 : launch_fwd_dense(d, ks, kw, C, (hipStream_t)stream);
     if (rc) return rc;
     p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
@@ -407,8 +414,9 @@ size_t ssg_loss_scratch_bytes(int B, int H, int W, int n_rows, int ks) {
 int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *tile_order,
                       const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
                       float sigma, int generalization,
-                      const float *ssg_sr, const float *ssg_gt, float w_l1, float w_kl, const float *upstream,
-                      float *loss_out, float *grad_sr, void *scratch, void *grad_fix, ssg_stream_t stream) {
+                      float *ssg_sr, float *ssg_gt, float w_l1, float w_kl, const float *upstream,
+                      float *loss_out, float *grad_sr, void *scratch, void *grad_fix, const double *row_scale,
+                      ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
@@ -438,6 +446,8 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
   p.ks = ks;
   p.kw = kw;
   p.dbg = (dbg_mask() >> 8) & 0xff;
+  p.row_scale = row_scale;
+  if (row_scale && !split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) return SSG_E_BADARG;  // only ssg_grad_rows rescales
   int rc = det_begin(p, grad_fix, st);
   if (rc) return rc;
   int nparts;
@@ -456,6 +466,7 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
 
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
   return align_up(sizeof(int) * 3 * (size_t)(capacity > 0 ? capacity : 1), 256) +
+         align_up(2 * sizeof(double) * (size_t)(capacity > 0 ? capacity : 1), 256) +
          align_up(sizeof(int) * (size_t)B * H * W, 256) + align_up(sizeof(int) * (size_t)(capacity > 0 ? capacity : 1), 256) +
          align_up(fwd_plan_bytes(B, H, W, capacity), 256) + align_up(edge_scratch_bytes(B, H, W), 256) +
          align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
@@ -481,14 +492,19 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   void *escratch = ws;
   ws += align_up(edge_scratch_bytes(B, H, W), 256);
   void *lscratch = ws;
+  ws += align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
+  double *row_scale = (double *)ws;
   int rc = ssg_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
                          W, mask_stride, lap_threshold, ks, edges, capacity, counts, rank, order, plan, escratch, stream);
   if (rc) return rc;
+  // (deferred normalisation wherever the split backward -- whose ssg_grad_rows pass rescales -- follows)
+  const bool defer = split_ok(ks, kw, C, rank, plan, lscratch) && dense_supported(ks, kw, C);
   rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
-                       generalization, ssg_sr, ssg_gt, stream);
+                       generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, stream);
   if (rc) return rc;
   return ssg_loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
-                           ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix, stream);
+                           ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix,
+                           defer ? row_scale : nullptr, stream);
 }
 
 int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,

@@ -155,6 +155,7 @@ struct BwdParams {
   int generalization;
   float w_l1, w_kl;
   const float *upstream;  // GRAD_LOSS, nullable: device {dL/dl1, dL/dkl}
+  const double *row_scale;  // GRAD_LOSS, nullable: deferred normalisation (GrowParams), split backward only
   float *partials;  // GRAD_LOSS: (gridDim.x, 2) per-workgroup sums of |a-b| and t'(log t' - log s')
   int ks, kw;       // generic kernel only
   int dbg;          // profiling ablations (0 in production): bit0 skip prologue math, bit1 skip pass A, bit2 skip pass B, bit3 skip atomics
@@ -247,6 +248,9 @@ struct GrowParams {
   const float *gin;   // GRAD_D / GRAD_S
   const float *ssg;   // GRAD_S / GRAD_LOSS
   const float *ssg2;  // GRAD_LOSS
+  // nullable [2][n_host] (GRAD_LOSS): deferred normalisation of the dense-tile forward -- a non-zero entry means the
+  // row still holds e = exp(-d/sigma) and is rescaled here (and written back, normalised, through ssg / ssg2)
+  const double *row_scale;
   const int *n_dev;
   int n_host;
   int C;

@@ -43,6 +43,7 @@ struct DenseParams {
   float sigma, eps;
   int generalization;
   int dbg;  // profiling ablations: bit0 no stores, bit1 no edge stage, bit3 no rescale, bit6 no main loop
+  double *row_scale;  // nullable [nimg][n_host]: deferred normalisation -- the rows stay e, 1/(sum e + eps) goes here
 };
 
 constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1) (8 for k_w = 9, 4 for k_w = 13)
@@ -317,6 +318,16 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   __threadfence_block();
   __syncthreads();
   if (!p.generalization || (p.dbg & 8)) return;
+  if (p.row_scale) {
+    // deferred normalisation: the consumer that streams the rows anyway (ssg_grad_rows) rescales them; saves this
+    // kernel's second pass over its rows (one read + one write of every row)
+    double *rsc = p.row_scale + (size_t)which * p.n_host;
+    for (int e = tid; e < n_e; e += 256) {
+      const double tot = rsum[e] + rsum[RSTR + e] + rsum[2 * RSTR + e] + rsum[3 * RSTR + e];
+      rsc[elist[3 * e + 2]] = 1.0 / (tot + (double)p.eps);
+    }
+    return;
+  }
   // global stores of this workgroup must be visible to its own later loads: same CU, L1 is
   // write-through, the loads below are issued after the barrier + vmcnt drain
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

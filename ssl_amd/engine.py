@@ -134,7 +134,7 @@ class _SSGMapFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().ssg_map_forward(_ptr(x), None, B, C, H, W, _ptr(edges), _ptr(f_order), _ptr(f_rank),
                                                   _ptr(f_plan), _ptr(counts), n_rows, ks, kw, float(sigma), float(eps),
-                                                  int(bool(generalization)), _ptr(ssg), None, _stream()))
+                                                  int(bool(generalization)), _ptr(ssg), None, None, _stream()))
         ctx.save_for_backward(x, edges, counts, ssg)
         ctx.order = order
         ctx.split = (f_rank, f_plan)
@@ -194,13 +194,19 @@ class _SSGLossFn(torch.autograd.Function):
         loss = torch.zeros(2, dtype=torch.float32, device=dev)
         grad = torch.zeros_like(x) if want_grad else None
         scratch = torch.empty(L.ssg_loss_scratch_bytes(B, H, W, n_rows, ks), dtype=torch.uint8, device=dev)
+        # deferred normalisation (include/ssg_hip.h): the dense-tile forward leaves its rows un-normalised and the
+        # backward's row pass rescales them -- only where that pass exists (split backward: plan + supported sizes)
+        rsc = None
+        if f_rank is not None and f_plan is not None and (ks, kw, C) in ((25, 9, 3), (49, 13, 3)):
+            rsc = torch.empty(2 * max(n_rows, 1), dtype=torch.float64, device=dev)
         _lib.check(L.ssg_map_forward(_ptr(x), _ptr(y), B, C, H, W, _ptr(edges), _ptr(f_order), _ptr(f_rank), _ptr(f_plan),
                                      _ptr(counts), n_rows, ks, kw, sigma, eps, gen, _ptr(ssg_sr), _ptr(ssg_gt),
-                                     _stream()))
+                                     _ptr(rsc), _stream()))
         fix = _grad_fix(det, x) if want_grad else None
         _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(order), _ptr(f_rank), _ptr(f_plan),
                                        _ptr(counts), n_rows, ks, kw, sigma, gen, _ptr(ssg_sr), _ptr(ssg_gt), w_l1,
-                                       w_kl, _ptr(upstream), _ptr(loss), _ptr(grad), _ptr(scratch), _ptr(fix), _stream()))
+                                       w_kl, _ptr(upstream), _ptr(loss), _ptr(grad), _ptr(scratch), _ptr(fix), _ptr(rsc),
+                                       _stream()))
         return loss, grad
 
     @staticmethod

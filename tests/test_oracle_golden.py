@@ -239,3 +239,19 @@ def test_f11_datapath_oracle_vs_reference(golden):
                                    lambda: torch.randperm(int(g["pool_size"])).numpy())
         assert np.array_equal(lq, g["pool_lq_out"][t]) and np.array_equal(gt, g["pool_gt_out"][t])
         assert np.array_equal(mk, g["pool_mask_out"][t])
+
+
+def test_f7_laplacian_second_independent_derivation(golden):
+    """cv2 is not installable here (`pip install opencv-python-headless`: no index, not in /opt/wheelhouse), so the
+    cv2.Laplacian(CV_8U) step of generate_mask.py:22-31 stays pinned by OpenCV's DOCUMENTED semantics only.  The
+    fixture's Laplacian (scipy.ndimage, mode='mirror') is re-derived here with a second, independent
+    implementation -- torch reflect padding (= BORDER_REFLECT_101: the edge sample is not repeated) + conv2d with the
+    ksize=1 aperture [[0,1,0],[1,-4,1],[0,1,0]] + saturate_cast<uchar> -- and both must equal the stored bytes."""
+    import torch
+    import torch.nn.functional as F
+    g = golden("f7_edge_mask")
+    L = torch.as_tensor(g["gray"].astype(np.float32))[None, None]
+    K = torch.tensor([[0., 1., 0.], [1., -4., 1.], [0., 1., 0.]])[None, None]
+    lap = F.conv2d(F.pad(L, (1, 1, 1, 1), mode="reflect"), K).clamp(0, 255)[0, 0].numpy().astype(np.uint8)
+    assert np.array_equal(lap, g["lap"])
+    assert np.array_equal((lap > 20).astype(np.uint8), g["mask"])
