@@ -53,8 +53,12 @@ constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1
 // pixels collide only if dx = -12 dy (mod 32), which no edge curve does inside an 8-row tile.
 constexpr int DT_HS = 44;
 
-template <int KS, int KW, int C>
-__global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
+// NW waves per workgroup share the tile's image region; wave w walks the offset rows q_y = w (mod NW).  (25,9): 4
+// (47 KB of LDS, two workgroups per CU); (49,13): 8 -- its 71 KB region allows one workgroup per CU, and a lone
+// wave per SIMD issues a VALU instruction only every ~4 cycles (5.4 -> 3.x ms at C5).
+template <int KS, int KW, int C, int NW>
+__global__ __launch_bounds__(64 * NW) void ssg_fwd_dense(DenseParams p) {
+  constexpr int NT = 64 * NW;
   constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK, DT_Y = 16 - 2 * HK;
   constexpr int RH = DT_Y + 2 * HALO, RWD = DT_X + 2 * HALO, RS = RWD + 1;  // image region
   constexpr int UH = DT_Y + 2 * HK, UW = DT_X + 2 * HK;                      // window halo U
@@ -66,14 +70,14 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   float *reg = smem;                       // [C][RH][RS]
   float *F = reg + C * RH * RS;            // [UH][UW]   sum_c I^2 on U
   float *HF = F + UH * UW;                 // [UH][DT_HS] full-window horizontal sums of F
-  float *Hb = HF + UH * DT_HS;             // [4][UH][DT_HS] per-wave horizontal sums of E_q
+  float *Hb = HF + UH * DT_HS;             // [NW][UH][DT_HS] per-wave horizontal sums of E_q
   // per-wave partial row sums (fp64, see ssg_fwd.hip): wave w's NE_MAX doubles reuse ITS OWN H buffer once its
   // offset rows are done (same size, wave-private, so no other wave is still reading it)
-  double *rsum = (double *)Hb;                    // [4][RSTR], RSTR = one H buffer in doubles
+  double *rsum = (double *)Hb;                    // [NW][RSTR], RSTR = one H buffer in doubles
   constexpr int RSTR = UH * DT_HS / 2;
   static_assert(NE_MAX <= RSTR, "row sums alias the wave's H buffer");
-  int *elist = (int *)(Hb + 4 * UH * DT_HS);      // [NE_MAX][3] (ey, ex, row)
-  int *misc = elist + NE_MAX * 3;          // [8]: wave counts, n_e
+  int *elist = (int *)(Hb + NW * UH * DT_HS);     // [NE_MAX][3] (ey, ex, row)
+  int *misc = elist + NE_MAX * 3;          // [16]: wave counts, n_e (misc[NW])
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int which = blockIdx.x / p.max_tiles, tslot = blockIdx.x - which * p.max_tiles;
@@ -102,7 +106,11 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
       elist[3 * pos + 1] = ex;
       elist[3 * pos + 2] = r;
     }
-    if (tid == 0) misc[4] = misc[0] + misc[1] + misc[2] + misc[3];
+    if (tid == 0) {
+      int t = 0;
+      for (int k = 0; k < NW; ++k) t += misc[k];
+      misc[NW] = t;
+    }
   }
   // ---- image region: C x RH x RWD, reflect by index mirroring (clamped: far corners of
   // tiles that overhang a small image are never used, but must stay in bounds) ----
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     const float *src = p.img[which] + (size_t)b * C * H * W;
     constexpr int CPLF = (RWD + 15) / 16;    // 16 lanes per row, CPLF consecutive pixels each
     const int lx = tid % 16, lr = tid / 16;
-    for (int R0 = 0; R0 < C * RH; R0 += 16) {
+    for (int R0 = 0; R0 < C * RH; R0 += NT / 16) {
       const int R = R0 + lr;
       if (R < C * RH) {
         const int c = R / RH, ry = R - c * RH;
@@ -131,8 +139,8 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     }
   }
   __syncthreads();
-  const int n_e = misc[4];
-  for (int i = tid; i < UH * UW; i += 256) {
+  const int n_e = misc[NW];
+  for (int i = tid; i < UH * UW; i += NT) {
     const int ur = i / UW, uc = i - ur * UW;
     float t = 0.f;
 #pragma unroll
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     F[i] = t;
   }
   __syncthreads();
-  for (int i = tid; i < UH * DT_X; i += 256) {
+  for (int i = tid; i < UH * DT_X; i += NT) {
     const int ur = i / DT_X, tc = i - ur * DT_X;
     float t = 0.f;
 #pragma unroll
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   const int n_e_stage = (p.dbg & 2) ? 0 : n_e;  // profiling ablations: 2 no edge stage, 1 no stores, 64 no main loop
   const bool do_store = !(p.dbg & 1);
 #pragma unroll 1
-  for (int qyi = wv; qyi < ((p.dbg & 64) ? 0 : KS); qyi += 4) {
+  for (int qyi = wv; qyi < ((p.dbg & 64) ? 0 : KS); qyi += NW) {
     // D[n,q] = sum_{k in K(q)} E_q[x+k] + sum_{k not in K(q)} |I[x+k]|^2 with K(q) = rows [ylo,yhi] x columns
     // [xlo,xhi] of the window.  Rows: wave-uniform 0/1 weights.  Columns: the lane adds the |I|^2 of the
     // columns that left (compile-time set) to its horizontal sums, so H' rows carry E inside and |I|^2 outside
@@ -322,8 +330,10 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
     // deferred normalisation: the consumer that streams the rows anyway (ssg_grad_rows) rescales them; saves this
     // kernel's second pass over its rows (one read + one write of every row)
     double *rsc = p.row_scale + (size_t)which * p.n_host;
-    for (int e = tid; e < n_e; e += 256) {
-      const double tot = rsum[e] + rsum[RSTR + e] + rsum[2 * RSTR + e] + rsum[3 * RSTR + e];
+    for (int e = tid; e < n_e; e += NT) {
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) tot += rsum[k * RSTR + e];
       rsc[elist[3 * e + 2]] = 1.0 / (tot + (double)p.eps);
     }
     return;
@@ -335,14 +345,16 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
   // two rows per wave and iteration: both rows' loads are in flight before the first store (the pass is a chain of
   // L2 round trips otherwise: 0.12 of the kernel's 0.52 ms at C2)
   constexpr int RPL = (P + 63) / 64;  // row elements per lane
-  for (int e0 = 2 * wv; e0 < n_e; e0 += 8) {
+  for (int e0 = 2 * wv; e0 < n_e; e0 += 2 * NW) {
     float v[2][RPL];
     double scale[2];
     float *o[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = e0 + j < n_e ? e0 + j : e0;
-      const double tot = rsum[e] + rsum[RSTR + e] + rsum[2 * RSTR + e] + rsum[3 * RSTR + e];
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) tot += rsum[k * RSTR + e];
       scale[j] = 1.0 / (tot + (double)p.eps);
       o[j] = outp + (size_t)elist[3 * e + 2] * P;
 #pragma unroll
@@ -365,12 +377,12 @@ __global__ __launch_bounds__(256) void ssg_fwd_dense(DenseParams p) {
 }
 
 // ------------------------------------------------------------------ host ----
-template <int KS, int KW, int C>
+template <int KS, int KW, int C, int NW>
 static size_t dense_lds_bytes() {
   constexpr int DT_Y = 16 - 2 * (KW / 2);
   constexpr int HALO = KS / 2 + KW / 2, RH = DT_Y + 2 * HALO, RS = DT_X + 2 * HALO + 1;
   constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X;
-  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_HS + 4 * UH * DT_HS) + sizeof(int) * (NE * 3 + 8);
+  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_HS + NW * UH * DT_HS) + sizeof(int) * (NE * 3 + 16);
 }
 
 bool dense_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }
@@ -383,19 +395,19 @@ int dense_max_tiles(int B, int H, int W, int ks) {
   return B * ((H + ty - 1) / ty) * ((W + DT_X - 1) / DT_X);
 }
 
-template <int KS, int KW, int C>
+template <int KS, int KW, int C, int NW>
 static int launch_fwd_dense_t(const DenseParams &p, hipStream_t st) {
-  const size_t lds = dense_lds_bytes<KS, KW, C>();
+  const size_t lds = dense_lds_bytes<KS, KW, C, NW>();
   static std::atomic<unsigned long long> lds_set{0};
-  if (const int rc = ensure_dynamic_lds(ssg_fwd_dense<KS, KW, C>, (int)lds, lds_set)) return rc;
-  hipLaunchKernelGGL((ssg_fwd_dense<KS, KW, C>), dim3((unsigned)p.max_tiles * p.nimg), dim3(256), lds, st, p);
+  if (const int rc = ensure_dynamic_lds(ssg_fwd_dense<KS, KW, C, NW>, (int)lds, lds_set)) return rc;
+  hipLaunchKernelGGL((ssg_fwd_dense<KS, KW, C, NW>), dim3((unsigned)p.max_tiles * p.nimg), dim3(64 * NW), lds, st, p);
   return (int)hipGetLastError();
 }
 
 int launch_fwd_dense(const DenseParams &p, int ks, int kw, int C, hipStream_t st) {
   if (!dense_supported(ks, kw, C)) return -1;
   if (p.max_tiles == 0) return 0;
-  return ks == 25 ? launch_fwd_dense_t<25, 9, 3>(p, st) : launch_fwd_dense_t<49, 13, 3>(p, st);
+  return ks == 25 ? launch_fwd_dense_t<25, 9, 3, 4>(p, st) : launch_fwd_dense_t<49, 13, 3, 8>(p, st);
 }
 
 }  // namespace ssg
