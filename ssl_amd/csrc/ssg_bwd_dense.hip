@@ -61,9 +61,9 @@ struct DenseBwdGeo {
   static constexpr int RR = 64 / RG, NHALF = UH / RR;         // U-rows per wave, waves per tile
   static constexpr int RW = UW + KS - 1, RH = UH + KS - 1;    // gradient / image region
   static constexpr int RWS = RW | 1;                          // channel stride inside a band row
-  // band row stride: RG = 4: C odd strides; RG = 8: = 8 (mod 16), the 4 slots x 8 groups (5 floats apart) of a
-  // half-wave on 32 different banks
-  static constexpr int BRS = RG == 8 ? ((C * RWS - 8 + 15) / 16 * 16 + 8) : C * RWS;
+  // band row stride: RG = 4: C odd strides; RG = 8: = 4 (mod 32), the 8 slots x 4 groups (5 floats apart) of a
+  // half-wave (lane = 8 * group + row) on 32 different banks
+  static constexpr int BRS = RG == 8 ? ((C * RWS - 4 + 31) / 32 * 32 + 4) : C * RWS;
   static constexpr int BR = RR;                               // band rows
   static constexpr int HG = 64 / TY, HOUT = (UW + HG - 1) / HG;
   // padded G field row.  The horizontal-sum lanes (tile row hty, group hg) read dword hty*GQS + HOUT*hg + m: with
@@ -73,7 +73,8 @@ struct DenseBwdGeo {
   static constexpr int GQS_RES = TY == 8 ? 20 : 8;
   static constexpr int GQS = GQS_MIN + ((GQS_RES - GQS_MIN % 32) + 32) % 32;
   static constexpr int PS = RG * NPXP;                        // prefix row
-  static constexpr int FSZ = TY * GQS + (TY + 1) * PS;        // one field + its prefix rows (two copies: steps alternate)
+  // one field + its prefix rows (two copies: steps alternate); RG = 8 keeps the prefix in registers: no rows
+  static constexpr int FSZ = TY * GQS + (RG == 8 ? 0 : (TY + 1) * PS);
   static constexpr int NE_MAX = TY * TX, NCHUNK = NE_MAX / 64;
   static constexpr int NG = KS / 4;                           // full groups of 4 offsets per offset row
   static constexpr int CPL = (RW + 63) / 64;                  // region columns per lane (row loads / flushes)
@@ -155,10 +156,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   }
 
   // lane roles: main (U-row r, column group g); prefix (tile row hty, column group hg)
-  const int g = lane % RG, r = RR * (int)blockIdx.z + lane / RG;  // U-row r of the tile, column group g
-  const int hty = lane % TY, hg = lane / TY;
+  // RG = 4: main lane = (U-row lane/4, group lane%4), prefix lane = (tile row lane%TY, group lane/TY), W through LDS
+  // prefix rows.  RG = 8 (TY = 8, HOUT = NPX): ONE role per lane -- lane = 8*group + j -- so that the vertical prefix a
+  // lane computes IS the W of its own pixels: the first half (U-rows 0..7) sums tile rows 0..j for U-row j; the
+  // second half walks the tile rows in reverse (lane j <-> tile row 7-j, U-row 15-j), so its prefix is the suffix
+  // sum rows 7-j..7 it needs.  Only offset rows whose window is cut vertically fetch two other lanes' prefixes
+  // (ds_bpermute inside the 8-lane group).
+  const int half = RG == 8 ? (int)blockIdx.z : 0;
+  const int jrow = lane & 7;
+  const int g = RG == 8 ? lane >> 3 : lane % RG;
+  const int r = RG == 8 ? (half ? 15 - jrow : jrow) : RR * (int)blockIdx.z + lane / RG;  // U-row of the tile
+  const int hty = RG == 8 ? jrow : lane % TY, hg = RG == 8 ? g : lane / TY;
   const float m1 = hty >= 1 ? 1.f : 0.f, m2 = hty >= 2 ? 1.f : 0.f, m4 = hty >= 4 ? 1.f : 0.f;
-  const int hsrc = hty * GQS + HOUT * hg;  // (offsets relative to a copy's base)
+  const int hsrc = (RG == 8 && half ? TY - 1 - hty : hty) * GQS + HOUT * hg;  // (offsets relative to a copy's base)
   int hdst[HOUT];
 #pragma unroll
   for (int i = 0; i < HOUT; ++i) {
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     hdst[i] = TY * GQS + (hty + 1) * PS + (uc < UW ? (uc / NPX) * NPXP + uc % NPX : PS - 1);
   }
 
+  float wout[HOUT];  // RG = 8: the prefix of the offset prepared last (consumed by the next step)
   // The box sum W of the field in copy `f` on the lane's NPX pixels comes in two halves, so that consecutive
   // offset steps overlap (x_stage of step s+1 runs beside the body of step s):
   //   x_stage: horizontal sums over the column taps kept (XLO..XHI), vertical inclusive prefix, prefix rows to LDS;
@@ -192,8 +203,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
       if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
     }
+    if constexpr (RG != 8) {
 #pragma unroll
-    for (int i = 0; i < HOUT; ++i) f[hdst[i]] = out[i];
+      for (int i = 0; i < HOUT; ++i) f[hdst[i]] = out[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < HOUT; ++i) wout[i] = out[i];
+    }
   };
   auto y_read = [&](const float *f, int pa, int pb, float (&Wv)[NPX]) {
 #pragma unroll
@@ -207,6 +223,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     const bool none = a > bb;
     pa = TY * GQS + (none ? 0 : a * PS) + NPXP * g;
     pb = TY * GQS + (none ? 0 : (bb + 1) * PS) + NPXP * g;
+  };
+
+  // RG = 8, offset rows with a vertically cut window [ylo, yhi]: W = (prefix of lane `lpos`) - (prefix of lane
+  // `lneg`), each times a 0/1 factor; byte addresses for ds_bpermute
+  auto cut_rows = [&](int ylo, int yhi, int &lpos, int &lneg, float &mpos, float &mneg) {
+    int a = r - HK - yhi, bb = r - HK - ylo;  // tile rows [a, bb] feed U-row r
+    a = a < 0 ? 0 : a;
+    bb = bb > TY - 1 ? TY - 1 : bb;
+    const bool none = a > bb;
+    const int base = lane & ~7;
+    int jp, jn;
+    if (!half) {  // lane k holds rows 0..k: rows [a,bb] = lane bb - lane (a-1)
+      jp = bb;
+      jn = a - 1;
+    } else {      // lane k holds rows 7-k..7: rows [a,bb] = lane (7-a) - lane (6-bb)
+      jp = TY - 1 - a;
+      jn = TY - 2 - bb;
+    }
+    mpos = none ? 0.f : 1.f;
+    mneg = (none || jn < 0) ? 0.f : 1.f;
+    lpos = 4 * (base + (none ? 0 : jp));
+    lneg = 4 * (base + (jn < 0 ? 0 : jn));
+  };
+  auto w_regs = [&](bool full, int lpos, int lneg, float mpos, float mneg, float (&Wv)[NPX]) {
+    static_assert(RG != 8 || HOUT == NPX, "one role per lane");
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) Wv[i] = wout[i < HOUT ? i : 0];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int wi = __builtin_bit_cast(int, wout[i < HOUT ? i : 0]);
+        const float vp = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(lpos, wi));
+        const float vn = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(lneg, wi));
+        Wv[i] = mpos * vp - mneg * vn;
+      }
+    }
   };
 
   // ---- the lane's own pixels, and Box(sum_b) on them ----
@@ -332,8 +385,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     load_img_row(r0 + qyi + RR < RH ? r0 + qyi + RR : RH - 1, nrow);
     const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
     const float ymask = (ylo > -HK || yhi < HK) ? 1.f : 0.f;
-    int pa, pb;
-    prefix_rows(ylo, yhi, pa, pb);
+    int pa = 0, pb = 0, lpos = 0, lneg = 0;
+    float mpos = 0.f, mneg = 0.f;
+    const bool rowfull = ylo == -HK && yhi == HK;
+    if constexpr (RG == 8) cut_rows(ylo, yhi, lpos, lneg, mpos, mneg);
+    else prefix_rows(ylo, yhi, pa, pb);
     float *fe = fld + (qyi & 1) * FSZ, *fo = fld + ((qyi & 1) ^ 1) * FSZ;  // copies of the even / odd q_x of this row
     const int slr = (r + qyi) & RMASK;
     const float *ib = imgb + slr * BRS + NPX * g;
@@ -362,11 +418,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       }
       if constexpr (qxi == KS - 2) load_last(qyn);
       // ---- top: every LDS read of the step ----
-      float wa[NPX], wb[NPX], v[HOUT + 2 * HK], fl[C], wn[C];
+      float Wv[NPX], v[HOUT + 2 * HK], fl[C], wn[C];
+      if constexpr (RG == 8) {
+        w_regs(rowfull, lpos, lneg, mpos, mneg, Wv);
+      } else {
 #pragma unroll
-      for (int i = 0; i < NPX; ++i) {
-        wb[i] = fc[pb + i];
-        wa[i] = fc[pa + i];
+        for (int i = 0; i < NPX; ++i) Wv[i] = fc[pb + i] - fc[pa + i];
       }
 #pragma unroll
       for (int m = M0; m <= M1; ++m) v[m] = fn[hsrc + m];
@@ -379,7 +436,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       constexpr bool xborder = xlo > -HK || xhi < HK;
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
-        const float Wi = wb[i] - wa[i];
+        const float Wi = Wv[i];
         if constexpr (xborder) swb[i] += Wi;
         else swb[i] = __builtin_fmaf(Wi, ymask, swb[i]);
 #pragma unroll
@@ -405,8 +462,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
         if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
       }
       // ---- end: every LDS write of the step ----
+      if constexpr (RG == 8) {
 #pragma unroll
-      for (int i = 0; i < HOUT; ++i) fn[hdst[i]] = out[i];
+        for (int i = 0; i < HOUT; ++i) wout[i] = out[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < HOUT; ++i) fn[hdst[i]] = out[i];
+      }
       // region column NPX*g + qxi of this band row is complete: to the band; the window moves on
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -440,11 +502,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
 #pragma unroll
     for (int ck = 0; ck < NCH; ++ck) fld[epos[ck]] = (blockIdx.y == 0) ? p.sum_b[erow[ck]] : 0.f;
     __builtin_amdgcn_wave_barrier();
-    int pa, pb;
-    prefix_rows(-HK, HK, pa, pb);
     x_stage(std::integral_constant<int, -HK>{}, std::integral_constant<int, HK>{}, fld);
     __builtin_amdgcn_wave_barrier();
-    y_read(fld, pa, pb, vbox);
+    if constexpr (RG == 8) {
+      w_regs(true, 0, 0, 0.f, 0.f, vbox);
+    } else {
+      int pa, pb;
+      prefix_rows(-HK, HK, pa, pb);
+      y_read(fld, pa, pb, vbox);
+    }
     step_fence();
   }
 
