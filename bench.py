@@ -279,14 +279,17 @@ def main():
     import torch
     cfg = CONFIGS[args.config]
     use_dist = world > 1 or "RANK" in os.environ    # launched by torch.distributed.run / self-spawned (also 1 rank)
-    if use_dist:
-        import torch.distributed as dist
-        dist.init_process_group("gloo" if args.dry_run else "nccl", rank=rank, world_size=world)   # nccl = RCCL on ROCm
     if args.dry_run:
         dev = torch.device("cpu")
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    if use_dist:
+        import torch.distributed as dist
+        if args.dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:   # "nccl" IS RCCL on ROCm; one process per GPU, the rank's device stated explicitly
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ssl_amd import synth
     sr_np, gt_np, mask_np = make_inputs(cfg, rank, world, args.scaling)

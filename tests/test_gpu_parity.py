@@ -1049,3 +1049,32 @@ def test_deterministic_backward_is_bit_reproducible(dev):
         (s * cot).sum().backward()
         outs.append(x.grad.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("thr", [0, 1])
+def test_stress_sizes_vjp_dense_and_direct_vs_oracle(dev, thr):
+    """(49, 13): d sum(SSG * cot)/d img under a smooth cotangent on an odd-sized image (72x100: tiles overhang the
+    image, border pixels reflect) through the direct kernels (threshold 0) and the 4x32-tile shared-term kernels
+    (threshold 1) vs the fp64 oracle: SSG <= 1e-5, gradient <= 1e-5 max|grad|."""
+    from ssl_amd import engine, synth
+    ks, kw, H, W = 49, 13, 72, 100
+    img = synth.natural_like(21, H, W)[None]
+    rng = np.random.default_rng(3)
+    m = (rng.random((H, W)) < 0.3).astype(np.uint8)
+    m[0, 0] = m[0, W - 1] = m[H - 1, 0] = m[H - 1, W - 1] = 1
+    pos = orc.mask_to_pos(m)
+    n = len(pos)
+    cot = rng.standard_normal((n, ks * ks)).astype(np.float32)
+    S = orc.ssg_epilogue(orc.distance(img[0].astype(np.float64), pos, ks, kw), kw, 3, 1.0, True)
+    gref = orc.distance_backward(img[0].astype(np.float64), pos, ks, kw,
+                                 orc.ssg_epilogue_backward(S, cot.astype(np.float64), ks, kw, 3, 1.0, True))
+    prev = engine.set_dense_threshold(thr)
+    try:
+        x = T(img, dev).clone().requires_grad_(True)
+        el = engine.edge_list(mask=T(m[None, None].astype(np.float32), dev), ks=ks)
+        s = engine.ssg_map(x, el.edges, el.counts, n, ks, kw, 1.0, order=el.order, fwd=el.fwd)
+        assert maxerr(s.detach().cpu(), S) <= 1e-5
+        (s * T(cot, dev)).sum().backward()
+        assert maxerr(x.grad[0].cpu(), gref) <= 1e-5 * np.abs(gref).max()
+    finally:
+        engine.set_dense_threshold(prev)
