@@ -225,3 +225,25 @@ def test_bench_self_launch_two_ranks_strong_scaling_dry_run():
     assert r["config"]["edge_px_rank0"] == int(mask[:8].sum())
     import bench
     assert [bench.shard_images(16, k, 3) for k in range(3)] == [(0, 5), (5, 10), (10, 16)]
+
+
+def test_argument_checks_need_no_gpu():
+    """Status codes of include/ssg_hip.h that are decided before anything is launched: k_w > k_s and even sizes are
+    SSG_E_BADARG (-1) at every entry point (the kernels would index their LDS tile out of bounds), an image side
+    <= k_s/2 is SSG_E_IMAGESMALL (-4) like torch's reflect-pad error, a short workspace SSG_E_WORKSPACE (-3)."""
+    from ssl_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(8)          # never dereferenced: the checks come first
+    assert L.ssg_compute_similarity(one, one, one, 4, 5, 9, 40, 40, 3, None) == -1       # k_w > k_s
+    assert L.ssg_compute_similarity(one, one, one, 4, 6, 3, 40, 40, 3, None) == -1       # even k_s
+    assert L.ssg_compute_similarity_backward(one, one, one, one, 4, 5, 9, 40, 40, 3, None) == -1
+    assert L.ssg_compute_similarity(one, one, one, 0, 5, 3, 40, 40, 3, None) == 0        # nothing to do
+    assert L.ssg_map_forward(one, None, 1, 3, 12, 40, one, None, None, None, None, 4, 25, 9, 1.0, 1e-10, 1, one, None,
+                             None, None) == -4
+    assert L.ssg_map_forward(one, None, 1, 3, 40, 40, one, None, None, None, None, 4, 9, 25, 1.0, 1e-10, 1, one, None,
+                             None, None) == -1
+    assert L.ssg_loss_fwd_bwd(one, one, one, 0, 1, 1, 3, 40, 40, 25, 9, 1.0, 1e-10, 1, 1.0, 1.0, 0, 20.0, 100, one, one,
+                              one, one, one, one, 16, None, None) == -3
+    assert L.ssg_augment_crop(one, one, 2, 1, 3, 8, 8, 4, 4, one, None) == -1            # element size 2
+    assert L.ssg_grad_fix_bytes(2, 3, 16, 16) == 8 * (2 * 3 * 16 * 16 + 8)
+    assert L.ssg_backward_scratch_bytes(100, 25) >= 100 * 625 * 4

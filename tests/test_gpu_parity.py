@@ -1078,3 +1078,45 @@ def test_stress_sizes_vjp_dense_and_direct_vs_oracle(dev, thr):
         assert maxerr(x.grad[0].cpu(), gref) <= 1e-5 * np.abs(gref).max()
     finally:
         engine.set_dense_threshold(prev)
+
+
+def test_dense_and_direct_paths_agree_on_random_shapes(dev):
+    """Property test over random batch shapes, densities, kernel sizes and capacities: the shared-term kernels
+    (threshold 1: every non-empty tile) and the direct kernels (threshold 0) give the same SSG rows (<= 2e-6), the
+    same losses (rel 1e-5) and gradients that both sit within the oracle tolerance of the fp64 oracle -- including
+    images whose sides are not multiples of the tile sizes, empty images, and a capacity smaller than N (the first
+    `capacity` rows only, in both paths)."""
+    from ssl_amd import engine, synth
+    rng = np.random.default_rng(2024)
+    cases = [(25, 9, 2, 37, 61, 0.2, None), (25, 9, 3, 64, 33, 0.6, None), (25, 9, 1, 26, 90, 1.0, None),
+             (49, 13, 1, 53, 70, 0.25, None), (49, 13, 2, 40, 45, 1.0, None), (25, 9, 2, 50, 50, 0.5, 700)]
+    for ks, kw, B, H, W, dens, cap in cases:
+        gt = np.stack([synth.natural_like(int(rng.integers(1 << 20)), H, W) for _ in range(B)])
+        sr = np.stack([synth.degrade(gt[i], int(rng.integers(1 << 20))) for i in range(B)])
+        mask = (rng.random((B, 1, H, W)) < dens).astype(np.float32)
+        if B > 1:
+            mask[0] = 0                                   # an empty image in the batch
+        n = int(mask.sum())
+        res = {}
+        for thr in (0, 1):
+            prev = engine.set_dense_threshold(thr)
+            try:
+                step = engine.LossStep(B, 3, H, W, ks, kw, 0.05, 1e-10, True, 1e3, 1e3, device=dev, capacity=cap)
+                loss, grad = step(T(sr, dev), T(gt, dev), T(mask, dev))
+                rows = min(n, cap or n)
+                assert int(step.counts[0]) == n
+                res[thr] = (loss.cpu().numpy().copy(), grad.cpu().numpy().copy(), step.ssg_sr[:rows].cpu().numpy().copy(),
+                            step.ssg_gt[:rows].cpu().numpy().copy())
+            finally:
+                engine.set_dense_threshold(prev)
+        (l0, g0, a0, b0), (l1, g1, a1, b1) = res[0], res[1]
+        assert maxerr(a0, a1) <= 2e-6 and maxerr(b0, b1) <= 2e-6, (ks, B, H, W)
+        assert np.all(np.abs(l0 - l1) <= 1e-5 * np.abs(l0) + 1e-12), (l0, l1)
+        if cap is None:
+            ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask[:, 0], ks, kw, 0.05, 1e3, 1e3)
+            tol = grad_tol_from_oracle(sr, gt, mask[:, 0], ks, kw, 0.05, ref)
+            for g_, a_, b_ in ((g0, a0, b0), (g1, a1, b1)):
+                gref, _ = ref_grad_with_gpu_signs(sr, mask[:, 0], ks, kw, 0.05, ref, a_, b_)
+                assert maxerr(g_, gref) <= tol, (ks, B, H, W, maxerr(g_, gref), tol)
+        else:
+            assert maxerr(g0, g1) <= 2e-3 * np.abs(g0).max()
