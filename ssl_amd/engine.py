@@ -136,6 +136,7 @@ class _SSGMapFn(torch.autograd.Function):
                                                   _ptr(f_plan), _ptr(counts), n_rows, ks, kw, float(sigma), float(eps),
                                                   int(bool(generalization)), _ptr(ssg), None, None, _stream()))
         ctx.save_for_backward(x, edges, counts, ssg)
+        ctx.in_dtype = img.dtype
         ctx.order = order
         ctx.split = (f_rank, f_plan)
         ctx.cfg = (n_rows, ks, kw, float(sigma), int(bool(generalization)))
@@ -159,7 +160,7 @@ class _SSGMapFn(torch.autograd.Function):
             _lib.check(L.ssg_map_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(ctx.order), _ptr(rank), _ptr(plan),
                                           _ptr(counts), n_rows, ks, kw, sigma, gen, _ptr(ssg), _ptr(g), _ptr(grad),
                                           _ptr(scratch), _ptr(fix), _stream()))
-        return grad, None, None, None, None, None, None, None, None, None, None, None
+        return grad.to(ctx.in_dtype), None, None, None, None, None, None, None, None, None, None, None
 
 
 def ssg_map(img, edges, counts, n_rows, ks, kw, sigma, eps=1e-10, generalization=True, order=None, fwd=None,
@@ -217,6 +218,7 @@ class _SSGLossFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             loss, grad = _SSGLossFn._run(x, y, edges, counts, *cfg, order, fwd, None, want_grad, det)
         ctx.cfg, ctx.order, ctx.fwd, ctx.det = cfg, order, fwd, det
+        ctx.in_dtype = sr.dtype
         if want_grad:
             ctx.save_for_backward(x, y, edges, counts, grad)
         return loss[0], loss[1]
@@ -232,7 +234,7 @@ class _SSGLossFn(torch.autograd.Function):
             up = torch.stack([g_l1.to(torch.float32).reshape(()), g_kl.to(torch.float32).reshape(())]).contiguous()
             with torch.cuda.device(x.device):
                 _, out = _SSGLossFn._run(x, y, edges, counts, *ctx.cfg, ctx.order, ctx.fwd, up, True, ctx.det)
-        return (out,) + (None,) * 14
+        return (out.to(ctx.in_dtype),) + (None,) * 14
 
 
 def ssg_loss(sr, gt, edges, counts, n_rows, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0,

@@ -1120,3 +1120,30 @@ def test_dense_and_direct_paths_agree_on_random_shapes(dev):
                 assert maxerr(g_, gref) <= tol, (ks, B, H, W, maxerr(g_, gref), tol)
         else:
             assert maxerr(g0, g1) <= 2e-3 * np.abs(g0).max()
+
+
+def test_module_accepts_half_precision_and_noncontiguous_inputs(dev):
+    """The drop-in module under autocast-style inputs: bf16 / channels-last tensors are converted to contiguous fp32
+    for the kernels (the reference's operator blindly casts data_ptr to float*, similaritywrapper.cpp:28-30) and the
+    gradient comes back in the input's dtype and layout."""
+    from ssl_amd import SSGLoss
+    rng = np.random.default_rng(9)
+    sr = T(rng.random((2, 3, 40, 48), dtype=np.float32), dev)
+    gt = T(rng.random((2, 3, 40, 48), dtype=np.float32), dev)
+    m = T((rng.random((2, 1, 40, 48)) < 0.2).astype(np.float32), dev)
+    crit = SSGLoss(7, 3, 0.5, True, 1.0, 1.0)
+    x32 = sr.clone().requires_grad_(True)
+    a, b = crit(x32, gt, m)
+    (a + b).backward()
+    xcl = sr.clone().to(memory_format=torch.channels_last).requires_grad_(True)
+    a2, b2 = crit(xcl, gt.to(memory_format=torch.channels_last), m)
+    (a2 + b2).backward()
+    assert torch.equal(a, a2) and torch.equal(x32.grad, xcl.grad)
+    xbf = sr.to(torch.bfloat16).requires_grad_(True)
+    a3, b3 = crit(xbf, gt, m)
+    (a3 + b3).backward()
+    assert xbf.grad.dtype == torch.bfloat16 and bool(torch.isfinite(xbf.grad.float()).all())
+    xr = sr.to(torch.bfloat16).float().requires_grad_(True)      # same values in fp32: same loss, same gradient
+    a4, b4 = crit(xr, gt, m)
+    (a4 + b4).backward()
+    assert torch.equal(a3, a4) and torch.equal(xbf.grad, xr.grad.to(torch.bfloat16))
