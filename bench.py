@@ -114,8 +114,9 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     (HIP events on the launch stream; results are not used)."""
     import torch
     from ssl_amd import _lib, engine
-    cfg = cfg or CONFIGS["c2"]
-    KS, KW, SIGMA, H, W = cfg["ks"], cfg["kw"], cfg["sigma"], cfg["H"], cfg["W"]
+    # geometry and kernel sizes come from the LossStep itself (`cfg` is kept for callers that pass it)
+    _, _, H, W = step.shape
+    KS, KW, SIGMA = step.cfg[0], step.cfg[1], step.cfg[2]
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
     B = sr.shape[0]

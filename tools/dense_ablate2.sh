@@ -16,7 +16,7 @@ for dens in (0.3, 1.0):
     L = _lib.lib(); P = engine._ptr
     s1 = torch.empty((n, 625), device=dev); s2 = torch.empty((n, 625), device=dev)
     def f():
-        _lib.check(L.ssg_map_forward(P(sr), P(gt), 4, 3, 256, 256, P(el.edges), P(el.order), P(el.rank), P(el.plan), P(el.counts), n, 25, 9, 1.0, 1e-10, 1, P(s1), P(s2), torch.cuda.current_stream().cuda_stream))
+        _lib.check(L.ssg_map_forward(P(sr), P(gt), 4, 3, 256, 256, P(el.edges), P(el.order), P(el.rank), P(el.plan), P(el.counts), n, 25, 9, 1.0, 1e-10, 1, P(s1), P(s2), None, torch.cuda.current_stream().cuda_stream))
     f(); torch.cuda.synchronize()
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
