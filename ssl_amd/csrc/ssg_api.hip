@@ -494,11 +494,13 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   void *lscratch = ws;
   ws += align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
   double *row_scale = (double *)ws;
+  // (deferred normalisation wherever the split backward -- whose ssg_grad_rows pass rescales -- follows)
+  const bool defer = split_ok(ks, kw, C, rank, plan, lscratch) && dense_supported(ks, kw, C);
+  // with the plan in use every kernel takes its job order from it: the full tile-major order is not built (3 launches)
+  if (defer) order = nullptr;
   int rc = ssg_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
                          W, mask_stride, lap_threshold, ks, edges, capacity, counts, rank, order, plan, escratch, stream);
   if (rc) return rc;
-  // (deferred normalisation wherever the split backward -- whose ssg_grad_rows pass rescales -- follows)
-  const bool defer = split_ok(ks, kw, C, rank, plan, lscratch) && dense_supported(ks, kw, C);
   rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
                        generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, stream);
   if (rc) return rc;
