@@ -54,16 +54,19 @@ template <int KS, int KW, int C, int TY, int RG = 4>
 struct DenseBwdGeo {
   static constexpr int TX = 32, HP = KS / 2, HK = KW / 2, HALO = HP + HK, P = KS * KS;
   static constexpr int UH = TY + 2 * HK, UW = TX + 2 * HK;    // tile grown by the window halo
-  static constexpr int NPX = UW / RG;                         // pixels per lane
+  static constexpr int NPX = (UW + RG - 1) / RG;              // pixels per lane; RG*NPX >= UW columns are walked (the
+                                                              // lanes past U see W = 0: their prefix entries are never written)
+  static constexpr int UWP = RG * NPX;
+  static constexpr bool REGW = RG == 8 && TY == 8 && UWP == UW;  // one role per lane: W from the lane's own prefix registers
   // (padded) pixels per lane in a prefix row; RG = 8: no pad and 40-float rows -- the half-wave's 4 rows x 8 groups
   // then fall on different banks (48-float rows of 6-float groups: 41 % of the LDS cycles were conflict replays)
   static constexpr int NPXP = RG == 8 ? NPX : ((NPX + 1) & ~1);
   static constexpr int RR = 64 / RG, NHALF = UH / RR;         // U-rows per wave, waves per tile
-  static constexpr int RW = UW + KS - 1, RH = UH + KS - 1;    // gradient / image region
+  static constexpr int RW = UWP + KS - 1, RH = UH + KS - 1;   // gradient / image region
   static constexpr int RWS = RW | 1;                          // channel stride inside a band row
   // band row stride: RG = 4: C odd strides; RG = 8: = 4 (mod 32), the 8 slots x 4 groups (5 floats apart) of a
   // half-wave (lane = 8 * group + row) on 32 different banks
-  static constexpr int BRS = RG == 8 ? ((C * RWS - 4 + 31) / 32 * 32 + 4) : C * RWS;
+  static constexpr int BRS = REGW ? ((C * RWS - 4 + 31) / 32 * 32 + 4) : (RG == 8 ? ((C * RWS - 8 + 15) / 16 * 16 + 8) : C * RWS);
   static constexpr int BR = RR;                               // band rows
   static constexpr int HG = 64 / TY, HOUT = (UW + HG - 1) / HG;
   // padded G field row.  The horizontal-sum lanes (tile row hty, group hg) read dword hty*GQS + HOUT*hg + m: with
@@ -74,11 +77,12 @@ struct DenseBwdGeo {
   static constexpr int GQS = GQS_MIN + ((GQS_RES - GQS_MIN % 32) + 32) % 32;
   static constexpr int PS = RG * NPXP;                        // prefix row
   // one field + its prefix rows (two copies: steps alternate); RG = 8 keeps the prefix in registers: no rows
-  static constexpr int FSZ = TY * GQS + (RG == 8 ? 0 : (TY + 1) * PS);
+  // (+4: the copy's last word is a dummy that absorbs the writes of lanes without an edge pixel / past U)
+  static constexpr int FSZ = TY * GQS + (REGW ? 0 : (TY + 1) * PS) + 4;
   static constexpr int NE_MAX = TY * TX, NCHUNK = NE_MAX / 64;
   static constexpr int NG = KS / 4;                           // full groups of 4 offsets per offset row
   static constexpr int CPL = (RW + 63) / 64;                  // region columns per lane (row loads / flushes)
-  static_assert(UH == 16 && UW % RG == 0 && (RG == 4 || RG == 8), "lane map: 16 x 4 or 2 x (8 x 8)");
+  static_assert(UH == 16 && (RG == 4 || RG == 8), "lane map: 16 x 4 or 2 x (8 x 8)");
   static_assert(KS % 4 == 1, "offset rows are consumed as groups of 4 + 1");
   static_assert(64 % TY == 0 && TY <= 8, "prefix lanes: tile row in the low lane bits");
   static constexpr size_t lds_bytes() {
@@ -97,7 +101,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   constexpr int UW = G::UW, NPX = G::NPX, NPXP = G::NPXP, RW = G::RW, RH = G::RH, RWS = G::RWS;
   constexpr int HOUT = G::HOUT, GQS = G::GQS, PS = G::PS, NCHUNK = G::NCHUNK, NG = G::NG, CPL = G::CPL;
   constexpr int FSZ = G::FSZ;
-  constexpr int DUMMY = 2 * FSZ;  // word after both copies (relative to the first field): absorbs the field writes of lanes without an edge pixel
+  constexpr bool REGW = G::REGW;
+  constexpr int DUMMY = FSZ - 1;  // last word of a copy (offsets are relative to the copy's base)
   constexpr int NCH_LO = NCH <= 2 ? 0 : NCH / 2;  // instantiations: 2 and 4 chunks
   static_assert(NG % 2 == 0 && NCH <= NCHUNK, "two G slots alternate over an even number of groups");
 
@@ -162,18 +167,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   // second half walks the tile rows in reverse (lane j <-> tile row 7-j, U-row 15-j), so its prefix is the suffix
   // sum rows 7-j..7 it needs.  Only offset rows whose window is cut vertically fetch two other lanes' prefixes
   // (ds_bpermute inside the 8-lane group).
-  const int half = RG == 8 ? (int)blockIdx.z : 0;
+  const int half = REGW ? (int)blockIdx.z : 0;
   const int jrow = lane & 7;
-  const int g = RG == 8 ? lane >> 3 : lane % RG;
-  const int r = RG == 8 ? (half ? 15 - jrow : jrow) : RR * (int)blockIdx.z + lane / RG;  // U-row of the tile
-  const int hty = RG == 8 ? jrow : lane % TY, hg = RG == 8 ? g : lane / TY;
+  const int g = REGW ? lane >> 3 : lane % RG;
+  const int r = REGW ? (half ? 15 - jrow : jrow) : RR * (int)blockIdx.z + lane / RG;  // U-row of the tile
+  const int hty = REGW ? jrow : lane % TY, hg = REGW ? g : lane / TY;
   const float m1 = hty >= 1 ? 1.f : 0.f, m2 = hty >= 2 ? 1.f : 0.f, m4 = hty >= 4 ? 1.f : 0.f;
-  const int hsrc = (RG == 8 && half ? TY - 1 - hty : hty) * GQS + HOUT * hg;  // (offsets relative to a copy's base)
+  const int hsrc = (REGW && half ? TY - 1 - hty : hty) * GQS + HOUT * hg;  // (offsets relative to a copy's base)
   int hdst[HOUT];
 #pragma unroll
   for (int i = 0; i < HOUT; ++i) {
     const int uc = HOUT * hg + i;
-    hdst[i] = TY * GQS + (hty + 1) * PS + (uc < UW ? (uc / NPX) * NPXP + uc % NPX : PS - 1);
+    hdst[i] = uc < UW ? TY * GQS + (hty + 1) * PS + (uc / NPX) * NPXP + uc % NPX : DUMMY;  // (columns past U: the dummy word)
   }
 
   float wout[HOUT];  // RG = 8: the prefix of the offset prepared last (consumed by the next step)
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
       if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
     }
-    if constexpr (RG != 8) {
+    if constexpr (!REGW) {
 #pragma unroll
       for (int i = 0; i < HOUT; ++i) f[hdst[i]] = out[i];
     } else {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     lneg = 4 * (base + (jn < 0 ? 0 : jn));
   };
   auto w_regs = [&](bool full, int lpos, int lneg, float mpos, float mneg, float (&Wv)[NPX]) {
-    static_assert(RG != 8 || HOUT == NPX, "one role per lane");
+    static_assert(!REGW || HOUT == NPX, "one role per lane");
     if (full) {
 #pragma unroll
       for (int i = 0; i < NPX; ++i) Wv[i] = wout[i < HOUT ? i : 0];
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     int pa = 0, pb = 0, lpos = 0, lneg = 0;
     float mpos = 0.f, mneg = 0.f;
     const bool rowfull = ylo == -HK && yhi == HK;
-    if constexpr (RG == 8) cut_rows(ylo, yhi, lpos, lneg, mpos, mneg);
+    if constexpr (REGW) cut_rows(ylo, yhi, lpos, lneg, mpos, mneg);
     else prefix_rows(ylo, yhi, pa, pb);
     float *fe = fld + (qyi & 1) * FSZ, *fo = fld + ((qyi & 1) ^ 1) * FSZ;  // copies of the even / odd q_x of this row
     const int slr = (r + qyi) & RMASK;
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       if constexpr (qxi == KS - 2) load_last(qyn);
       // ---- top: every LDS read of the step ----
       float Wv[NPX], v[HOUT + 2 * HK], fl[C], wn[C];
-      if constexpr (RG == 8) {
+      if constexpr (REGW) {
         w_regs(rowfull, lpos, lneg, mpos, mneg, Wv);
       } else {
 #pragma unroll
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
         if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
       }
       // ---- end: every LDS write of the step ----
-      if constexpr (RG == 8) {
+      if constexpr (REGW) {
 #pragma unroll
         for (int i = 0; i < HOUT; ++i) wout[i] = out[i];
       } else {
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     __builtin_amdgcn_wave_barrier();
     x_stage(std::integral_constant<int, -HK>{}, std::integral_constant<int, HK>{}, fld);
     __builtin_amdgcn_wave_barrier();
-    if constexpr (RG == 8) {
+    if constexpr (REGW) {
       w_regs(true, 0, 0, 0.f, 0.f, vbox);
     } else {
       int pa, pb;
@@ -548,7 +553,10 @@ static int launch_one(const DenseBwdParams &p, hipStream_t st) {
 int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st) {
   if (!dense_bwd_supported(ks, kw, C)) return -1;
   if (p.max_tiles == 0) return 0;
-  if (ks == 49) return launch_one<49, 13, 3, 4, 2, 4>(p, st);  // 4 x 32 tiles: at most 128 edge pixels
+  // 4 x 32 tiles: at most 128 edge pixels.  One wave per tile: the two-waves-per-tile layout (RG = 8, 48 padded
+  // columns, prefix rows through LDS) was measured slower here, 3.16 vs 2.27 ms at C5 -- with 4 tile rows each half
+  // repeats a W stage that is most of its work
+  if (ks == 49) return launch_one<49, 13, 3, 4, 2, 4>(p, st);
   int rc = launch_one<25, 9, 3, 8, 2, 8>(p, st);
   if (!rc) rc = launch_one<25, 9, 3, 8, 4, 8>(p, st);
   return rc;

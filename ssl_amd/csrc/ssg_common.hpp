@@ -63,6 +63,8 @@ __device__ __forceinline__ void pin_row(float (&v)[N]) {
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
   } else if constexpr (N == 5) {
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");
+  } else if constexpr (N == 6) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])::"memory");
   } else if constexpr (N == 7) {
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6])::"memory");
   } else if constexpr (N == 9) {
