@@ -40,6 +40,32 @@ __device__ __forceinline__ float dpp_row_shr(float v) {
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// Inclusive prefix over 8 tile rows held 2 lanes apart in a 16-lane DPP row, for 5 values at once: 15 in-place DPP
+// adds (a lane whose source lies outside its row keeps its value).  The leading s_nop covers the VALU-write ->
+// DPP-read wait states the assembler does not insert for inline asm; inside the block 4 instructions separate a
+// register's write from its next DPP read.
+__device__ __forceinline__ void dpp_prefix8x5(float (&v)[5]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
+}
+
 // Nothing moves across an offset step: without it hipcc hoists the address arithmetic and the LDS loads of all
 // k_s unrolled steps to the top of the offset row (1,100 live values, 650 spilled).
 __device__ __forceinline__ void step_fence() {
@@ -168,8 +194,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   // sum rows 7-j..7 it needs.  Only offset rows whose window is cut vertically fetch two other lanes' prefixes
   // (ds_bpermute inside the 8-lane group).
   const int half = REGW ? (int)blockIdx.z : 0;
-  const int jrow = lane & 7;
-  const int g = REGW ? lane >> 3 : lane % RG;
+  // (RG = 8 lane map: lane = 2*j + (g & 1) + 16*(g >> 1) -- the 8 tile rows of a group sit 2 lanes apart inside one
+  // 16-lane DPP row, so that the prefix scan is three in-place `v_add_f32_dpp row_shr:2/4/8`: a lane whose source
+  // falls off its DPP row is disabled (bound_ctrl off), which is exactly the scan's "j >= shift" condition.  A
+  // half-wave still holds groups 0..3 x rows 0..7, so the bank maps below are unchanged)
+  const int jrow = REGW ? (lane >> 1) & 7 : lane & 7;
+  const int g = REGW ? ((lane & 1) | ((lane >> 4) << 1)) : lane % RG;
   const int r = REGW ? (half ? 15 - jrow : jrow) : RR * (int)blockIdx.z + lane / RG;  // U-row of the tile
   const int hty = REGW ? jrow : lane % TY, hg = REGW ? g : lane / TY;
   const float m1 = hty >= 1 ? 1.f : 0.f, m2 = hty >= 2 ? 1.f : 0.f, m4 = hty >= 4 ? 1.f : 0.f;
@@ -202,11 +232,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     }
     // inclusive prefix over the tile rows (adjacent lanes); the 0/1 factors stop a row group from reading
     // its neighbour's lanes
+    if constexpr (REGW && HOUT == 5) {
+      dpp_prefix8x5(out);
+    } else {
 #pragma unroll
-    for (int i = 0; i < HOUT; ++i) {
-      out[i] = __builtin_fmaf(dpp_row_shr<1>(out[i]), m1, out[i]);
-      if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
-      if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
+      for (int i = 0; i < HOUT; ++i) {
+        out[i] = __builtin_fmaf(dpp_row_shr<1>(out[i]), m1, out[i]);
+        if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
+        if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
+      }
     }
     if constexpr (!REGW) {
 #pragma unroll
@@ -237,7 +271,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     a = a < 0 ? 0 : a;
     bb = bb > TY - 1 ? TY - 1 : bb;
     const bool none = a > bb;
-    const int base = lane & ~7;
+    const int base = lane & ~14;  // row 0 of this lane's group (rows are 2 lanes apart)
     int jp, jn;
     if (!half) {  // lane k holds rows 0..k: rows [a,bb] = lane bb - lane (a-1)
       jp = bb;
@@ -248,8 +282,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     }
     mpos = none ? 0.f : 1.f;
     mneg = (none || jn < 0) ? 0.f : 1.f;
-    lpos = 4 * (base + (none ? 0 : jp));
-    lneg = 4 * (base + (jn < 0 ? 0 : jn));
+    lpos = 4 * (base + 2 * (none ? 0 : jp));
+    lneg = 4 * (base + 2 * (jn < 0 ? 0 : jn));
   };
   auto w_regs = [&](bool full, int lpos, int lneg, float mpos, float mneg, float (&Wv)[NPX]) {
     static_assert(!REGW || HOUT == NPX, "one role per lane");
@@ -460,11 +494,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
         for (int m = i + HK - nhi + 1; m <= i + HK - nlo; ++m) t += v[m];
         out[i] = t;
       }
+      if constexpr (REGW && HOUT == 5) {
+        dpp_prefix8x5(out);
+      } else {
 #pragma unroll
-      for (int i = 0; i < HOUT; ++i) {
-        out[i] = __builtin_fmaf(dpp_row_shr<1>(out[i]), m1, out[i]);
-        if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
-        if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
+        for (int i = 0; i < HOUT; ++i) {
+          out[i] = __builtin_fmaf(dpp_row_shr<1>(out[i]), m1, out[i]);
+          if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
+          if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
+        }
       }
       // ---- end: every LDS write of the step ----
       if constexpr (REGW) {
