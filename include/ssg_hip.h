@@ -8,6 +8,14 @@
  * torch.cuda.current_stream().cuda_stream from PyTorch).  All floating point
  * is IEEE fp32; indices are int32.
  *
+ * Stream semantics: everything a call queues is ordered after the work already on
+ * `stream` and before whatever the caller queues on `stream` next.  Inside a call
+ * the direct kernel of a forward / backward pass (k_s <= 25) runs on a library-owned
+ * side stream beside the dense-tile kernel, forked from and joined back into
+ * `stream` with events -- invisible to the caller, and a stream capture of `stream`
+ * records it as two parallel graph branches.  SSG_OVERLAP=0 (environment, read at
+ * first use) keeps every launch on `stream` itself.
+ *
  * Reference interface each group replaces (paths relative to
  * /root/reference/GAN-Based-SR/):
  *   (A) ssg_compute_similarity[_backward]   <- basicsr/losses/similarity/similarity.h:2-23

@@ -104,6 +104,58 @@ extern "C" int ssg_set_profile_mask(int mask) {
   return prev;
 }
 
+// The dense-tile kernel and the direct kernel of a pass work on disjoint SSG rows (and add into the gradient with
+// atomics), so the direct one runs on a side stream beside the dense one: fork = side waits for an event on the
+// caller's stream, join = the caller's stream waits for the side's event.  Both are plain event edges, so a stream
+// capture of the caller's stream (hipGraph) records the fork as two parallel branches.  One side stream and two
+// events per (host thread, device); SSG_OVERLAP=0 keeps every launch on the caller's stream.  Measured on MI355X:
+// C2 (k_s 25) 1.541 -> 1.510 ms per step; C5 (k_s 49, every kernel already fills the chip for its whole run)
+// 9.15 -> 9.64 ms -- so the fork is taken for k_s <= 25 only.
+struct SideStream {
+  hipStream_t side = nullptr;
+  hipEvent_t forked = nullptr, joined = nullptr;
+};
+static bool overlap_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SSG_OVERLAP");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
+}
+static SideStream *side_stream() {
+  constexpr int MAXDEV = 64;
+  thread_local SideStream tab[MAXDEV];
+  int dev = 0;
+  if (!overlap_enabled() || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  SideStream &s = tab[dev];
+  if (!s.side) {
+    if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s.forked, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.joined, hipEventDisableTiming) != hipSuccess) {
+      s.side = nullptr;
+      return nullptr;
+    }
+  }
+  return &s;
+}
+// stream for the second branch after everything queued on `st` so far (st itself when overlap is off)
+static hipStream_t fork_from(hipStream_t st, int ks, SideStream *&s) {
+  s = ks <= 25 ? side_stream() : nullptr;
+  if (!s) return st;
+  if (hipEventRecord(s->forked, st) != hipSuccess || hipStreamWaitEvent(s->side, s->forked, 0) != hipSuccess) {
+    s = nullptr;
+    return st;
+  }
+  return s->side;
+}
+static int join_to(hipStream_t st, SideStream *s) {
+  if (!s) return 0;
+  int rc = (int)hipEventRecord(s->joined, s->side);
+  if (!rc) rc = (int)hipStreamWaitEvent(st, s->joined, 0);
+  return rc;
+}
+
 static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (kw & 1) && kw <= ks; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -175,16 +227,20 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   d.W = p.W;
   d.qsplit = bwd_qsplit();
   d.dbg = p.dbg;
+  SideStream *fk = nullptr;
+  hipStream_t st2 = (dbg_mask() & ((1 << 27) | (1 << 28))) ? st : fork_from(st, p.ks, fk);
   rc = (dbg_mask() & (1 << 27)) ? 0 : launch_bwd_dense(d, p.ks, p.kw, p.C, st);
-  if (rc) return rc;
-  if (dbg_mask() & (1 << 28)) return 0;
-  BwdParams s = p;
-  s.mode = GRAD_D;
-  s.gin = grows;
-  s.order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
-  s.n_dev = plan;  // n_sparse
-  s.partials = nullptr;
-  return launch_bwd(s, st);
+  if (!rc && !(dbg_mask() & (1 << 28))) {
+    BwdParams s = p;
+    s.mode = GRAD_D;
+    s.gin = grows;
+    s.order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
+    s.n_dev = plan;  // n_sparse
+    s.partials = nullptr;
+    rc = launch_bwd(s, st2);
+  }
+  const int rcj = join_to(st, fk);
+  return rc ? rc : rcj;
 }
 
 // Deterministic mode: the kernels add into the caller's zeroed fixed-point buffer; one flush folds it into grad.
@@ -351,11 +407,15 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
       const int rc0 = (int)hipMemsetAsync(row_scale, 0, sizeof(double) * 2 * (size_t)n_rows, (hipStream_t)stream);
       if (rc0) return rc0;
     }
-    const int rc = (dbg_mask() & (1 << 25)) ? 0 : launch_fwd_dense(d, ks, kw, C, (hipStream_t)stream);
-    if (rc) return rc;
+    SideStream *fk = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st2 = (dbg_mask() & ((1 << 25) | (1 << 26))) ? st : fork_from(st, ks, fk);
+    int rc = (dbg_mask() & (1 << 25)) ? 0 : launch_fwd_dense(d, ks, kw, C, st);
     p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
     p.n_dev = fwd_plan;  // n_sparse
-    if (dbg_mask() & (1 << 26)) return 0;
+    if (!rc && !(dbg_mask() & (1 << 26))) rc = launch_fwd(p, st2);
+    const int rcj = join_to(st, fk);
+    return rc ? rc : rcj;
   }
   return launch_fwd(p, (hipStream_t)stream);
 }
