@@ -29,6 +29,60 @@
 
 namespace ssg {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// value of lane + D inside the lane's quad (the last lanes read the quad's last lane: their sums belong to centres
+// outside the tile)
+template <int D>
+__device__ __forceinline__ float quad_next(float v) {
+  constexpr int ctrl = D == 1 ? 0xF9 : 0xFE;  // quad_perm [1,2,3,3] / [2,3,3,3]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+}
+
+// Sums of consecutive entries of a register array as trees of power-of-two blocks (the compiler shares the blocks
+// between the sums that contain them): depth log2 instead of the length -- a chain of 9 additions per window costs
+// the KL of nearly flat rows its 1e-5 (tests: kl_conditioning_on_flat_rows).
+template <int LO, int LEN, typename T, int N>
+__device__ __forceinline__ T block_sum(const T (&e)[N]) {
+  static_assert(LEN >= 1 && (LEN & (LEN - 1)) == 0 && LO >= 0 && LO + LEN <= N, "power-of-two block inside the array");
+  if constexpr (LEN == 1) return e[LO];
+  else return block_sum<LO, LEN / 2>(e) + block_sum<LO + LEN / 2, LEN / 2>(e);
+}
+constexpr int floor_pow2(int n) { return n < 2 ? 1 : 2 * floor_pow2(n / 2); }
+// e[LO] + ... + e[LO+LEN-1], blocks aligned from LO (prefix sums share them)
+template <int LO, int LEN, typename T, int N>
+__device__ __forceinline__ T sum_from(const T (&e)[N]) {
+  constexpr int B = floor_pow2(LEN);
+  if constexpr (B == LEN) return block_sum<LO, LEN>(e);
+  else return block_sum<LO, B>(e) + sum_from<LO + B, LEN - B>(e);
+}
+// e[HI-LEN] + ... + e[HI-1], blocks aligned from HI downwards (suffix sums share them)
+template <int HI, int LEN, typename T, int N>
+__device__ __forceinline__ T sum_upto(const T (&e)[N]) {
+  constexpr int B = floor_pow2(LEN);
+  if constexpr (B == LEN) return block_sum<HI - LEN, LEN>(e);
+  else return block_sum<HI - B, B>(e) + sum_upto<HI - B, LEN - B>(e);
+}
+
+// sum_k w[k] v[k] + rest with 0/1 weights (the products are exact) as a balanced tree of packed operations: two
+// accumulator pairs take the taps four at a time.  Depth 5 instead of a chain of KW dependent FMAs -- the chain's
+// rounding costs the KL of nearly flat rows its 1e-5 (tests: kl_conditioning_on_flat_rows), and its latency the
+// two waves of a SIMD cannot hide.
+template <int KW>
+__device__ __forceinline__ float tap_sum(const float (&v)[KW], const float (&w)[KW], float rest) {
+  static_assert(KW % 2 == 1 && KW >= 5, "pairs of taps and a last one");
+  constexpr int NP = KW / 2;
+  f2 a = f2{v[0], v[1]} * f2{w[0], w[1]}, b = f2{v[2], v[3]} * f2{w[2], w[3]};
+#pragma unroll
+  for (int j = 2; j < NP; ++j) {
+    const f2 vv = f2{v[2 * j], v[2 * j + 1]}, ww = f2{w[2 * j], w[2 * j + 1]};
+    if (j % 2 == 0) a = __builtin_elementwise_fma(vv, ww, a);
+    else b = __builtin_elementwise_fma(vv, ww, b);
+  }
+  const f2 r2 = a + b;
+  return (r2.x + r2.y) + __builtin_fmaf(w[KW - 1], v[KW - 1], rest);
+}
+
 struct DenseParams {
   const float *img[2];
   float *out[2];
@@ -47,24 +101,46 @@ struct DenseParams {
 };
 
 constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1) (8 for k_w = 9, 4 for k_w = 13)
-// Row stride of the H buffers (horizontal sums on the 16 x 32 centre columns of U).  The tile's edge pixels read
-// them at (row ey + k, column ex): with stride 32 every pixel of a VERTICAL edge line falls on one LDS bank (half of
-// the kernel's LDS cycles were conflict replays, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.49); with 44 two
-// pixels collide only if dx = -12 dy (mod 32), which no edge curve does inside an 8-row tile.
-constexpr int DT_HS = 44;
+// Pixels of a U-row per lane: the 4 lanes of a quad cover the row without overlap (10 x 4 = 40 = U for k_w 9; 12 x 4
+// = 48 >= 44 for k_w 13, even so that the pixels pair up for packed fp32 math).
+constexpr int dense_lane_px(int kw) { return kw == 9 ? 10 : 12; }
+// H buffers (horizontal sums on the 16 U-rows x 4L centre columns): lane (r, g) stores its L sums in row r, the
+// tile's edge pixels gather them at (row ey + k, column of ex).  The LDS, not the VALU, bounds this kernel, so the
+// layout is chosen per size for what its tiles do most:
+//   k_w 9  (8 x 32 tiles, a few dozen edge pixels each): stores first -- the lane's register pairs (centres k, k + L/2)
+//          go out as 8-byte stores at r * 40 + 10 g + 2 (k % 5); a ds_write_b64 is served 16 lanes (4 rows x 4
+//          groups) at a time on 32 banks and S = 8 (mod 32) puts the 16 pairs on 16 different bank pairs (S = 44:
+//          2 LDS cycles per cycle, SQ_LDS_BANK_CONFLICT over half of SQ_LDS_IDX_ACTIVE).  The gathers of an arbitrary
+//          pixel set collide ~3-way whatever the stride.
+//   k_w 13 (4 x 32 tiles, in practice full ones -- C5 is a 100 % mask): gathers first -- 32 lanes read 32 consecutive
+//          centres of one row, conflict-free only if column = ex; the stores are then single dwords (12 g + k at an
+//          odd row stride: 2-way, the best a contiguous row allows).
+constexpr bool dense_h_paired(int kw) { return kw == 9; }
+constexpr int dense_h_stride(int kw) { return kw == 9 ? 40 : 49; }
+__device__ __forceinline__ int dense_h_col(int ex, int L, bool paired) {
+  const int k = ex % L;
+  return paired ? ex - k + 2 * (k % (L / 2)) + k / (L / 2) : ex;
+}
+
 
 // NW waves per workgroup share the tile's image region; wave w walks the offset rows q_y = w (mod NW).  (25,9): 4
-// (47 KB of LDS, two workgroups per CU); (49,13): 8 -- its 71 KB region allows one workgroup per CU, and a lone
-// wave per SIMD issues a VALU instruction only every ~4 cycles (5.4 -> 3.x ms at C5).
+// (47 KB of LDS, two workgroups per CU, 2 waves per SIMD -- hence the register cap: with 14 AGPRs on top of 256 VGPRs
+// only one workgroup fits and the kernel takes 0.63 instead of 0.45 ms); (49,13): its 71 KB region allows one
+// workgroup per CU, and a lone wave per SIMD issues a VALU instruction only every ~4 cycles, so 7 waves -- 49 rows
+// are 7 each, with 8 the workgroup waits for the one wave that has a 7th row.
 template <int KS, int KW, int C, int NW>
-__global__ __launch_bounds__(64 * NW) void ssg_fwd_dense(DenseParams p) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_fwd_dense(DenseParams p) {
   constexpr int NT = 64 * NW;
   constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK, DT_Y = 16 - 2 * HK;
   constexpr int RH = DT_Y + 2 * HALO, RWD = DT_X + 2 * HALO, RS = RWD + 1;  // image region
   constexpr int UH = DT_Y + 2 * HK, UW = DT_X + 2 * HK;                      // window halo U
-  constexpr int LW = 8 + KW - 1;                                             // U columns per lane
+  constexpr int L = dense_lane_px(KW), HL = L / 2;                           // U columns per lane (10 / 12), no overlap
+  constexpr int NV = HL + KW - 1;                                            // pixel pairs the windows of a lane reach
+  constexpr int DT_HS = dense_h_stride(KW);
+  constexpr bool HPAIR = dense_h_paired(KW);
   constexpr int NE_MAX = DT_Y * DT_X, NCHUNK = NE_MAX / 64;
-  static_assert(UH == 16 && DT_X == 32, "lane map: 16 U-rows x 4 column groups of 8 centres");
+  static_assert(UH == 16 && DT_X == 32 && 4 * L >= UW && 4 * L <= DT_HS && L % 2 == 0 && KW - 1 <= L,
+                "lane map: 16 U-rows x 4 column groups (one quad) of L pixels; a window spans two lanes");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *reg = smem;                       // [C][RH][RS]
@@ -156,22 +232,35 @@ __global__ __launch_bounds__(64 * NW) void ssg_fwd_dense(DenseParams p) {
     float t = 0.f;
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) t += F[ur * UW + tc + kx];
-    HF[ur * DT_HS + tc] = t;
+    HF[ur * DT_HS + dense_h_col(tc, L, HPAIR)] = t;
   }
   __syncthreads();
 
   // ---- main loop: wave wv takes offset rows qyi = wv, wv+4, ... ----
   const int r = lane >> 2, g = lane & 3;
-  float iu[C][LW];
+  // Packed fp32: register pair j of the lane = its pixels (j, j + L/2), so that every operation below is one
+  // v_pk_* on two pixels, and the circular window of I[u+q] pairs up the same way whatever the step (slot s and
+  // slot s + L/2 always hold two pixels L/2 apart; for s >= L/2 in swapped order, which the packed operand select
+  // absorbs).
+  f2 iu[C][HL];
 #pragma unroll
   for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int i = 0; i < LW; ++i) iu[c][i] = reg[(c * RH + r + HP) * RS + 8 * g + HP + i];
-  float Fr[LW];  // |I|^2 of the lane's LW pixels (complement of the columns that leave the area)
+    for (int j = 0; j < HL; ++j) {
+      const float *q = reg + (c * RH + r + HP) * RS + L * g + HP + j;
+      iu[c][j] = f2{q[0], q[HL]};
+    }
+  // |I|^2 on the pixels the lane's windows reach, paired like the window values V of a truncated step (below):
+  // Fv[m] = (F[m], F[m + L/2]), m = 0 .. L/2 + KW - 2, columns counted from the lane's first pixel.  The last
+  // group's columns past UW belong to centres outside the tile (never read): clamped.
+  f2 Fv[NV];
 #pragma unroll
-  for (int i = 0; i < LW; ++i) Fr[i] = F[r * UW + 8 * g + i];
+  for (int m = 0; m < NV; ++m) {
+    const int c0 = L * g + m, c1 = c0 + HL;
+    Fv[m] = f2{F[r * UW + (c0 < UW ? c0 : UW - 1)], F[r * UW + (c1 < UW ? c1 : UW - 1)]};
+  }
   float *hb = Hb + wv * UH * DT_HS;
-  float *hrow = hb + r * DT_HS + 8 * g;
+  float *hrow = hb + r * DT_HS + L * g;  // the lane's centres L*g .. L*g + L-1 (those >= DT_X: written, never read)
   // exp(x) = 2^(x log2 e), constant folded (see ssg_fwd.hip)
   const float nk = (float)(-1.4426950408889634 / ((double)(C * KW * KW) * (double)p.sigma));
   double rs[NCHUNK];
@@ -188,7 +277,7 @@ __global__ __launch_bounds__(64 * NW) void ssg_fwd_dense(DenseParams p) {
     eon[ck] = e < n_e;
     const int ec = eon[ck] ? e : 0;
     const int ey = elist[3 * ec], ex = elist[3 * ec + 1];
-    hoff[ck] = ey * DT_HS + ex;  // window row k of the centre is U-row ey + k
+    hoff[ck] = ey * DT_HS + dense_h_col(ex, L, HPAIR);  // window row k of the centre is U-row ey + k
     orow[ck] = (size_t)elist[3 * ec + 2] * P;
   }
 
@@ -210,78 +299,115 @@ __global__ __launch_bounds__(64 * NW) void ssg_fwd_dense(DenseParams p) {
       av[ck] = 0.f;
       if (ck * 64 < n_e && (ylo > -HK || yhi < HK)) {
         const float *fc = HF + hoff[ck];
+        float fv[KW], cw[KW];
 #pragma unroll
-        for (int k = 0; k < KW; ++k) av[ck] = __builtin_fmaf(1.f - wgt[k], fc[k * DT_HS], av[ck]);
+        for (int k = 0; k < KW; ++k) {
+          fv[k] = fc[k * DT_HS];
+          cw[k] = 1.f - wgt[k];
+        }
+        av[ck] = tap_sum<KW>(fv, cw, 0.f);
       }
     }
-    const float *rq = reg + (r + qyi) * RS + 8 * g;  // + c*RH*RS + column (i + qxi)
-    float w[C][LW];
+    const float *rq = reg + (r + qyi) * RS + L * g;  // + c*RH*RS + column (i + qxi)
+    f2 w[C][HL];  // slots (t, t + L/2)
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int i = 0; i < LW; ++i) w[c][i] = rq[c * RH * RS + i];
+      for (int t = 0; t < HL; ++t) w[c][t] = f2{rq[c * RH * RS + t], rq[c * RH * RS + t + HL]};
     constexpr int SB = 13;  // consecutive offsets per edge pixel buffered in registers and stored together
     float evb[NCHUNK][SB];
     static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
-      // E_q on the lane's LW pixels; the window of I[u+q] is a circular buffer whose slot index is
-      // a compile-time function of the step: pixel i of step qxi lives in slot (i + qxi) % LW
-      float E[LW];
+      // E_q on the lane's L pixels, E[j] = (pixel j, pixel j + L/2); pixel i of step qxi lives in window slot
+      // (i + qxi) % L -- a compile-time function of the step
+      f2 E[HL];
 #pragma unroll
-      for (int i = 0; i < LW; ++i) {
-        float t = 0.f;
+      for (int j = 0; j < HL; ++j) {
+        const int a = (j + qxi) % L;  // slot of pixel j; pixel j + L/2 sits in slot (a + L/2) % L
+        f2 t = f2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          const float d = iu[c][i] - w[c][(i + qxi) % LW];
-          t = __builtin_fmaf(d, d, t);
+          const f2 wv2 = a < HL ? w[c][a] : w[c][a - HL].yx;
+          const f2 d = iu[c][j] - wv2;
+          t = __builtin_elementwise_fma(d, d, t);
         }
-        // pixels whose column left the area enter the sums with |I|^2 instead of E_q: window tap kx of centre
-        // column j is pixel i = j + HK + kx, i.e. kx = i - HK - j; only one-sided sets occur, so the swap can be
-        // made per (i, j) at compile time below
-        E[i] = t;
+        E[j] = t;
       }
-      // horizontal sums for the 8 centre columns: E on taps [xlo, xhi], |I|^2 on the others
-      float Hs[8];
-      if constexpr (xlo == -HK && xhi == HK && KW == 9) {
-        // full 9-tap windows (17 of the 25 steps): pair / quad / octet sums shared between the 8 outputs,
-        // 44 additions instead of 64
-        float p2[15], p4[13];
+      // horizontal sums for the lane's L centre columns k (window = pixels k .. k+KW-1 of the row: the lane's own
+      // from k to L-1, then the next lane's of the quad): E on taps [xlo, xhi], |I|^2 on the others.
+      // Hs[k] = (centre k, centre k + L/2).
+      f2 Hs[HL];
+      if constexpr (xlo == -HK && xhi == HK) {
+        // full windows (17 of 25 / 37 of 49 steps): own suffix sum + the next lane's prefix sum.  Prefix and suffix
+        // sums of the two half rows come from shared power-of-two blocks of pairs (packed), the sums across the
+        // halves and across the lanes are scalar: ~25 VALU instead of L (KW-1) = 80
+        float Pf[L], Sf[L];  // Pf[m] = pixels 0..m, Sf[k] = pixels k..L-1 (only the ones used survive)
+        static_for(std::make_integer_sequence<int, HL>{}, [&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const f2 pl = sum_from<0, m + 1>(E);    // (pixels 0..m, pixels L/2 .. L/2+m)
+          const f2 su = sum_upto<HL, HL - m>(E);  // (pixels m..L/2-1, pixels L/2+m .. L-1)
+          const f2 tot = sum_from<0, HL>(E);
+          Pf[m] = pl.x;
+          Pf[m + HL] = tot.x + pl.y;
+          Sf[m + HL] = su.y;
+          Sf[m] = su.x + tot.y;
+        });
+        float hs[L];
+        static_for(std::make_integer_sequence<int, L>{}, [&](auto kc) {
+          constexpr int k = decltype(kc)::value, last = k + KW - 1;  // window [k, last] in the lane's own coordinates
+          if constexpr (last < L) {
+            static_assert(k == 0 || last == L - 1, "in-lane windows: a prefix or a suffix");
+            hs[k] = k == 0 ? Pf[last] : Sf[k];
+          } else {
+            hs[k] = Sf[k] + quad_next<1>(Pf[last - L]);
+          }
+        });
 #pragma unroll
-        for (int i = 0; i < 15; ++i) p2[i] = E[i] + E[i + 1];
+        for (int k = 0; k < HL; ++k) Hs[k] = f2{hs[k], hs[k + HL]};
+      } else {
+        // truncated windows: V[m] = (value m, value m + L/2) of the row continued into the next lane, value = E on
+        // the taps kept and |I|^2 (Fv) on the others; Hs[k] = sum_t V[k + t]
+        f2 V[NV];
 #pragma unroll
-        for (int i = 0; i < 13; ++i) p4[i] = p2[i] + p2[i + 2];
+        for (int m = 0; m < NV; ++m) {
+          if (m < HL) V[m] = E[m];
+          else if (m < L) V[m] = f2{E[m - HL].y, quad_next<1>(E[m - HL].x)};
+          else V[m] = f2{quad_next<1>(E[m - L].x), quad_next<1>(E[m - L].y)};
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Hs[j] = (p4[j] + p4[j + 4]) + E[j + 8];
-      } else if constexpr (xlo == -HK && xhi == HK && KW == 13) {
-        // full 13-tap windows: 13 = 8 + 4 + 1 from shared pair / quad / octet sums (53 additions instead of 96)
-        float p2[19], p4[17], p8[8];
+        for (int k = 0; k < HL; ++k) {
+          f2 t = f2{0.f, 0.f};
+          bool first = true;
 #pragma unroll
-        for (int i = 0; i < 19; ++i) p2[i] = E[i] + E[i + 1];
-#pragma unroll
-        for (int i = 0; i < 17; ++i) p4[i] = p2[i] + p2[i + 2];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) p8[j] = p4[j] + p4[j + 4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Hs[j] = (p8[j] + p4[j + 8]) + E[j + 12];
-      } else
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float t = E[j + HK + xlo];
-#pragma unroll
-        for (int kx = xlo + 1; kx <= xhi; ++kx) t += E[j + HK + kx];
-#pragma unroll
-        for (int kx = -HK; kx < xlo; ++kx) t += Fr[j + HK + kx];
-#pragma unroll
-        for (int kx = xhi + 1; kx <= HK; ++kx) t += Fr[j + HK + kx];
-        Hs[j] = t;
+          for (int tp = 0; tp < KW; ++tp) {
+            const bool kept = tp - HK >= xlo && tp - HK <= xhi;
+            const f2 v = kept ? V[k + tp] : Fv[k + tp];
+            t = first ? v : t + v;
+            first = false;
+          }
+          Hs[k] = t;
+        }
       }
-      *(float4 *)(hrow) = make_float4(Hs[0], Hs[1], Hs[2], Hs[3]);
-      *(float4 *)(hrow + 4) = make_float4(Hs[4], Hs[5], Hs[6], Hs[7]);
-      // next q_x: the pixel that leaves the window (slot qxi % LW) is replaced by the one that enters
+      if constexpr (HPAIR) {
+#pragma unroll
+        for (int k = 0; k < HL; ++k) *(f2 *)(hrow + 2 * k) = Hs[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < HL; ++k) {
+          hrow[k] = Hs[k].x;
+          hrow[k + HL] = Hs[k].y;
+        }
+      }
+      // next q_x: the pixel that leaves the window (slot qxi % L) is replaced by the one that enters
       if (qxi + 1 < KS) {
+        constexpr int sl = qxi % L;
 #pragma unroll
-        for (int c = 0; c < C; ++c) w[c][qxi % LW] = rq[c * RH * RS + LW + qxi];
+        for (int c = 0; c < C; ++c) {
+          const float v = rq[c * RH * RS + L + qxi];
+          if constexpr (sl < HL) w[c][sl].x = v;
+          else w[c][sl - HL].y = v;
+        }
       }
       // (the H buffer is private to this wave and LDS operations of one wave execute in issue order: the reads
       // below see the writes above, and the next step's writes cannot overtake them -- no wait, no barrier)
@@ -293,9 +419,7 @@ __global__ __launch_bounds__(64 * NW) void ssg_fwd_dense(DenseParams p) {
           float hv[KW];
 #pragma unroll
           for (int k = 0; k < KW; ++k) hv[k] = hc[k * DT_HS];
-          float d = av[ck];
-#pragma unroll
-          for (int k = 0; k < KW; ++k) d = __builtin_fmaf(wgt[k], hv[k], d);
+          const float d = tap_sum<KW>(hv, wgt, av[ck]);
           const float ev = __builtin_amdgcn_exp2f(d * nk);
           rs[ck] += (double)ev;
           // every lane writes its own SSG row: single dwords are one L2 request per lane and step (request-
@@ -381,7 +505,7 @@ template <int KS, int KW, int C, int NW>
 static size_t dense_lds_bytes() {
   constexpr int DT_Y = 16 - 2 * (KW / 2);
   constexpr int HALO = KS / 2 + KW / 2, RH = DT_Y + 2 * HALO, RS = DT_X + 2 * HALO + 1;
-  constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X;
+  constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X, DT_HS = dense_h_stride(KW);
   return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_HS + NW * UH * DT_HS) + sizeof(int) * (NE * 3 + 16);
 }
 
@@ -407,7 +531,7 @@ static int launch_fwd_dense_t(const DenseParams &p, hipStream_t st) {
 int launch_fwd_dense(const DenseParams &p, int ks, int kw, int C, hipStream_t st) {
   if (!dense_supported(ks, kw, C)) return -1;
   if (p.max_tiles == 0) return 0;
-  return ks == 25 ? launch_fwd_dense_t<25, 9, 3, 4>(p, st) : launch_fwd_dense_t<49, 13, 3, 8>(p, st);
+  return ks == 25 ? launch_fwd_dense_t<25, 9, 3, 4>(p, st) : launch_fwd_dense_t<49, 13, 3, 7>(p, st);
 }
 
 }  // namespace ssg

@@ -346,13 +346,23 @@ def test_c2_full_size_properties(dev):
 
 
 def test_gradient_of_one_image_vs_oracle_paper_sizes(dev):
-    """Full gradient parity at k_s=25,k_w=9 on a 96x96 crop (oracle: seconds)."""
-    from ssl_amd import SSGLoss, synth
+    """Full gradient parity at k_s=25,k_w=9 on a 96x96 crop (oracle: seconds).
+
+    One entry of this input (edge pixel (52,71), offset (10,13), s = 9.5e-4) has s_sr - s_gt = 6.9e-10, six fp32 ulps:
+    L1Loss's derivative sign(s_sr - s_gt) is not determined at fp32 there, and that one sign moves the gradient by
+    1.2e-4 of its maximum.  The oracle therefore takes the sign of entries tied within the forward tolerance (1e-5
+    relative) from the device's own SSG rows (oracle.ssg_loss l1_ties) -- everything else is the plain fp64 value."""
+    from ssl_amd import SSGLoss, engine, synth
     ks, kw, sigma = 25, 9, 0.004
     gt = synth.natural_like(400, 96, 96)[None]
     sr = synth.degrade(gt[0], 401)[None]
     mask = synth.laplacian_edge_mask(gt[0])[None]
-    ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask, ks, kw, sigma, 1e3, 1e3)
+    step = engine.LossStep(1, 3, 96, 96, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
+    step(T(sr, dev), T(gt, dev), T(mask[:, None], dev))
+    n = int(step.counts[0])
+    ties = (step.ssg_sr[:n].cpu().numpy(), step.ssg_gt[:n].cpu().numpy())
+    ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask, ks, kw, sigma, 1e3, 1e3, l1_ties=ties)
+    assert n == ref["n_edges"] and ref["n_ties"] < 1e-4 * n * ks * ks
     x = T(sr, dev).requires_grad_(True)
     l1, kl = SSGLoss(ks, kw, sigma, True, 1e3, 1e3)(x, T(gt, dev), T(mask[:, None], dev))
     (l1 + kl).backward()
