@@ -107,21 +107,22 @@ constexpr int dense_lane_px(int kw) { return kw == 9 ? 10 : 12; }
 // H buffers (horizontal sums on the 16 U-rows x 4L centre columns): lane (r, g) stores its L sums in row r, the
 // tile's edge pixels gather them at (row ey + k, column of ex).  The LDS, not the VALU, bounds this kernel, so the
 // layout is chosen per size for what its tiles do most:
-//   k_w 9  (8 x 32 tiles, a few dozen edge pixels each): stores first -- the lane's register pairs (centres k, k + L/2)
-//          go out as 8-byte stores at r * 40 + 10 g + 2 (k % 5); a ds_write_b64 is served 16 lanes (4 rows x 4
-//          groups) at a time on 32 banks and S = 8 (mod 32) puts the 16 pairs on 16 different bank pairs (S = 44:
-//          2 LDS cycles per cycle, SQ_LDS_BANK_CONFLICT over half of SQ_LDS_IDX_ACTIVE).  The gathers of an arbitrary
-//          pixel set collide ~3-way whatever the stride.
+//   k_w 9  (8 x 32 tiles, a few dozen edge pixels each): the lane's register pairs (centres k, k + L/2) go out as
+//          8-byte stores at r * 40 + 10 g + 2 (k % 5).  A ds_write_b64 is served 16 lanes (4 rows x 4 groups) at a
+//          time on 32 banks, and a row stride of 8 (mod 32) puts the 16 pairs on 16 different bank pairs.  Measured
+//          (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE per launch at C2): stride 44: 7.6e7 / 1.46e8; stride 40: 4.1e7 /
+//          1.11e8; 16-byte stores at r * 48 + 12 g: 5.3e7 / 1.23e8.  The gathers are kept apart by the order of the
+//          tile's edge list instead (census).
 //   k_w 13 (4 x 32 tiles, in practice full ones -- C5 is a 100 % mask): gathers first -- 32 lanes read 32 consecutive
 //          centres of one row, conflict-free only if column = ex; the stores are then single dwords (12 g + k at an
 //          odd row stride: 2-way, the best a contiguous row allows).
 constexpr bool dense_h_paired(int kw) { return kw == 9; }
+constexpr int dense_h_group(int kw) { return kw == 9 ? 10 : 12; }
 constexpr int dense_h_stride(int kw) { return kw == 9 ? 40 : 49; }
-__device__ __forceinline__ int dense_h_col(int ex, int L, bool paired) {
+__device__ __forceinline__ int dense_h_col(int ex, int L, int G, bool paired) {
   const int k = ex % L;
-  return paired ? ex - k + 2 * (k % (L / 2)) + k / (L / 2) : ex;
+  return paired ? G * (ex / L) + 2 * (k % (L / 2)) + k / (L / 2) : ex;
 }
-
 
 // NW waves per workgroup share the tile's image region; wave w walks the offset rows q_y = w (mod NW).  (25,9): 4
 // (47 KB of LDS, two workgroups per CU, 2 waves per SIMD -- hence the register cap: with 14 AGPRs on top of 256 VGPRs
@@ -138,8 +139,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int NV = HL + KW - 1;                                            // pixel pairs the windows of a lane reach
   constexpr int DT_HS = dense_h_stride(KW);
   constexpr bool HPAIR = dense_h_paired(KW);
+  constexpr int HG = dense_h_group(KW);
   constexpr int NE_MAX = DT_Y * DT_X, NCHUNK = NE_MAX / 64;
-  static_assert(UH == 16 && DT_X == 32 && 4 * L >= UW && 4 * L <= DT_HS && L % 2 == 0 && KW - 1 <= L,
+  static_assert(UH == 16 && DT_X == 32 && 4 * L >= UW && 3 * HG + L <= DT_HS && HG >= L && (HPAIR || HG == L) && L % 2 == 0 && KW - 1 <= L,
                 "lane map: 16 U-rows x 4 column groups (one quad) of L pixels; a window spans two lanes");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int RSTR = UH * DT_HS / 2;
   static_assert(NE_MAX <= RSTR, "row sums alias the wave's H buffer");
   int *elist = (int *)(Hb + NW * UH * DT_HS);     // [NE_MAX][3] (ey, ex, row)
-  int *misc = elist + NE_MAX * 3;          // [16]: wave counts, n_e (misc[NW])
+  int *misc = elist + NE_MAX * 3;          // [16 + 64 NW]: wave counts, n_e (misc[NW]); then the census' (wave, bank) counts and starts
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int which = blockIdx.x / p.max_tiles, tslot = blockIdx.x - which * p.max_tiles;
@@ -165,8 +167,61 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int ty0 = (tr / tx_n) * DT_Y, tx0 = (tr % tx_n) * DT_X;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
 
-  // ---- census of the tile's edge pixels (row-major inside the tile) ----
-  {
+  // ---- census of the tile's edge pixels ----
+  // List slot e = (chunk of 64, lane) decides which lanes gather together from the H buffers.  k_w 13 (full tiles):
+  // row-major, 32 consecutive centres of a row per half-wave, conflict-free.  k_w 9 (a few dozen pixels anywhere in the
+  // tile): row-major order puts ~3 pixels of a half-wave on one LDS bank; instead the pixels are counting-sorted by
+  // the bank of their H column (ballots per wave, one scan over banks x waves -- LDS atomics cost 0.03 ms here) and
+  // dealt round-robin to the half-waves, so that a half-wave holds about one pixel per bank.  The list then has
+  // holes (row -1) up to a multiple of 32.
+  if constexpr (HPAIR) {
+    static_assert(DT_Y * DT_X == NT, "one thread per tile pixel");
+    int *wcnt = misc + 16, *bstart = wcnt + NW * 32;  // [NW][32] pixels per (wave, bank); starts in the sorted list
+    const int ey = tid / DT_X, ex = tid % DT_X;
+    const int y = ty0 + ey, x = tx0 + ex;
+    int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+    if (r >= nrows) r = -1;
+    elist[3 * tid + 2] = -1;
+    const int bank = (DT_HS * ey + dense_h_col(ex, L, HG, true)) & 31;
+    // per wave: how many of its pixels fall on each bank (kept by lane `bank`), and each pixel's place among them
+    int pib = 0, mycnt = 0;
+    for (int bk = 0; bk < 32; ++bk) {
+      const unsigned long long m = __ballot(r >= 0 && bank == bk);
+      if (bank == bk) pib = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == bk) mycnt = __popcll(m);
+    }
+    if (lane < 32) wcnt[wv * 32 + lane] = mycnt;
+    __syncthreads();
+    if (tid < 32) {  // exclusive scan over (bank, wave)
+      int c[NW], tot = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        c[k] = wcnt[k * 32 + tid];
+        tot += c[k];
+      }
+      int incl = tot;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(incl, o, 32);
+        if (tid >= o) incl += t;
+      }
+      int run = incl - tot;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        bstart[k * 32 + tid] = run;
+        run += c[k];
+      }
+      if (tid == 31) misc[NW] = 32 * ((incl + 31) / 32);   // slots: whole half-waves
+    }
+    __syncthreads();
+    if (r >= 0) {
+      const int ng = misc[NW] / 32, i = bstart[wv * 32 + bank] + pib;
+      const int pos = (i % ng) * 32 + i / ng;
+      elist[3 * pos + 0] = ey;
+      elist[3 * pos + 1] = ex;
+      elist[3 * pos + 2] = r;
+    }
+  } else {
     const int ey = tid / DT_X, ex = tid % DT_X;
     const int y = ty0 + ey, x = tx0 + ex;
     int r = (ey < DT_Y && y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
@@ -215,7 +270,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
   __syncthreads();
-  const int n_e = misc[NW];
+  const int n_e = misc[NW];  // list slots (k_w 9: with holes, row -1)
   for (int i = tid; i < UH * UW; i += NT) {
     const int ur = i / UW, uc = i - ur * UW;
     float t = 0.f;
@@ -232,7 +287,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float t = 0.f;
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) t += F[ur * UW + tc + kx];
-    HF[ur * DT_HS + dense_h_col(tc, L, HPAIR)] = t;
+    HF[ur * DT_HS + dense_h_col(tc, L, HG, HPAIR)] = t;
   }
   __syncthreads();
 
@@ -260,7 +315,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     Fv[m] = f2{F[r * UW + (c0 < UW ? c0 : UW - 1)], F[r * UW + (c1 < UW ? c1 : UW - 1)]};
   }
   float *hb = Hb + wv * UH * DT_HS;
-  float *hrow = hb + r * DT_HS + L * g;  // the lane's centres L*g .. L*g + L-1 (those >= DT_X: written, never read)
+  float *hrow = hb + r * DT_HS + HG * g;  // the lane's centres L*g .. L*g + L-1 (those >= DT_X: written, never read)
   // exp(x) = 2^(x log2 e), constant folded (see ssg_fwd.hip)
   const float nk = (float)(-1.4426950408889634 / ((double)(C * KW * KW) * (double)p.sigma));
   double rs[NCHUNK];
@@ -274,10 +329,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
   for (int ck = 0; ck < NCHUNK; ++ck) {
     const int e = ck * 64 + lane;
-    eon[ck] = e < n_e;
+    eon[ck] = e < n_e && elist[3 * (e < n_e ? e : 0) + 2] >= 0;
     const int ec = eon[ck] ? e : 0;
     const int ey = elist[3 * ec], ex = elist[3 * ec + 1];
-    hoff[ck] = ey * DT_HS + dense_h_col(ex, L, HPAIR);  // window row k of the centre is U-row ey + k
+    hoff[ck] = ey * DT_HS + dense_h_col(ex, L, HG, HPAIR);  // window row k of the centre is U-row ey + k
     orow[ck] = (size_t)elist[3 * ec + 2] * P;
   }
 
@@ -455,6 +510,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // kernel's second pass over its rows (one read + one write of every row)
     double *rsc = p.row_scale + (size_t)which * p.n_host;
     for (int e = tid; e < n_e; e += NT) {
+      if (elist[3 * e + 2] < 0) continue;
       double tot = 0.0;
 #pragma unroll
       for (int k = 0; k < NW; ++k) tot += rsum[k * RSTR + e];
@@ -473,14 +529,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float v[2][RPL];
     double scale[2];
     float *o[2];
+    bool ok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = e0 + j < n_e ? e0 + j : e0;
+      ok[j] = e0 + j < n_e && elist[3 * e + 2] >= 0;
       double tot = 0.0;
 #pragma unroll
       for (int k = 0; k < NW; ++k) tot += rsum[k * RSTR + e];
       scale[j] = 1.0 / (tot + (double)p.eps);
-      o[j] = outp + (size_t)elist[3 * e + 2] * P;
+      o[j] = outp + (size_t)(ok[j] ? elist[3 * e + 2] : 0) * P;
 #pragma unroll
       for (int k = 0; k < RPL; ++k) {
         const int q = lane + 64 * k;
@@ -489,7 +547,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if (e0 + j < n_e) {
+      if (ok[j]) {
 #pragma unroll
         for (int k = 0; k < RPL; ++k) {
           const int q = lane + 64 * k;
@@ -506,7 +564,7 @@ static size_t dense_lds_bytes() {
   constexpr int DT_Y = 16 - 2 * (KW / 2);
   constexpr int HALO = KS / 2 + KW / 2, RH = DT_Y + 2 * HALO, RS = DT_X + 2 * HALO + 1;
   constexpr int UH = DT_Y + 2 * (KW / 2), UW = DT_X + 2 * (KW / 2), NE = DT_Y * DT_X, DT_HS = dense_h_stride(KW);
-  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_HS + NW * UH * DT_HS) + sizeof(int) * (NE * 3 + 16);
+  return sizeof(float) * (size_t)(C * RH * RS + UH * UW + UH * DT_HS + NW * UH * DT_HS) + sizeof(int) * (NE * 3 + 16 + 64 * NW);
 }
 
 bool dense_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }
