@@ -19,8 +19,11 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
   roofline      for the dominant kernel: algorithmic HBM bytes of the step (8 k_s^2 + (12C+4) HW/N per
                 edge pixel) x edge pixels per launch / that kernel's mean duration, measured here with HIP events
                 on the launch stream while the step's other launches are masked out (ssg_set_profile_mask);
-                `kernel_ms` lists every kernel of the step measured that way, `step` repeats the figure over the
-                whole step's GPU time, `valu` prices the same time against the fp32 vector peak.
+                `kernel_ms` lists every kernel of the step measured that way (each ALONE on the chip: inside the
+                step the direct kernel of a pass runs on a side stream beside the dense one for k_s <= 25, so the
+                step is shorter than their sum; profiles/*_kernel_stats.csv is taken with SSG_OVERLAP=0 for the
+                same reason), `step` repeats the figure over the whole step's GPU time, `valu` prices the same
+                time against the fp32 vector peak.
   module        the same step through the drop-in nn.Module (ssl_amd.SSGLoss: autograd forward + backward).
   cpu_baseline  the C/OpenMP oracle ("port") on the host cores over a bounded sample of the same workload
                 (rank 0, N = 1 only).
