@@ -45,3 +45,4 @@ for cfg in ("c2", "c5"):
             print(k.replace('void ssg::', ''), ' '.join('%s=%.4g' % (c, v / n) for c, v in sorted(d.items())))
 PY
 ls gpurun_out/r2 | head -30
+python tools/pmc_to_json.py
