@@ -143,7 +143,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     def f_bwd():
         _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts), n_edges,
                                        KS, KW, SIGMA, 1, p(step.ssg_sr), p(step.ssg_gt), W_L1, W_KL, None, p(step.loss),
-                                       p(step.grad), p(lscratch), None, p(rsc), st))
+                                       p(step.grad), p(lscratch), None, p(rsc), 0, st))
 
     def only(fn, keep, group):
         mask_bits = sum(1 << SKIP_BITS[k] for k in group if k != keep)
@@ -265,6 +265,9 @@ def main():
                     help="weak: 16 images per GPU; strong: the 16 images split over the GPUs (SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-module", action="store_true", help="skip the SSGLoss (nn.Module) timing")
+    ap.add_argument("--no-ssg-output", action="store_true",
+                    help="the fused step of the C ABI (ssg_sr = ssg_gt = NULL): a SEPARATE metric with SURVEY 8d's "
+                         "B_alg' = (12C+4)HW/N -- not comparable with the default line")
     ap.add_argument("--graph", action="store_true", help="replay the step as a recorded HIP graph instead of "
                     "launching its kernels one by one (measured: no difference, the step is not launch-bound)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launcher / sharding / "
@@ -317,7 +320,8 @@ def main():
         from ssl_amd import engine
         sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
         step = engine.LossStep(max(B, 1), C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1,
-                               W_KL, device=dev, capacity=n_edges + 1024, graph=args.graph) if B else None
+                               W_KL, device=dev, capacity=n_edges + 1024, graph=args.graph,
+                               materialise=not args.no_ssg_output) if B else None
 
         def run_step():
             if step is not None:
@@ -345,12 +349,15 @@ def main():
     if rank == 0:
         value = total_edges * args.steps / elapsed
         res = {
-            "metric": "SSG-loss edge-pixels/sec (fwd+bwd) 3x256x256 k_s=25 k_w=9" if args.config == "c2" else
-                      "SSG-loss edge-pixels/sec (fwd+bwd) 3x512x512 k_s=49 k_w=13 dense mask",
+            "metric": ("SSG-loss edge-pixels/sec (fwd+bwd) 3x256x256 k_s=25 k_w=9" if args.config == "c2" else
+                       "SSG-loss edge-pixels/sec (fwd+bwd) 3x512x512 k_s=49 k_w=13 dense mask") +
+                      (" [fused step, no SSG output: B_alg' = (12C+4)HW/N]" if args.no_ssg_output else ""),
             "value": value, "unit": "edge-px/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["name"] + (" (16 images split over the GPUs)" if args.scaling == "strong" else ""),
+            "config": {"workload": (cfg["name"].replace("SSGs materialised", "fused step: no SSG output")
+                                    if args.no_ssg_output else cfg["name"]) +
+                                   (" (16 images split over the GPUs)" if args.scaling == "strong" else ""),
                        "launch": "HIP graph replay" if args.graph else "per-kernel", "ranks_seen": ranks_seen,
                        "edge_px_rank0": n_edges, "edge_px_total": total_edges, "images_rank0": B,
                        "mask_density": n_edges / max(B * cfg["H"] * cfg["W"], 1),
@@ -365,9 +372,16 @@ def main():
             assert int(step.counts[0]) == n_edges
             loss = step.loss.cpu().numpy()
             res["config"]["l1"], res["config"]["kl"] = float(loss[0]), float(loss[1])
-            b_alg = alg_bytes_per_edge_px(cfg, n_edges, B)
+            b_alg = alg_bytes_per_edge_px(cfg, n_edges, B) - (8.0 * cfg["ks"] ** 2 if args.no_ssg_output else 0.0)
             it = max(3, min(args.steps, 10))
-            stages = stage_times(step, sr, gt, mask, n_edges, it, cfg)
+            # (per-kernel times: through the separate entry points, which need SSG tensors of their own)
+            step_k = step if not args.no_ssg_output else engine.LossStep(
+                B, C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1, W_KL, device=dev,
+                capacity=n_edges + 1024)
+            if step_k is not step:
+                step_k(sr, gt, mask)
+            stages = stage_times(step_k, sr, gt, mask, n_edges, it, cfg)
+            del step_k
             step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), it)
             dom = max((k for k in stages if k.startswith("ssg_") and "launches" not in k and "+" not in k),
                       key=lambda k: stages[k])
@@ -384,7 +398,7 @@ def main():
                          "note": "SURVEY's DIRECT flop count over the step's GPU time; the dense-tile kernels do "
                                  "fewer real flops, so this is throughput in reference-equivalent flops, not "
                                  "VALU utilisation (see profiles/ for SQ_INSTS_VALU)"}}
-            if not args.no_module:
+            if not args.no_module and not args.no_ssg_output:
                 mm = module_time_ms(cfg, sr, gt, mask, n_edges, it)
                 res["module"] = {"what": "ssl_amd.SSGLoss forward + autograd backward (drop-in path)",
                                  "ms_per_step": mm, "value": n_edges / (mm * 1e-3), "unit": "edge-px/s"}

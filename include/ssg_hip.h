@@ -209,6 +209,8 @@ size_t ssg_grad_fix_bytes(int B, int C, int H, int W);
  * (e = exp(-d/sigma)) with their 1/(sum e + eps) in row_scale, and this call rescales them in place while it
  * streams them anyway -- same arithmetic, same bits, one pass over the SSG tensors less.  Between the two calls
  * ssg_sr / ssg_gt are NOT yet the SSG tensors.  Requires rank_map, fwd_plan and scratch (SSG_E_BADARG otherwise).
+ * rows_are_scratch != 0: the caller will not look at ssg_sr / ssg_gt again (an autograd node that keeps only the
+ * gradient): the rescaled rows are then not written back -- one write of every deferred row less.
  * `upstream`
  * (nullable) points at two DEVICE floats {dL/dl1, dL/dkl} that scale the two
  * criteria's gradients (autograd's incoming gradients, read on device so the
@@ -225,18 +227,27 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
                       float w_kl, const float *upstream /* nullable */,
                       float *loss_out, float *grad_sr /* nullable */,
                       void *scratch, void *grad_fix /* nullable: deterministic mode */,
-                      const double *row_scale /* nullable */, ssg_stream_t stream);
+                      const double *row_scale /* nullable */, int rows_are_scratch, ssg_stream_t stream);
 
 /* Everything in one call: edge list (from a mask or from GT's Laplacian),
  * SSG(sr), SSG(gt), both criteria and the gradient.  ssg_sr / ssg_gt
  * (capacity, k_s*k_s) receive the SSG tensors; `counts` as in ssg_edge_list;
- * workspace >= ssg_loss_workspace_bytes(B,H,W,capacity,ks). */
+ * workspace >= ssg_loss_workspace_bytes(B,H,W,capacity,ks).
+ *
+ * Fused step, no SSG output (SURVEY 8d's B_alg' mode): ssg_sr == ssg_gt == NULL.  The rows then live in the
+ * workspace, which must hold ssg_loss_workspace_bytes(...) + ssg_loss_rows_bytes(capacity, ks); the dense-tile
+ * forward leaves them un-normalised, ssg_grad_rows reads them once (rescaling in registers) and nothing normalised is
+ * ever written -- one write and one read of every row instead of two writes and two reads (C5: 26 -> 21 GB per step).
+ * Loss and gradient are bit-identical to the materialising call.  A kernel that kept a tile's rows on chip through
+ * criteria and backward would need 64 edge pixels x k_s^2 x 2 images x 4 B = 320 KB at (25,9) -- twice the LDS of a
+ * CU -- or a second forward sweep; DESIGN.md section 8 has the measured costing. */
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks);
+size_t ssg_loss_rows_bytes(int capacity, int ks);
 int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask,
                      int mask_kind, int mask_channels, int B, int C, int H,
                      int W, int ks, int kw, float sigma, float eps,
                      int generalization, float w_l1, float w_kl, int mask_stride,
-                     float lap_threshold, int capacity, float *ssg_sr,
+                     float lap_threshold, int capacity, float *ssg_sr /* nullable with ssg_gt: fused step */,
                      float *ssg_gt, int *counts, float *loss_out, float *grad_sr,
                      void *workspace, size_t workspace_bytes,
                      void *grad_fix /* nullable: deterministic mode */, ssg_stream_t stream);

@@ -35,8 +35,9 @@ PROTOTYPES = {
     "ssg_grad_fix_bytes": (_sz, [_i, _i, _i, _i]),
     "ssg_loss_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ssg_loss_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _f, _f,
-                               _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ssg_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ssg_loss_rows_bytes": (_sz, [_i, _i]),
     "ssg_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,
                               _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ssg_augment_crop": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -191,6 +191,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   g.ssg = p.ssg;
   g.ssg2 = p.ssg2;
   g.row_scale = p.row_scale;
+  g.rows_scratch = p.rows_scratch;
   g.n_dev = p.n_dev;
   g.n_host = p.n_host;
   g.C = p.C;
@@ -262,7 +263,7 @@ static bool split_ok(int ks, int kw, int C, const int *rank, const int *plan, co
 
 extern "C" {
 
-int ssg_abi_version(void) { return 2; }
+int ssg_abi_version(void) { return 3; }
 
 const char *ssg_status_string(int status) {
   switch (status) {
@@ -471,12 +472,11 @@ size_t ssg_loss_scratch_bytes(int B, int H, int W, int n_rows, int ks) {
   return partials_bytes(B, H, W, n_rows) + split_scratch_bytes(n_rows, ks);
 }
 
-int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *tile_order,
-                      const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
-                      float sigma, int generalization,
-                      float *ssg_sr, float *ssg_gt, float w_l1, float w_kl, const float *upstream,
-                      float *loss_out, float *grad_sr, void *scratch, void *grad_fix, const double *row_scale,
-                      ssg_stream_t stream) {
+static int loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *tile_order,
+                         const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
+                         float sigma, int generalization, float *ssg_sr, float *ssg_gt, float w_l1, float w_kl,
+                         const float *upstream, float *loss_out, float *grad_sr, void *scratch, void *grad_fix,
+                         const double *row_scale, bool rows_scratch, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
@@ -507,6 +507,7 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
   p.kw = kw;
   p.dbg = (dbg_mask() >> 8) & 0xff;
   p.row_scale = row_scale;
+  p.rows_scratch = rows_scratch ? 1 : 0;
   if (row_scale && !split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) return SSG_E_BADARG;  // only ssg_grad_rows rescales
   int rc = det_begin(p, grad_fix, st);
   if (rc) return rc;
@@ -524,6 +525,21 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
   return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
 }
 
+int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *tile_order,
+                      const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
+                      float sigma, int generalization,
+                      float *ssg_sr, float *ssg_gt, float w_l1, float w_kl, const float *upstream,
+                      float *loss_out, float *grad_sr, void *scratch, void *grad_fix, const double *row_scale,
+                      int rows_are_scratch, ssg_stream_t stream) {
+  return loss_backward(sr, B, C, H, W, edges, tile_order, rank_map, fwd_plan, n_edges_dev, n_rows, ks, kw, sigma,
+                       generalization, ssg_sr, ssg_gt, w_l1, w_kl, upstream, loss_out, grad_sr, scratch, grad_fix,
+                       row_scale, rows_are_scratch != 0, stream);
+}
+
+size_t ssg_loss_rows_bytes(int capacity, int ks) {
+  return 2 * align_up(sizeof(float) * (size_t)(capacity > 0 ? capacity : 1) * ks * ks, 256);
+}
+
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
   return align_up(sizeof(int) * 3 * (size_t)(capacity > 0 ? capacity : 1), 256) +
          align_up(2 * sizeof(double) * (size_t)(capacity > 0 ? capacity : 1), 256) +
@@ -537,9 +553,17 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
                      float w_kl, int mask_stride, float lap_threshold, int capacity, float *ssg_sr, float *ssg_gt,
                      int *counts, float *loss_out, float *grad_sr, void *workspace, size_t workspace_bytes,
                      void *grad_fix, ssg_stream_t stream) {
-  if (!sr || !gt || !ssg_sr || !ssg_gt || !counts || !loss_out || !workspace || capacity <= 0) return SSG_E_BADARG;
+  if (!sr || !gt || !counts || !loss_out || !workspace || capacity <= 0) return SSG_E_BADARG;
+  if ((ssg_sr == nullptr) != (ssg_gt == nullptr)) return SSG_E_BADARG;
   if (mask_kind != 2 && !mask) return SSG_E_BADARG;
-  if (workspace_bytes < ssg_loss_workspace_bytes(B, H, W, capacity, ks)) return SSG_E_WORKSPACE;
+  // fused step (no SSG output): the rows are the engine's scratch, behind the regular workspace
+  const bool fused = ssg_sr == nullptr;
+  const size_t base_bytes = ssg_loss_workspace_bytes(B, H, W, capacity, ks);
+  if (workspace_bytes < base_bytes + (fused ? ssg_loss_rows_bytes(capacity, ks) : 0)) return SSG_E_WORKSPACE;
+  if (fused) {
+    ssg_sr = (float *)((char *)workspace + base_bytes);
+    ssg_gt = (float *)((char *)ssg_sr + ssg_loss_rows_bytes(capacity, ks) / 2);
+  }
   char *ws = (char *)workspace;
   int *edges = (int *)ws;
   ws += align_up(sizeof(int) * 3 * (size_t)capacity, 256);
@@ -564,9 +588,9 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
                        generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, stream);
   if (rc) return rc;
-  return ssg_loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
-                           ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix,
-                           defer ? row_scale : nullptr, stream);
+  return loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
+                       ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix,
+                       defer ? row_scale : nullptr, fused, stream);
 }
 
 int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,

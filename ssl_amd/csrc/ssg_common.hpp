@@ -158,6 +158,7 @@ struct BwdParams {
   float w_l1, w_kl;
   const float *upstream;  // GRAD_LOSS, nullable: device {dL/dl1, dL/dkl}
   const double *row_scale;  // GRAD_LOSS, nullable: deferred normalisation (GrowParams), split backward only
+  int rows_scratch;         // GRAD_LOSS: the rows are scratch, ssg_grad_rows does not write the rescaled rows back
   float *partials;  // GRAD_LOSS: (gridDim.x, 2) per-workgroup sums of |a-b| and t'(log t' - log s')
   int ks, kw;       // generic kernel only
   int dbg;          // profiling ablations (0 in production): bit0 skip prologue math, bit1 skip pass A, bit2 skip pass B, bit3 skip atomics
@@ -253,6 +254,7 @@ struct GrowParams {
   // nullable [2][n_host] (GRAD_LOSS): deferred normalisation of the dense-tile forward -- a non-zero entry means the
   // row still holds e = exp(-d/sigma) and is rescaled here (and written back, normalised, through ssg / ssg2)
   const double *row_scale;
+  int rows_scratch;   // 1: ssg / ssg2 are the engine's own scratch (fused step, no SSG output): nothing is written back
   const int *n_dev;
   int n_host;
   int C;

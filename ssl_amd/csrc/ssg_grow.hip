@@ -44,14 +44,14 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
       if (p.row_scale && p.mode == GRAD_LOSS) {
         // rows of the dense-tile forward arrive un-normalised: s = e * 1/(sum e + eps), the product in fp64 and
         // rounded once (what the forward's own rescale pass does), written back so that the SSG tensors the caller
-        // sees are the normalised ones
+        // sees are the normalised ones (not in the fused step, where the rows are the engine's scratch)
         const double sa = p.row_scale[n], sb2 = p.row_scale[(size_t)p.n_host + n];
         if (sa != 0.0) {
 #pragma unroll
           for (int k = 0; k < EPL; ++k) {
             const int e = lane + 64 * k;
             va[k] = (float)(sa * (double)va[k]);
-            if (e < P) const_cast<float *>(p.ssg)[base + e] = va[k];
+            if (e < P && !p.rows_scratch) const_cast<float *>(p.ssg)[base + e] = va[k];
           }
         }
         if (sb2 != 0.0) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
           for (int k = 0; k < EPL; ++k) {
             const int e = lane + 64 * k;
             vg[k] = (float)(sb2 * (double)vg[k]);
-            if (e < P) const_cast<float *>(p.ssg2)[base + e] = vg[k];
+            if (e < P && !p.rows_scratch) const_cast<float *>(p.ssg2)[base + e] = vg[k];
           }
         }
       }

@@ -207,7 +207,7 @@ class _SSGLossFn(torch.autograd.Function):
         _lib.check(L.ssg_loss_backward(_ptr(x), B, C, H, W, _ptr(edges), _ptr(order), _ptr(f_rank), _ptr(f_plan),
                                        _ptr(counts), n_rows, ks, kw, sigma, gen, _ptr(ssg_sr), _ptr(ssg_gt), w_l1,
                                        w_kl, _ptr(upstream), _ptr(loss), _ptr(grad), _ptr(scratch), _ptr(fix), _ptr(rsc),
-                                       _stream()))
+                                       1, _stream()))   # (the rows die with this call: no write-back)
         return loss, grad
 
     @staticmethod
@@ -259,19 +259,24 @@ class LossStep:
     """
 
     def __init__(self, B, C, H, W, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0, w_kl=1.0,
-                 mask_stride=0, lap_threshold=20.0, capacity=None, device="cuda", graph=False, deterministic=None):
+                 mask_stride=0, lap_threshold=20.0, capacity=None, device="cuda", graph=False, deterministic=None,
+                 materialise=True):
         L = _lib.lib()
         self.shape = (B, C, H, W)
         self.cfg = (ks, kw, float(sigma), float(eps), int(bool(generalization)), float(w_l1), float(w_kl),
                     int(mask_stride or 0), float(lap_threshold))
         self.capacity = int(capacity if capacity is not None else B * H * W)
         P = ks * ks
-        self.ssg_sr = torch.empty((self.capacity, P), dtype=torch.float32, device=device)
-        self.ssg_gt = torch.empty((self.capacity, P), dtype=torch.float32, device=device)
+        # materialise=False: the fused step of the C ABI (no SSG output) -- the rows are scratch inside the workspace
+        self.materialise = bool(materialise)
+        self.ssg_sr = torch.empty((self.capacity, P), dtype=torch.float32, device=device) if materialise else None
+        self.ssg_gt = torch.empty((self.capacity, P), dtype=torch.float32, device=device) if materialise else None
         self.counts = torch.zeros(B + 2, dtype=torch.int32, device=device)
         self.loss = torch.zeros(2, dtype=torch.float32, device=device)
         self.grad = torch.zeros((B, C, H, W), dtype=torch.float32, device=device)
         self.ws_bytes = L.ssg_loss_workspace_bytes(B, H, W, self.capacity, ks)
+        if not materialise:
+            self.ws_bytes += L.ssg_loss_rows_bytes(self.capacity, ks)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.fix = _grad_fix(deterministic, self.grad)   # deterministic mode: fixed-point accumulation buffer
         self.use_graph = bool(graph)

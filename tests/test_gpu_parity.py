@@ -1157,3 +1157,32 @@ def test_module_accepts_half_precision_and_noncontiguous_inputs(dev):
     a4, b4 = crit(xr, gt, m)
     (a4 + b4).backward()
     assert torch.equal(a3, a4) and torch.equal(xbf.grad, xr.grad.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ks,kw,shape,dense", [(25, 9, (2, 3, 96, 128), False), (49, 13, (1, 3, 64, 96), True),
+                                               (11, 5, (2, 3, 40, 48), False)])
+def test_fused_step_without_ssg_output_is_bit_identical(dev, ks, kw, shape, dense):
+    """ssg_loss_fwd_bwd(ssg_sr = ssg_gt = NULL): the rows stay un-normalised scratch inside the workspace and are
+    never written back; loss and gradient must be the bits of the materialising call (dense-tile sizes and a size that
+    only the direct kernels serve), and a too-small workspace must be refused."""
+    from ssl_amd import _lib, engine, synth
+    B, C, H, W = shape
+    gt = np.stack([synth.natural_like(900 + i, H, W) for i in range(B)])
+    sr = np.stack([synth.degrade(gt[i], 950 + i) for i in range(B)])
+    mask = np.ones((B, 1, H, W), np.float32) if dense else \
+        np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(B)])[:, None].astype(np.float32)
+    a = engine.LossStep(B, C, H, W, ks, kw, 0.05, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True)
+    b = engine.LossStep(B, C, H, W, ks, kw, 0.05, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True,
+                        materialise=False)
+    la, ga = a(T(sr, dev), T(gt, dev), T(mask, dev))
+    lb, gb = b(T(sr, dev), T(gt, dev), T(mask, dev))
+    assert b.ssg_sr is None and int(a.counts[0]) == int(b.counts[0]) > 0
+    assert torch.equal(la, lb) and torch.equal(ga, gb) and float(ga.abs().max()) > 0
+    L = _lib.lib()
+    assert b.ws_bytes == L.ssg_loss_workspace_bytes(B, H, W, b.capacity, ks) + L.ssg_loss_rows_bytes(b.capacity, ks)
+    rc = L.ssg_loss_fwd_bwd(engine._ptr(T(sr, dev)), engine._ptr(T(gt, dev)), engine._ptr(T(mask, dev)), 0, 1, B, C, H,
+                            W, ks, kw, 0.05, 1e-10, 1, 1e3, 1e3, 0, 20.0, b.capacity, None, None,
+                            engine._ptr(b.counts), engine._ptr(b.loss), engine._ptr(b.grad), engine._ptr(b.ws),
+                            a.ws_bytes, None, engine._stream())
+    assert rc == -3   # SSG_E_WORKSPACE

@@ -25,15 +25,20 @@ def _generator():
     return mod.Generator
 
 
-def _time_steps(step, flag, n=4):
+def _time_steps(step, flag, n=4, repeats=3):
+    """Best of `repeats` timings of n steps (a fresh box ramps its clocks during the first seconds: one sample of 4
+    steps of a 55 ms generator step has swung by 25 % between the two flags)."""
     for _ in range(2):
         step(flag)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step(flag)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    best = float("inf")
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(flag)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+    return best
 
 
 def test_c3_and_c4_shaped_generator_steps_with_and_without_ssl():
@@ -62,6 +67,7 @@ def test_c3_and_c4_shaped_generator_steps_with_and_without_ssl():
         opt.step()
 
     base, ssl = _time_steps(step3, False), _time_steps(step3, True)
+    base, ssl = min(base, _time_steps(step3, False)), min(ssl, _time_steps(step3, True))   # (interleaved twice)
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
     ref = engine.LossStep(4, 3, 256, 256, 25, 9, 0.004, 1e-10, True, 1e3, 1e3, device=dev)
     loss_ref, _ = ref(last["sr"].contiguous(), gt, mask)

@@ -17,7 +17,7 @@ scratch = torch.empty(L.ssg_loss_scratch_bytes(16, 256, 256, n + 1024, 25), dtyp
 def bwd():
     _lib.check(L.ssg_loss_backward(p(sr), 16, 3, 256, 256, p(el.edges), p(el.order), p(el.rank), p(el.plan), p(el.counts), n,
                                    25, 9, 1.0, 1, p(step.ssg_sr), p(step.ssg_gt), 1e3, 1e3, None, p(step.loss), p(step.grad),
-                                   p(scratch), None, None, st))
+                                   p(scratch), None, None, 0, st))
 base = (1 << 28) | (1 << 29)   # skip direct backward and G rows: the dense backward (+finalize) alone
 for name, bits in (("full", 0), ("no atomics", 8), ("all lanes stream G row 0", 16), ("both", 24)):
     L.ssg_set_profile_mask(base | (bits << 8))

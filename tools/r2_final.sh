@@ -4,6 +4,9 @@ cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 R="$PWD"; O="$R/gpurun_out/r2"; rm -rf "$O"; mkdir -p "$O"; export TMPDIR=/tmp
 python bench.py --steps 30 --warmup 5 > "$O/r2_bench_c2.json" 2> "$O/bench_c2.err"; echo "bench c2 rc=$?"
 python bench.py --config c5 --steps 10 --warmup 3 > "$O/r2_bench_c5.json" 2> "$O/bench_c5.err"; echo "bench c5 rc=$?"
+# the fused step (no SSG output) is a separate metric (B_alg' = (12C+4)HW/N)
+python bench.py --no-ssg-output --steps 30 --warmup 5 --no-cpu-baseline > "$O/r2_bench_c2_fused.json" 2>> "$O/bench_c2.err"; echo "bench c2 fused rc=$?"
+python bench.py --no-ssg-output --config c5 --steps 10 --warmup 3 --no-cpu-baseline > "$O/r2_bench_c5_fused.json" 2>> "$O/bench_c5.err"; echo "bench c5 fused rc=$?"
 cd /tmp
 # Kernel durations: with SSG_OVERLAP=0 every launch runs alone on the caller's stream -- these are the durations
 # bench.py's roofline line measures (one kernel at a time under the profile mask).  The default build runs the direct
