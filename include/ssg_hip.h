@@ -268,6 +268,17 @@ int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, i
                      const int *params, ssg_stream_t stream);
 int ssg_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, ssg_stream_t stream);
 
+/* USMSharp.forward (basicsr/utils/img_process_util.py:63-83; applied to every GT batch, realesrganssl_model.py:165,
+ * 315): out = soft * clip(img + weight * (img - G*img), 0, 1) + (1 - soft) * img, soft = G * (|img - G*img| * 255 >
+ * threshold), G = cv2.getGaussianKernel(radius | 1, sigma) x its transpose (sigma <= 0: OpenCV's rule 0.3 ((k-1)/2 -
+ * 1) + 0.8), reflect padding.  img, out (B,C,H,W) fp32, out != img; H, W > radius / 2 (SSG_E_IMAGESMALL otherwise, as
+ * F.pad raises); odd kernel size <= 63; scratch >= ssg_usm_scratch_bytes (3 planes of the batch).  Reference defaults:
+ * radius 50, sigma 0, weight 0.5, threshold 10.  Floating point: within 2e-6 of the fp64 evaluation except where
+ * |residual| * 255 is within rounding of `threshold` (the mask bit is then not determined at fp32). */
+size_t ssg_usm_scratch_bytes(int B, int C, int H, int W);
+int ssg_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int radius, float sigma, float weight,
+                  float threshold, void *scratch, size_t scratch_bytes, ssg_stream_t stream);
+
 /* Profiling only (results are WRONG while a mask is set): skip kernel phases or whole launches so that one
  * kernel of a multi-kernel entry point can be timed with events on its stream.  Bits: 25 dense-tile forward,
  * 26 direct forward, 27 dense-tile backward, 28 direct backward (split mode), 29 G rows; lower bits ablate

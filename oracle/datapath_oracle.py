@@ -56,3 +56,43 @@ class PairPool:
             q[self.ptr:self.ptr + b] = t
         self.ptr += b
         return [t.copy() for t in tensors]
+
+
+def gaussian_kernel_1d(ksize, sigma=0.0):
+    """cv2.getGaussianKernel(ksize, sigma) (n,) float64 as OpenCV documents it (imgproc, getGaussianKernel): the fixed
+    tables for ksize <= 7 with sigma <= 0, else exp(-(i-(ksize-1)/2)^2 / (2 sigma^2)) normalised, sigma <= 0 meaning
+    0.3*((ksize-1)*0.5 - 1) + 0.8.  cv2 is not installed: this function is pinned by the documentation only (the
+    callers below are pinned by the reference's own code, fixture F12)."""
+    fixed = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+             7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+    if sigma <= 0 and ksize in fixed:
+        return np.asarray(fixed[ksize], np.float64)
+    sg = sigma if sigma > 0 else ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    k = np.exp(-0.5 * x * x / (sg * sg))
+    return k / k.sum()
+
+
+def filter2d_reflect(img, k1d):
+    """img_process_util.py:7-31 `filter2D` for one kernel shared by the batch: reflect-pad by k//2 (F.pad 'reflect'),
+    correlate every (b, c) plane with the k x k kernel -- here with the separable factors of USMSharp's outer product
+    (img_process_util.py:71), in the dtype of `img`."""
+    r = len(k1d) // 2
+    p = np.pad(img, ((0, 0), (0, 0), (r, r), (r, r)), mode="reflect")
+    H, W = img.shape[-2:]
+    t = sum(k1d[i] * p[..., :, i:i + W] for i in range(len(k1d)))
+    return sum(k1d[i] * t[..., i:i + H, :] for i in range(len(k1d)))
+
+
+def usm_sharp(img, radius=50, sigma=0.0, weight=0.5, threshold=10.0, return_parts=False):
+    """USMSharp.__init__ + forward (img_process_util.py:63-83) on (B,C,H,W) in [0,1], computed in float64."""
+    img = np.asarray(img, np.float64)
+    ksize = radius + 1 if radius % 2 == 0 else radius
+    k = gaussian_kernel_1d(ksize, sigma)
+    blur = filter2d_reflect(img, k)
+    residual = img - blur
+    mask = (np.abs(residual) * 255 > threshold).astype(np.float64)
+    soft = filter2d_reflect(mask, k)
+    sharp = np.clip(img + weight * residual, 0, 1)
+    out = soft * sharp + (1 - soft) * img
+    return (out, residual, mask) if return_parts else out

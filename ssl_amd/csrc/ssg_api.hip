@@ -52,6 +52,9 @@ int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t
 int launch_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,
                         const int *params, hipStream_t st);
 int launch_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, hipStream_t st);
+size_t usm_scratch_bytes(int B, int C, int H, int W);
+int launch_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int ksize, float sigma, float weight,
+                     float threshold, void *scratch, hipStream_t st);
 int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st);
 int launch_grad_fix_bound(const BwdParams &p, hipStream_t st);
 int launch_grad_fix_reduce(const float *part, int n, long long *gfix, size_t n_fix, hipStream_t st);
@@ -604,6 +607,19 @@ int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, i
 int ssg_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, ssg_stream_t stream) {
   if (!queue || !batch || !slots || b < 0) return SSG_E_BADARG;
   return launch_pool_swap(queue, batch, sample_bytes, slots, b, (hipStream_t)stream);
+}
+
+size_t ssg_usm_scratch_bytes(int B, int C, int H, int W) { return usm_scratch_bytes(B, C, H, W); }
+
+int ssg_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int radius, float sigma, float weight,
+                  float threshold, void *scratch, size_t scratch_bytes, ssg_stream_t stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0 || radius < 0) return SSG_E_BADARG;
+  if (B == 0) return 0;
+  if (!img || !out || !scratch || img == out) return SSG_E_BADARG;
+  if (scratch_bytes < usm_scratch_bytes(B, C, H, W)) return SSG_E_WORKSPACE;
+  const int ksize = radius % 2 == 0 ? radius + 1 : radius;   // img_process_util.py:67-68
+  const int rc = launch_usm_sharp(img, out, B, C, H, W, ksize, sigma, weight, threshold, scratch, (hipStream_t)stream);
+  return rc == -1 ? SSG_E_BADARG : rc == -4 ? SSG_E_IMAGESMALL : rc;
 }
 
 const char *ssg_kernel_name(int ks, int kw, int backward) {

@@ -9,6 +9,13 @@
 //                      tensor: the b samples at `slots` leave the queue and the current batch takes their place,
 //                      in place (the reference permutes the whole queue with queue[idx] first; the host keeps that
 //                      permutation as a slot table instead, ssl_amd/datapath.py).
+//   ssg_usm_sharp    : USMSharp.forward (basicsr/utils/img_process_util.py:63-83), the sharpening that turns every GT
+//                      batch into gt_usm (realesrganssl_model.py:165,315): blur = G * img (reflect padding), residual
+//                      = img - blur, mask = |residual| * 255 > threshold, soft = G * mask, out = soft * clip(img +
+//                      weight * residual, 0, 1) + (1 - soft) * img, with G the (radius x radius) Gaussian.  The
+//                      reference convolves with the 51 x 51 outer product; here the two blurs are separable row /
+//                      column passes through LDS tiles (2 x 51 instead of 2601 taps per pixel), the elementwise steps
+//                      ride in the column passes' epilogues: four launches, ~12 floats of HBM traffic per element.
 #include "ssg_common.hpp"
 
 namespace ssg {
@@ -77,6 +84,178 @@ int launch_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *s
   else
     hipLaunchKernelGGL(pool_swap<uint8_t>, dim3(grid), dim3(256), 0, st, (uint8_t *)queue, (uint8_t *)batch, sv, slots,
                        b);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- USM ----
+constexpr int USM_MAX_TAPS = 63, USM_PAD = 15;
+struct UsmTaps {
+  float k[USM_PAD + USM_MAX_TAPS + USM_PAD + 3];   // taps at [USM_PAD, USM_PAD + n), zeros around them
+  int n;
+};
+
+// One separable pass of the Gaussian over (planes, H, W) fp32, PyTorch 'reflect' padding (F.pad(..., 'reflect'),
+// img_process_util.py:17), 256 threads per tile, the input tile with its halo along the pass direction in LDS:
+//   column pass: 64 x 64 outputs (114 input rows for 51 taps: 1.8 x re-read), a thread owns 16 consecutive rows of one
+//                column -- 64 lanes on 64 consecutive columns, one LDS dword per input row, 16 FMAs each;
+//   row pass   : 16 rows x 128 columns, a thread owns 8 consecutive columns -- one 16-byte LDS read per 4 inputs.
+// Every input is multiplied into all the outputs it reaches against the zero-padded tap array, so the loops carry no
+// conditions.  NTAPS > 0: tap count at compile time (51 = the reference's USMSharp()): the loops unroll and the taps sit
+// in SGPRs; 0: any odd count <= 63, taps fetched from the kernel arguments step by step.
+//   EPI 0: dst = blur
+//   EPI 1: (column pass of the image blur) res = img - blur -> dst, mask = |res| * 255 > threshold -> dst2 (0/1 floats)
+//   EPI 2: (column pass of the mask blur) soft = blur; out = soft * clip(img + weight * res, 0, 1) + (1 - soft) * img
+constexpr int USM_VTX = 64, USM_VTY = 64, USM_HTX = 128, USM_HTY = 16;
+template <bool VERT, int EPI, int NTAPS>
+__global__ __launch_bounds__(256) void usm_pass(const float *src, float *dst, float *dst2, const float *img,
+                                                const float *res, int planes, int H, int W, UsmTaps taps, float weight,
+                                                float threshold) {
+  constexpr int TX = VERT ? USM_VTX : USM_HTX, TY = VERT ? USM_VTY : USM_HTY, RPT = VERT ? 16 : 8;
+  static_assert(RPT - 1 <= USM_PAD, "tap array padding");
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int n = NTAPS > 0 ? NTAPS : taps.n, R = n / 2;
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  const size_t plane = (size_t)blockIdx.z * H * W;
+  const float *sp = src + plane;
+  const int tw = VERT ? TX : TX + 2 * R, th = VERT ? TY + 2 * R : TY;
+  const int ts = VERT ? TX + 1 : ((tw + RPT + 3) & ~3);   // (row pass: 16-byte rows, zeros behind the window)
+  // (all global loads of a batch are issued before the first LDS store: one load per loop trip pays the L2 latency
+  // 28 times per thread -- the fill, not the 51 taps, was what the first version spent its 40 us per pass on)
+  if (VERT) {
+    const int lx = threadIdx.x & 63;
+    int gx = tx0 + lx;
+    gx = gx >= W ? W - 1 : gx;                 // (columns of a partial tile past the image: never written)
+    constexpr int U = 8;
+    for (int base = threadIdx.x >> 6; base < th; base += 4 * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int gy = reflect_idx(ty0 + base + 4 * u - R, H);
+        gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+        v[u] = sp[(size_t)gy * W + gx];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (base + 4 * u < th) tile[(base + 4 * u) * ts + lx] = v[u];
+    }
+  } else {
+    const int lx = threadIdx.x;                // tw <= 128 + 62 < 256
+    int gx = reflect_idx(tx0 + lx - R, W);
+    gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    float v[TY];
+#pragma unroll
+    for (int ly = 0; ly < TY; ++ly) {
+      int gy = ty0 + ly;
+      gy = gy >= H ? H - 1 : gy;
+      v[ly] = sp[(size_t)gy * W + gx];
+    }
+#pragma unroll
+    for (int ly = 0; ly < TY; ++ly)
+      if (lx < ts) tile[ly * ts + lx] = lx < tw ? v[ly] : 0.f;
+  }
+  __syncthreads();
+  float acc[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) acc[j] = 0.f;
+  int x, y;   // first of the thread's RPT outputs
+  if (VERT) {
+    const int lx = threadIdx.x & 63, ly = RPT * (threadIdx.x >> 6);
+    x = tx0 + lx;
+    y = ty0 + ly;
+    const float *col = tile + ly * ts + lx;
+#pragma unroll
+    for (int t = 0; t < n + RPT - 1; ++t) {     // input row ly + t feeds output j with tap t - j
+      const float v = col[t * ts];
+      const float *kp = taps.k + USM_PAD + t;
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) acc[j] = __builtin_fmaf(kp[-j], v, acc[j]);
+    }
+  } else {
+    const int lx = RPT * (threadIdx.x & 15), ly = threadIdx.x >> 4;
+    x = tx0 + lx;
+    y = ty0 + ly;
+    const float4 *row = (const float4 *)(tile + ly * ts + lx);
+#pragma unroll
+    for (int t4 = 0; t4 < (n + RPT - 1 + 3) / 4; ++t4) {
+      const float4 q = row[t4];
+      const float v[4] = {q.x, q.y, q.z, q.w};
+      const float *kp = taps.k + USM_PAD + 4 * t4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) acc[j] = __builtin_fmaf(kp[u - j], v[u], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int yy = VERT ? y + j : y, xx = VERT ? x : x + j;
+    if (yy >= H || xx >= W) continue;
+    const size_t o = plane + (size_t)yy * W + xx;
+    if (EPI == 0) {
+      dst[o] = acc[j];
+    } else if (EPI == 1) {
+      const float r = img[o] - acc[j];
+      dst[o] = r;
+      dst2[o] = fabsf(r) * 255.f > threshold ? 1.f : 0.f;
+    } else {
+      const float v = img[o];
+      float sharp = v + weight * res[o];
+      sharp = fminf(fmaxf(sharp, 0.f), 1.f);
+      dst[o] = acc[j] * sharp + (1.f - acc[j]) * v;
+    }
+  }
+}
+
+// cv2.getGaussianKernel(ksize, sigma) as documented (OpenCV imgproc, getGaussianKernel): fixed tables for ksize <= 7
+// with sigma <= 0, else G_i = a exp(-(i - (ksize-1)/2)^2 / (2 sigma^2)) normalised to sum 1, sigma <= 0 meaning
+// 0.3 ((ksize-1) 0.5 - 1) + 0.8; computed in fp64 and rounded once (the reference rounds the fp64 outer product).
+int usm_gaussian_taps(int ksize, double sigma, UsmTaps *out) {
+  if (ksize < 1 || ksize > USM_MAX_TAPS || !(ksize & 1)) return -1;
+  static const double tab1[] = {1.0}, tab3[] = {0.25, 0.5, 0.25}, tab5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625},
+                      tab7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+  const double *fixed = nullptr;
+  if (sigma <= 0 && ksize <= 7) fixed = ksize == 1 ? tab1 : ksize == 3 ? tab3 : ksize == 5 ? tab5 : tab7;
+  double k[USM_MAX_TAPS], sum = 0.0;
+  const double sg = sigma > 0 ? sigma : ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8, s2 = -0.5 / (sg * sg);
+  for (int i = 0; i < ksize; ++i) {
+    const double x = i - (ksize - 1) * 0.5;
+    k[i] = fixed ? fixed[i] : exp(s2 * x * x);
+    sum += k[i];
+  }
+  out->n = ksize;
+  for (float &v : out->k) v = 0.f;
+  for (int i = 0; i < ksize; ++i) out->k[USM_PAD + i] = (float)(fixed ? k[i] : k[i] / sum);
+  return 0;
+}
+
+size_t usm_scratch_bytes(int B, int C, int H, int W) { return 3 * sizeof(float) * (size_t)B * C * H * W; }
+
+int launch_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int ksize, float sigma, float weight,
+                     float threshold, void *scratch, hipStream_t st) {
+  UsmTaps taps;
+  if (usm_gaussian_taps(ksize, (double)sigma, &taps)) return -1;
+  const int R = ksize / 2;
+  if (H <= R || W <= R) return -4;   // reflect padding needs pad < size (PyTorch raises the same way)
+  const size_t n = (size_t)B * C * H * W;
+  if (n == 0) return 0;
+  float *t1 = (float *)scratch, *res = t1 + n, *msk = res + n;
+  const dim3 grid_h((unsigned)((W + USM_HTX - 1) / USM_HTX), (unsigned)((H + USM_HTY - 1) / USM_HTY), (unsigned)(B * C));
+  const dim3 grid_v((unsigned)((W + USM_VTX - 1) / USM_VTX), (unsigned)((H + USM_VTY - 1) / USM_VTY), (unsigned)(B * C));
+  const size_t lds_h = sizeof(float) * USM_HTY * ((USM_HTX + 2 * R + 8 + 3) & ~3);
+  const size_t lds_v = sizeof(float) * (USM_VTY + 2 * R) * (USM_VTX + 1);
+  auto run = [&](auto nt) {
+    constexpr int NT = decltype(nt)::value;
+    hipLaunchKernelGGL((usm_pass<false, 0, NT>), grid_h, dim3(256), lds_h, st, img, t1, nullptr, nullptr, nullptr, B * C,
+                       H, W, taps, weight, threshold);
+    hipLaunchKernelGGL((usm_pass<true, 1, NT>), grid_v, dim3(256), lds_v, st, t1, res, msk, img, nullptr, B * C, H, W,
+                       taps, weight, threshold);
+    hipLaunchKernelGGL((usm_pass<false, 0, NT>), grid_h, dim3(256), lds_h, st, msk, t1, nullptr, nullptr, nullptr, B * C,
+                       H, W, taps, weight, threshold);
+    hipLaunchKernelGGL((usm_pass<true, 2, NT>), grid_v, dim3(256), lds_v, st, t1, out, nullptr, img, res, B * C, H, W,
+                       taps, weight, threshold);
+  };
+  if (ksize == 51) run(std::integral_constant<int, 51>{});
+  else run(std::integral_constant<int, 0>{});
   return (int)hipGetLastError();
 }
 

@@ -114,3 +114,30 @@ class PairPool:
             q[self.queue_ptr:self.queue_ptr + b] = t
         self.queue_ptr += b
         return tuple(batch)
+
+
+class USMSharp(torch.nn.Module):
+    """basicsr/utils/img_process_util.py:63-83 on the HIP engine (ssg_usm_sharp): same constructor and forward
+    arguments; `img` (B,C,H,W) float32 CUDA in [0,1].  Not differentiable (the reference applies it to GT only,
+    realesrganssl_model.py:165,315)."""
+
+    def __init__(self, radius=50, sigma=0):
+        super().__init__()
+        self.radius = radius + 1 if radius % 2 == 0 else radius
+        self.sigma = float(sigma)
+
+    @torch.no_grad()
+    def forward(self, img, weight=0.5, threshold=10):
+        if not img.is_cuda:
+            raise RuntimeError("ssl_amd.datapath.USMSharp: tensor must be on the GPU (there is no CPU path)")
+        x = img.detach().to(torch.float32).contiguous()
+        B, C, H, W = x.shape
+        L = _lib.lib()
+        out = torch.empty_like(x)
+        nb = L.ssg_usm_scratch_bytes(B, C, H, W)
+        scratch = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ssg_usm_sharp(x.data_ptr(), out.data_ptr(), B, C, H, W, self.radius, self.sigma, float(weight),
+                                       float(threshold), scratch.data_ptr(), nb, torch.cuda.current_stream().cuda_stream))
+        return out.to(img.dtype)
+

@@ -551,8 +551,57 @@ def cpu_reference_timing():
     print("  ", res)
 
 
+def f12_usm():
+    """F12: the reference's USMSharp (basicsr/utils/img_process_util.py:63-83), imported by path
+    and run on the CPU (fp32).  `cv2` is not installed; the module's only cv2 call on this path is
+    cv2.getGaussianKernel(radius, sigma) in USMSharp.__init__, stubbed with the documented formula (the same
+    restatement the oracle uses, oracle/datapath_oracle.py gaussian_kernel_1d) -- so F12 pins filter2D's padding and
+    correlation, the residual / mask / soft-mask / clip / blend chain and the 51 x 51 outer-product kernel, not
+    OpenCV's kernel values themselves.  Inputs quantised to k/255 like real GT; the threshold test |residual| * 255
+    > 10 has no pixel within 5e-4 of the threshold (the seed is searched for that), so the mask is the same at any precision."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import datapath_oracle as dorc
+    from ssl_amd import synth
+    cv2 = types.ModuleType("cv2")
+    cv2.getGaussianKernel = lambda ksize, sigma: dorc.gaussian_kernel_1d(int(ksize), float(sigma)).reshape(-1, 1)
+    saved = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+    spec = importlib.util.spec_from_file_location("ref_img_process_util",
+                                                  "/root/reference/GAN-Based-SR/basicsr/utils/img_process_util.py")
+    ipu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ipu)
+    usm = ipu.USMSharp()                  # radius 50 -> 51, sigma 0: the configuration of realesrganssl_model.py:35
+    usm9 = ipu.USMSharp(radius=9, sigma=1.5)
+    if saved is not None:
+        sys.modules["cv2"] = saved
+    else:
+        del sys.modules["cv2"]
+    def margin_of(im, mod, kw, sg):
+        _, res, _ = dorc.usm_sharp(im, radius=mod.radius, sigma=sg, weight=kw.get("weight", 0.5),
+                                   threshold=kw.get("threshold", 10), return_parts=True)
+        return np.abs(np.abs(res) * 255 - kw.get("threshold", 10)).min()
+
+    cfgs = (("r50", usm, dict(), 0.0), ("r9", usm9, dict(weight=0.8, threshold=4), 1.5))
+    for seed in range(1200, 1300):   # first seed whose residuals keep clear of both thresholds (fp32 noise: ~3e-5)
+        img = np.stack([synth.natural_like(seed + 100 * i, 72, 88, 0.15, 0.05) for i in range(2)]).astype(np.float32)
+        if all(margin_of(img, m, kw, sg) > 5e-4 for _, m, kw, sg in cfgs):
+            break
+    else:
+        raise RuntimeError("no seed with a clear threshold margin")
+    x = torch.as_tensor(img)
+    out = dict(img=img, kernel51=usm.kernel.numpy()[0], seed=seed)
+    for tag, mod, kw, sg in cfgs:
+        o32 = mod(x, **kw).numpy()   # (fp32 only: forward()'s mask.float() rules out a double run of the module)
+        out["out32_" + tag] = o32
+        orc_out = dorc.usm_sharp(img, radius=mod.radius, sigma=sg, weight=kw.get("weight", 0.5),
+                                 threshold=kw.get("threshold", 10))
+        margin = margin_of(img, mod, kw, sg)
+        print("f12", tag, "fp64 oracle vs reference fp32:", np.abs(orc_out - o32).max(), "threshold margin", margin)
+    save("f12_usm", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11"]
+    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12"]
     torch.manual_seed(0)
     if "f1" in which:
         f1_c1()
@@ -576,5 +625,7 @@ if __name__ == "__main__":
         f10_paper_cotangent()
     if "f11" in which:
         f11_datapath()
+    if "f12" in which:
+        f12_usm()
     if "time" in which:
         cpu_reference_timing()

@@ -1186,3 +1186,39 @@ def test_fused_step_without_ssg_output_is_bit_identical(dev, ks, kw, shape, dens
                             engine._ptr(b.counts), engine._ptr(b.loss), engine._ptr(b.grad), engine._ptr(b.ws),
                             a.ws_bytes, None, engine._stream())
     assert rc == -3   # SSG_E_WORKSPACE
+
+
+@pytest.mark.gpu
+def test_f12_usm_sharp_vs_oracle_and_reference(dev, golden):
+    """ssg_usm_sharp / datapath.USMSharp against the fp64 oracle (2e-6) and the reference's own fp32
+    output (fixture F12, 3e-6: both sides round); tiles that overhang the image (72 x 88), both configurations, a
+    3-plane 40 x 200 strip, and the refusals (image side <= radius / 2, short scratch, in-place)."""
+    from oracle import datapath_oracle as dp
+    from ssl_amd import _lib, datapath, engine
+    g = golden("f12_usm")
+    x = T(g["img"], dev)
+    for mod, kw, okw, key in ((datapath.USMSharp(), {}, {}, "out32_r50"),
+                              (datapath.USMSharp(radius=9, sigma=1.5), dict(weight=0.8, threshold=4),
+                               dict(radius=9, sigma=1.5, weight=0.8, threshold=4), "out32_r9")):
+        y = mod(x, **kw).cpu().numpy()
+        assert np.abs(y - dp.usm_sharp(g["img"], **okw)).max() <= 2e-6
+        assert np.abs(y - g[key]).max() <= 3e-6
+    rng = np.random.default_rng(5)
+    strip = (np.round(rng.random((1, 3, 40, 200)) * 255) / 255).astype(np.float32)
+    ref, res, _ = dp.usm_sharp(strip, return_parts=True)
+    y = datapath.USMSharp()(T(strip, dev)).cpu().numpy()
+    tie = np.abs(np.abs(res) * 255 - 10) < 1e-3          # mask bits not determined at fp32 (random input: a few)
+    soft_tol = 2e-6 + 0.004 * tie.sum()                   # one flipped bit moves soft by <= max kernel weight 0.0025
+    assert np.abs(y - ref).max() <= soft_tol and tie.sum() < 20
+    L = _lib.lib()
+    small = T(strip[:, :, :20], dev)
+    out = torch.empty_like(small)
+    scr = torch.empty(L.ssg_usm_scratch_bytes(1, 3, 20, 200), dtype=torch.uint8, device=dev)
+    args = (1, 3, 20, 200, 50, 0.0, 0.5, 10.0, engine._ptr(scr))
+    assert L.ssg_usm_sharp(engine._ptr(small), engine._ptr(out), *args, scr.numel(), engine._stream()) == -4
+    assert L.ssg_usm_sharp(engine._ptr(small), engine._ptr(out), 1, 3, 20, 200, 9, 0.0, 0.5, 10.0, engine._ptr(scr), 16,
+                           engine._stream()) == -3
+    assert L.ssg_usm_sharp(engine._ptr(small), engine._ptr(small), 1, 3, 20, 200, 9, 0.0, 0.5, 10.0, engine._ptr(scr),
+                           scr.numel(), engine._stream()) == -1
+    with pytest.raises(RuntimeError):
+        datapath.USMSharp()(torch.zeros(1, 3, 64, 64))

@@ -255,3 +255,18 @@ def test_f7_laplacian_second_independent_derivation(golden):
     lap = F.conv2d(F.pad(L, (1, 1, 1, 1), mode="reflect"), K).clamp(0, 255)[0, 0].numpy().astype(np.uint8)
     assert np.array_equal(lap, g["lap"])
     assert np.array_equal((lap > 20).astype(np.uint8), g["mask"])
+
+
+def test_f12_usm_oracle_vs_reference(golden):
+    """USM sharpening: the fp64 numpy restatement against the reference's USMSharp run in fp32
+    (fixture F12: radius 50 / sigma 0 -- the model's configuration -- and radius 9 / sigma 1.5, weight 0.8, threshold
+    4).  The reference sums 2601 fp32 taps per pixel, hence 2e-6; its 51 x 51 kernel buffer is the rounded outer
+    product of the oracle's 1-D kernel (whose values are pinned by OpenCV's documentation only)."""
+    from oracle import datapath_oracle as dp
+    g = golden("f12_usm")
+    k = dp.gaussian_kernel_1d(51, 0.0)
+    assert abs(k.sum() - 1) < 1e-15 and np.array_equal(np.outer(k, k).astype(np.float32), g["kernel51"])
+    assert np.array_equal(dp.gaussian_kernel_1d(3), [0.25, 0.5, 0.25])
+    _close(dp.usm_sharp(g["img"]), g["out32_r50"], 2e-6)
+    _close(dp.usm_sharp(g["img"], radius=9, sigma=1.5, weight=0.8, threshold=4), g["out32_r9"], 2e-6)
+    assert np.abs(g["out32_r50"] - g["img"]).max() > 0.02   # (the sharpening does something on this input)
