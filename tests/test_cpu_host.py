@@ -247,3 +247,9 @@ def test_argument_checks_need_no_gpu():
     assert L.ssg_augment_crop(one, one, 2, 1, 3, 8, 8, 4, 4, one, None) == -1            # element size 2
     assert L.ssg_grad_fix_bytes(2, 3, 16, 16) == 8 * (2 * 3 * 16 * 16 + 8)
     assert L.ssg_backward_scratch_bytes(100, 25) >= 100 * 625 * 4
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() -- the driver's "does it build" check -- must keep up with the library (ABI version)."""
+    import __graft_entry__ as g
+    g.build()
