@@ -38,6 +38,7 @@ __device__ __forceinline__ float dpp_row_shr(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xf, 0xf, true));
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // Inclusive prefix over 8 tile rows held 2 lanes apart in a 16-lane DPP row, for 5 values at once: 15 in-place DPP
@@ -303,7 +304,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
 
   // ---- the lane's own pixels, and Box(sum_b) on them ----
   const float *src = p.img + (size_t)b * C * H * W;
-  float iu[C][NPX];
+  // (channels 0 and 1 of a pixel travel as one packed-fp32 register pair, channel 2 alone: the per-pixel work of a
+  // step is then 1 v_pk + 1 scalar instruction instead of 3 -- the ring slots of the u+q window rotate by one pixel
+  // per step, so pairing two PIXELS would alternate alignment, pairing two CHANNELS of one pixel never does)
+  static_assert(C == 3, "channel pairing: (0,1) packed + 2");
+  f2 iuA[NPX];
+  float iuB[NPX];
   {
     int gy = reflect_idx(ty0 - HK + r, H);
     gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
@@ -311,8 +317,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     for (int i = 0; i < NPX; ++i) {
       int gx = reflect_idx(tx0 - HK + NPX * g + i, W);
       gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-#pragma unroll
-      for (int c = 0; c < C; ++c) iu[c][i] = src[((size_t)c * H + gy) * W + gx];
+      iuA[i] = f2{src[((size_t)0 * H + gy) * W + gx], src[((size_t)1 * H + gy) * W + gx]};
+      iuB[i] = src[((size_t)2 * H + gy) * W + gx];
     }
   }
   // image band rows: global -> registers -> LDS (lane = region column)
@@ -368,12 +374,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     store_img_row(rho, v);
   }
 
-  float gu[C][NPX], swb[NPX];
+  f2 guA[NPX];
+  float guB[NPX], swb[NPX];
 #pragma unroll
   for (int i = 0; i < NPX; ++i) {
     swb[i] = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) gu[c][i] = 0.f;
+    guA[i] = f2{0.f, 0.f};
+    guB[i] = 0.f;
   }
 
   // G values of the lane's edge pixels, 4 offsets per load, one group ahead (two register slots) + the row's
@@ -433,14 +440,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     const int slr = (r + qyi) & RMASK;
     const float *ib = imgb + slr * BRS + NPX * g;
     float *gb = grb + slr * BRS + NPX * g;
-    float w[C][NPX], gr[C][NPX];
+    f2 wA[NPX], grA[NPX];
+    float wB[NPX], grB[NPX];
 #pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-      for (int i = 0; i < NPX; ++i) {
-        w[c][i] = ib[c * RWS + i];
-        gr[c][i] = 0.f;
-      }
+    for (int i = 0; i < NPX; ++i) {
+      wA[i] = f2{ib[i], ib[RWS + i]};
+      wB[i] = ib[2 * RWS + i];
+      grA[i] = f2{0.f, 0.f};
+      grB[i] = 0.f;
+    }
     static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
@@ -478,11 +486,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
         const float Wi = Wv[i];
         if constexpr (xborder) swb[i] += Wi;
         else swb[i] = __builtin_fmaf(Wi, ymask, swb[i]);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const float d = iu[c][i] - w[c][(i + qxi) % NPX];
-          gu[c][i] = __builtin_fmaf(Wi, d, gu[c][i]);
-          gr[c][(i + qxi) % NPX] = __builtin_fmaf(-Wi, d, gr[c][(i + qxi) % NPX]);
+        const int sl = (i + qxi) % NPX;
+        const float dB = iuB[i] - wB[sl];
+        guB[i] = __builtin_fmaf(Wi, dB, guB[i]);
+        grB[sl] = __builtin_fmaf(-Wi, dB, grB[sl]);
+        if constexpr (RG == 4) {   // measured: packed 2.27 -> 2.06 ms for (49,13); 0.31 -> 0.33 ms for (25,9), which stays scalar
+          const f2 Wi2 = f2{Wi, Wi};
+          const f2 dA = iuA[i] - wA[sl];
+          guA[i] = __builtin_elementwise_fma(Wi2, dA, guA[i]);
+          grA[sl] = __builtin_elementwise_fma(-Wi2, dA, grA[sl]);
+        } else {
+          const float d0 = iuA[i].x - wA[sl].x, d1 = iuA[i].y - wA[sl].y;
+          guA[i].x = __builtin_fmaf(Wi, d0, guA[i].x);
+          guA[i].y = __builtin_fmaf(Wi, d1, guA[i].y);
+          grA[sl].x = __builtin_fmaf(-Wi, d0, grA[sl].x);
+          grA[sl].y = __builtin_fmaf(-Wi, d1, grA[sl].y);
         }
       }
       // ---- next offset: horizontal sums over its column taps, vertical prefix ----
@@ -513,25 +531,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
         for (int i = 0; i < HOUT; ++i) fn[hdst[i]] = out[i];
       }
       // region column NPX*g + qxi of this band row is complete: to the band; the window moves on
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        gb[c * RWS + qxi] = fl[c] + gr[c][qxi % NPX];
-        gr[c][qxi % NPX] = 0.f;
-        if constexpr (qxi + 1 < KS) w[c][qxi % NPX] = wn[c];
+      {
+        constexpr int s0 = qxi % NPX;
+        gb[qxi] = fl[0] + grA[s0].x;
+        gb[RWS + qxi] = fl[1] + grA[s0].y;
+        gb[2 * RWS + qxi] = fl[2] + grB[s0];
+        grA[s0] = f2{0.f, 0.f};
+        grB[s0] = 0.f;
+        if constexpr (qxi + 1 < KS) {
+          wA[s0] = f2{wn[0], wn[1]};
+          wB[s0] = wn[2];
+        }
       }
       x_put(std::integral_constant<int, qx2>{}, qxi + 2 < KS ? qyi : qyn, fc);
       // (the accumulators of the lane's own pixels pass through an empty asm: they are not read again before
       // the end of the sweep, and hipcc otherwise sinks their FMAs below all k_s steps, keeping every step's
       // W and differences alive: 1,000 spilled registers)
-      pin_block<C, NPX>(gu);
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        asm volatile("" : "+v"(guA[i]));
+        asm volatile("" : "+v"(guB[i]));
+      }
       pin_row<NPX>(swb);
       step_fence();
     });
     // the row's last NPX-1 columns
 #pragma unroll
     for (int i = 1; i < NPX; ++i)
-#pragma unroll
-      for (int c = 0; c < C; ++c) gb[c * RWS + KS - 1 + i] += gr[c][(i + KS - 1) % NPX];
+    {
+      gb[KS - 1 + i] += grA[(i + KS - 1) % NPX].x;
+      gb[RWS + KS - 1 + i] += grA[(i + KS - 1) % NPX].y;
+      gb[2 * RWS + KS - 1 + i] += grB[(i + KS - 1) % NPX];
+    }
     __builtin_amdgcn_wave_barrier();
     flush_row(r0 + qyi);
     store_img_row(r0 + qyi + RR, nrow);
@@ -568,7 +599,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       const float vt = vbox[i] - swb[i];
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float v = __builtin_fmaf(iu[c][i], vt, gu[c][i]);
+        const float iuc = c == 0 ? iuA[i].x : c == 1 ? iuA[i].y : iuB[i], guc = c == 0 ? guA[i].x : c == 1 ? guA[i].y : guB[i];
+        const float v = __builtin_fmaf(iuc, vt, guc);
         if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
       }
     }
