@@ -51,7 +51,7 @@ __device__ __forceinline__ void shared_window_sums(const float (&v)[BS + KW - 1]
 // -HK .. KS+HK-1 need no masking; rows outside the tile come from the all-zero row.
 template <class G>
 __device__ __forceinline__ void load_grow(const float *tg, const float *zrow, int ry, int cx0, float (&out)[G::PW]) {
-  const float *rowp = ((unsigned)ry < (unsigned)G::KS) ? (tg + ry * (G::KS + G::HK)) : zrow;
+  const float *rowp = ((unsigned)ry < (unsigned)G::KS) ? (tg + ry * G::GS) : zrow;
 #pragma unroll
   for (int j = 0; j < G::PW; ++j) out[j] = rowp[cx0 + j];
 }
@@ -67,7 +67,7 @@ template <class G, int KHC>
 __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
   constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
-  constexpr int JOBS = G::JOBS, PW = G::PW, S = KS + HK, CHG = KS * S;  // G tile: row stride, size
+  constexpr int JOBS = G::JOBS, PW = G::PW, S = G::GS, CHG = KS * S;  // G tile: row stride, size
   constexpr int PADF = (HK + 3) & ~3;
   constexpr int NCH = (KW + KHC - 1) / KHC;  // pass-B chunks of KHC stencil rows
   constexpr int SL = KHC * KW;               // partials per chunk
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
     sh_edge[tid * 4 + 3] = row;
   }
   for (int i = tid; i < G::ZROW + 4; i += WG) zero[i] = 0.f;
-  for (int i = tid; i < JOBS * KS * HK; i += WG) gt[(i / HK) * S + KS + i % HK] = 0.f;
+  for (int i = tid; i < JOBS * KS * (S - KS); i += WG) gt[(i / (S - KS)) * S + KS + i % (S - KS)] = 0.f;
   if (tid < PADF) smem[tid] = 0.f;
   __syncthreads();
 
@@ -756,7 +756,7 @@ int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st
 template <class G, int KHC>
 static size_t bwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
-  return sizeof(float) * (size_t)(PADF + G::JOBS * G::KS * (G::KS + G::HK) + ((G::ZROW + 3) & ~3) + G::JOBS * KHC * G::KW * G::LPJ +
+  return sizeof(float) * (size_t)(PADF + G::JOBS * G::KS * G::GS + ((G::ZROW + 3) & ~3) + G::JOBS * KHC * G::KW * G::LPJ +
                                   G::WG + G::JOBS * 4 + G::JOBS * 4 + G::JOBS * (C + 1) * G::KW * G::KW + 8);
 }
 

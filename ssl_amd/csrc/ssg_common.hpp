@@ -46,6 +46,10 @@ struct Geo {
   static constexpr int S = KS + 1;               // LDS row stride of a tile (floats)
   static constexpr int CH = KS * S;              // LDS channel stride
   static constexpr int ZROW = NB * BS + 2 * HK;  // length of the all-zero row
+  // Backward: row stride of a job's G tile (KS values, then >= HK zeros).  The 25 lanes of a job read rows 5 by + r at
+  // columns 5 bx + j: with KS + HK = 29 two of them share a bank (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.49 for
+  // ssg_bwd_tiled<Geo<25,9,5,128>>), with 37 the 25 addresses 185 by + 5 bx fall on 25 different banks.
+  static constexpr int GS = (KS == 25 && KW == 9) ? 37 : KS + HK;
   static_assert(JOBS >= 1, "workgroup too small for one job");
   static_assert(KW <= KS && (KS & 1) && (KW & 1), "odd sizes, k_w <= k_s");
 };
