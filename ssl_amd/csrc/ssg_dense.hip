@@ -222,26 +222,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       elist[3 * pos + 2] = r;
     }
   } else {
-    const int ey = tid / DT_X, ex = tid % DT_X;
-    const int y = ty0 + ey, x = tx0 + ex;
-    int r = (ey < DT_Y && y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
-    if (r >= nrows) r = -1;
-    const unsigned long long bal = __ballot(r >= 0);
-    if (lane == 0) misc[wv] = __popcll(bal);
-    __syncthreads();
-    int base = 0;
-    for (int k = 0; k < wv; ++k) base += misc[k];
-    if (r >= 0) {
-      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-      elist[3 * pos + 0] = ey;
-      elist[3 * pos + 1] = ex;
-      elist[3 * pos + 2] = r;
+    // k_w 13: a fixed map instead of a list -- slot e = 64 p + lane is pixel (ey = 2 (lane / 32) + p, ex = lane % 32),
+    // row -1 where that pixel is no edge pixel: a lane's two pixels sit in one column, one row apart, so their
+    // vertical windows share 12 of 13 taps and the edge stage reads 14 H values for both (26 before)
+    static_assert(HPAIR || (DT_Y == 4 && NCHUNK == 2), "pair map: 4 x 32 tile, two pixels per lane");
+    if (tid < NE_MAX) {
+      const int pp = tid >> 6, ln = tid & 63;
+      const int ey = 2 * (ln >> 5) + pp, ex = ln & 31;
+      const int y = ty0 + ey, x = tx0 + ex;
+      int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+      if (r >= nrows) r = -1;
+      elist[3 * tid + 0] = ey;
+      elist[3 * tid + 1] = ex;
+      elist[3 * tid + 2] = r;
     }
-    if (tid == 0) {
-      int t = 0;
-      for (int k = 0; k < NW; ++k) t += misc[k];
-      misc[NW] = t;
-    }
+    if (tid == 0) misc[NW] = NE_MAX;
   }
   // ---- image region: C x RH x RWD, reflect by index mirroring (clamped: far corners of
   // tiles that overhang a small image are never used, but must stay in bounds) ----
@@ -330,10 +325,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int ck = 0; ck < NCHUNK; ++ck) {
     const int e = ck * 64 + lane;
     eon[ck] = e < n_e && elist[3 * (e < n_e ? e : 0) + 2] >= 0;
-    const int ec = eon[ck] ? e : 0;
+    // (k_w 13: the slot's position is the fixed map's whether or not the pixel is an edge pixel -- the lane's two
+    // windows are read through hoff[0])
+    const int ec = (eon[ck] || !HPAIR) ? e : 0;
     const int ey = elist[3 * ec], ex = elist[3 * ec + 1];
     hoff[ck] = ey * DT_HS + dense_h_col(ex, L, HG, HPAIR);  // window row k of the centre is U-row ey + k
-    orow[ck] = (size_t)elist[3 * ec + 2] * P;
+    orow[ck] = eon[ck] ? (size_t)elist[3 * ec + 2] * P : 0;
   }
 
   const int n_e_stage = (p.dbg & 2) ? 0 : n_e;  // profiling ablations: 2 no edge stage, 1 no stores, 64 no main loop
@@ -348,6 +345,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float wgt[KW];
 #pragma unroll
     for (int k = 0; k < KW; ++k) wgt[k] = (k - HK >= ylo && k - HK <= yhi) ? 1.f : 0.f;
+    const bool interior = ylo == -HK && yhi == HK;
     float av[NCHUNK];
 #pragma unroll
     for (int ck = 0; ck < NCHUNK; ++ck) {
@@ -467,14 +465,46 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // (the H buffer is private to this wave and LDS operations of one wave execute in issue order: the reads
       // below see the writes above, and the next step's writes cannot overtake them -- no wait, no barrier)
       // ---- the tile's edge pixels: weighted vertical taps, row complement, exp, store ----
+      float dpair[2];
+      if constexpr (!HPAIR) {
+        if (n_e_stage > 0) {
+          // the lane's two pixels (rows ey0, ey0 + 1 of one column): 14 H values serve both windows
+          const float *hc = hb + hoff[0];
+          float hv[KW + 1];
+#pragma unroll
+          for (int k = 0; k <= KW; ++k) hv[k] = hc[k * DT_HS];
+          if (interior) {   // every tap kept, no complement: the 12 shared taps are summed once
+            f2 t01 = f2{hv[2], hv[3]} + f2{hv[4], hv[5]}, t23 = f2{hv[6], hv[7]} + f2{hv[8], hv[9]};
+            t01 = t01 + f2{hv[10], hv[11]};
+            t01 = t01 + t23;
+            const float common = (t01.x + t01.y) + (hv[1] + hv[KW - 1]);
+            dpair[0] = common + hv[0];
+            dpair[1] = common + hv[KW];
+          } else {
+            float h0[KW], h1[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+              h0[k] = hv[k];
+              h1[k] = hv[k + 1];
+            }
+            dpair[0] = tap_sum<KW>(h0, wgt, av[0]);
+            dpair[1] = tap_sum<KW>(h1, wgt, av[1]);
+          }
+        }
+      }
 #pragma unroll
       for (int ck = 0; ck < NCHUNK; ++ck) {
         if (ck * 64 < n_e_stage) {
-          const float *hc = hb + hoff[ck];
-          float hv[KW];
+          float d;
+          if constexpr (HPAIR) {
+            const float *hc = hb + hoff[ck];
+            float hv[KW];
 #pragma unroll
-          for (int k = 0; k < KW; ++k) hv[k] = hc[k * DT_HS];
-          const float d = tap_sum<KW>(hv, wgt, av[ck]);
+            for (int k = 0; k < KW; ++k) hv[k] = hc[k * DT_HS];
+            d = tap_sum<KW>(hv, wgt, av[ck]);
+          } else {
+            d = dpair[ck];
+          }
           const float ev = __builtin_amdgcn_exp2f(d * nk);
           rs[ck] += (double)ev;
           // every lane writes its own SSG row: single dwords are one L2 request per lane and step (request-
