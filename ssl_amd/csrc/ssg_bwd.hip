@@ -72,7 +72,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   constexpr int NCH = (KW + KHC - 1) / KHC;  // pass-B chunks of KHC stencil rows
   constexpr int SL = KHC * KW;               // partials per chunk
   constexpr int EPL = (P + LPJ - 1) / LPJ;   // row elements per lane
-  constexpr int MH = KS + 7, MW = KS + 15;   // merge window: centres within 8 rows x 16 columns
+  constexpr int MH = KS + MERGE_ROWS - 1, MW = KS + MERGE_COLS - 1;   // merge window: centres within 8 rows x 16 columns
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = p.C, H = p.H, W = p.W;

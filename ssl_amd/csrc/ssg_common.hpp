@@ -101,6 +101,9 @@ __device__ __forceinline__ void pin_block(float (&v)[R][N]) {
 // `order` entries: bits 0..29 = row; bit 30 of the FIRST entry of every group of ORDER_GROUP
 // consecutive entries = "these jobs are one image's edge pixels within 8 rows x 16 columns".
 constexpr int ORDER_GROUP = 5;
+// a group of jobs is "mergeable" (one shared LDS region / gradient window) when its edge pixels are one image's and lie
+// within MERGE_ROWS x MERGE_COLS pixels
+constexpr int MERGE_ROWS = 16, MERGE_COLS = 16;
 constexpr int ORDER_FLAG = 1 << 30;
 constexpr int ORDER_MASK = ORDER_FLAG - 1;
 

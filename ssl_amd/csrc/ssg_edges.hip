@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void tile_group_flags(int *order_a, const int 
     x0 = x < x0 ? x : x0;
     x1 = x > x1 ? x : x1;
   }
-  ok = ok && (y1 - y0) <= 7 && (x1 - x0) <= 15;
+  ok = ok && (y1 - y0) <= MERGE_ROWS - 1 && (x1 - x0) <= MERGE_COLS - 1;
   order[k0] = first | (ok ? ORDER_FLAG : 0);
 }
 

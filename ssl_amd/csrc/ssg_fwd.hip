@@ -46,7 +46,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
   constexpr int JOBS = G::JOBS, PW = G::PW, S = G::S, CH = G::CH;
   constexpr int PADF = (HK + 3) & ~3;
-  constexpr int MH = KS + 7, MW = KS + 15, MS = MW + 1;  // merged region: rows, cols, row stride
+  constexpr int MH = KS + MERGE_ROWS - 1, MW = KS + MERGE_COLS - 1, MS = MW + 1;  // merged region: rows, cols, row stride
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = p.C, H = p.H, W = p.W;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void ssg_fwd_generic(FwdParams p) {
 template <class G, bool MERGED>
 static size_t fwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
-  constexpr int MH = G::KS + 7, MS = G::KS + 16;
+  constexpr int MH = G::KS + MERGE_ROWS - 1, MS = G::KS + MERGE_COLS;
   const size_t region = (size_t)C * MH * MS, rows = (size_t)G::JOBS * G::P;
   const size_t tiles = MERGED ? ((region > rows ? region : rows + 1) & ~(size_t)1) : (size_t)G::JOBS * C * G::CH;
   return sizeof(float) * (size_t)(PADF + tiles + ((G::ZROW + 3) & ~3) + 4 + 2 * G::WG) + sizeof(int) * 6 * G::JOBS;
