@@ -103,7 +103,7 @@ __device__ __forceinline__ void pin_block(float (&v)[R][N]) {
 constexpr int ORDER_GROUP = 5;
 // a group of jobs is "mergeable" (one shared LDS region / gradient window) when its edge pixels are one image's and lie
 // within MERGE_ROWS x MERGE_COLS pixels
-constexpr int MERGE_ROWS = 16, MERGE_COLS = 16;
+constexpr int MERGE_ROWS = 8, MERGE_COLS = 16;   // (16 x 16 measured: no change at C2)
 constexpr int ORDER_FLAG = 1 << 30;
 constexpr int ORDER_MASK = ORDER_FLAG - 1;
 
