@@ -245,6 +245,75 @@ def ssg_loss(sr, gt, edges, counts, n_rows, ks=25, kw=9, sigma=0.004, eps=1e-10,
                             w_kl, order, fwd, deterministic)
 
 
+class _SSGFusedFn(torch.autograd.Function):
+    """(l1, kl) of a batch straight from the mask: ONE C call (ssg_loss_fwd_bwd in its fused form, ssg_sr = ssg_gt =
+    NULL) builds the edge list, both SSGs as scratch rows inside the workspace, the criteria and d(l1+kl)/d sr.  Only
+    that gradient (and the inputs, for the rare case below) is kept for backward(), which scales it by the incoming
+    gradient; if autograd hands two DIFFERENT gradients for l1 and kl the step is redone through _SSGLossFn with them.
+    `counts` (B+2 int32, device) receives the edge counts of the call."""
+
+    @staticmethod
+    def forward(ctx, sr, gt, mask, counts, cap, ks, kw, sigma, eps, generalization, w_l1, w_kl, mask_stride, lap_threshold,
+                det):
+        L = _lib.lib()
+        x, y = _f32c(sr), _f32c(gt)
+        B, C, H, W = x.shape
+        if mask is None:
+            kind, mc, mp = 2, 3, None
+            if C != 3:
+                raise ValueError("Laplacian edge mask needs a 3-channel image")
+        elif mask.dtype == torch.uint8 or mask.dtype == torch.bool:
+            mp = mask.contiguous().view(torch.uint8)
+            kind, mc = 1, mp.shape[1]
+        else:
+            mp = _f32c(mask)
+            kind, mc = 0, mp.shape[1]
+        want_grad = bool(ctx.needs_input_grad[0])
+        dev = x.device
+        loss = torch.zeros(2, dtype=torch.float32, device=dev)
+        grad = torch.zeros_like(x) if want_grad else None
+        nb = L.ssg_loss_workspace_bytes(B, H, W, cap, ks) + L.ssg_loss_rows_bytes(cap, ks)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        fix = _grad_fix(det, x) if want_grad else None
+        with torch.cuda.device(dev):
+            _lib.check(L.ssg_loss_fwd_bwd(_ptr(x), _ptr(y), _ptr(mp), kind, mc, B, C, H, W, ks, kw, float(sigma),
+                                          float(eps), int(bool(generalization)), float(w_l1), float(w_kl),
+                                          int(mask_stride or 0), float(lap_threshold), cap, None, None, _ptr(counts),
+                                          _ptr(loss), _ptr(grad), _ptr(ws), nb, _ptr(fix), _stream()))
+        ctx.cfg = (cap, ks, kw, sigma, eps, generalization, w_l1, w_kl, mask_stride, lap_threshold, det)
+        ctx.in_dtype = sr.dtype
+        ctx.has_mask = mask is not None
+        if want_grad:
+            ctx.save_for_backward(x, y, grad, *((mask,) if mask is not None else ()))
+        return loss[0], loss[1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_l1, g_kl):
+        x, y, grad = ctx.saved_tensors[:3]
+        mask = ctx.saved_tensors[3] if ctx.has_mask else None
+        same = (g_l1.data_ptr() == g_kl.data_ptr() and g_l1.numel() == 1 and g_kl.numel() == 1)
+        if same:
+            out = grad * g_l1.to(torch.float32).reshape(())
+        else:
+            cap, ks, kw, sigma, eps, gen, w_l1, w_kl, stride, thr, det = ctx.cfg
+            up = torch.stack([g_l1.to(torch.float32).reshape(()), g_kl.to(torch.float32).reshape(())]).contiguous()
+            el = edge_list(mask=mask, gt=y if mask is None else None, mask_stride=stride, lap_threshold=thr,
+                           capacity=cap, ks=ks)
+            with torch.cuda.device(x.device):
+                _, out = _SSGLossFn._run(x, y, el.edges, el.counts, cap, ks, kw, float(sigma), float(eps),
+                                         int(bool(gen)), float(w_l1), float(w_kl), el.order, el.fwd, up, True, det)
+        return (out.to(ctx.in_dtype),) + (None,) * 14
+
+
+def ssg_loss_from_mask(sr, gt, mask, counts, capacity, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True,
+                       w_l1=1.0, w_kl=1.0, mask_stride=0, lap_threshold=20.0, deterministic=None):
+    """Differentiable (l1, kl) of a batch from its mask (or from GT's Laplacian, mask=None) in one fused C call."""
+    _need_gpu(sr, gt, mask, counts)
+    return _SSGFusedFn.apply(sr, gt, mask, counts, int(capacity), int(ks), int(kw), sigma, eps, generalization, w_l1,
+                             w_kl, mask_stride, lap_threshold, deterministic)
+
+
 class LossStep:
     """The whole loss step in ONE C call (ssg_loss_fwd_bwd): edge list, SSG(sr), SSG(gt),
     L1 + KL and d(l1+kl)/d sr, with persistent buffers sized for `capacity` edge pixels.

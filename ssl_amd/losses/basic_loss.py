@@ -125,15 +125,15 @@ class SSGLoss(nn.Module):
         cap = self.capacity if self.capacity is not None else max(1024, (B * H * W) // 4)
         cap = min(cap, B * H * W)
         self.capacity = cap
-        el = engine.edge_list(mask=mask, gt=gt if mask is None else None, mask_stride=self.mask_stride,
-                              lap_threshold=self.lap_threshold, capacity=cap, ks=self.ks)
-        self.last_counts = el.counts
+        counts = torch.empty(B + 2, dtype=torch.int32, device=sr.device)
+        out = engine.ssg_loss_from_mask(sr, gt.detach(), mask, counts, cap, self.ks, self.kw, self.sigma, self.eps,
+                                        self.generalization, self.w_l1, self.w_kl, self.mask_stride, self.lap_threshold,
+                                        self.deterministic)
+        self.last_counts = counts
         if self._pending is None:      # one outstanding copy at a time
             host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            host.copy_(el.counts[:1], non_blocking=True)
+            host.copy_(counts[:1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             self._pending = (ev, host, cap)
-        return engine.ssg_loss(sr, gt.detach(), el.edges, el.counts, cap, self.ks, self.kw, self.sigma, self.eps,
-                               self.generalization, self.w_l1, self.w_kl, order=el.order, fwd=el.fwd,
-                               deterministic=self.deterministic)
+        return out

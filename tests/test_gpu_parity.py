@@ -1222,3 +1222,27 @@ def test_f12_usm_sharp_vs_oracle_and_reference(dev, golden):
                            scr.numel(), engine._stream()) == -1
     with pytest.raises(RuntimeError):
         datapath.USMSharp()(torch.zeros(1, 3, 64, 64))
+
+
+@pytest.mark.gpu
+def test_module_backward_with_two_different_upstream_gradients(dev):
+    """SSGLoss keeps d(l1 + kl)/d sr from its fused forward call; when autograd hands DIFFERENT gradients to the two
+    outputs (2 l1 + 3 kl) the step is redone with them on the device.  Checked against the two single-criterion
+    gradients obtained with loss weights (w, 0) and (0, w): grad = 2 g_l1 + 3 g_kl."""
+    from ssl_amd import SSGLoss, synth
+    gt = synth.natural_like(77, 64, 96)[None]
+    sr = synth.degrade(gt[0], 78)[None]
+    mask = synth.laplacian_edge_mask(gt[0])[None, None].astype(np.float32)
+    tg, tm = T(gt, dev), T(mask, dev)
+
+    def grad_of(w1, w2, c1, c2):
+        x = T(sr, dev).requires_grad_(True)
+        a, b = SSGLoss(25, 9, 0.05, True, w1, w2, deterministic=True)(x, tg, tm)
+        (c1 * a + c2 * b).backward()
+        return x.grad.clone()
+
+    g_mixed = grad_of(1e3, 1e3, 2.0, 3.0)
+    g_l1, g_kl = grad_of(1e3, 0.0, 1.0, 1.0), grad_of(0.0, 1e3, 1.0, 1.0)
+    ref = 2.0 * g_l1 + 3.0 * g_kl
+    assert float(ref.abs().max()) > 0
+    assert float((g_mixed - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
