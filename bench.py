@@ -239,6 +239,26 @@ def pmc_traffic(kernel_name):
     return None
 
 
+def pmc_issue(config_key, step_gpu_ms):
+    """Issued VALU wave-instructions and LDS-active cycles of one step from the committed SQ passes (profiles/
+    pmc_traffic.json: SQ_INSTS_VALU / SQ_LDS_IDX_ACTIVE per launch, summed over the step's kernels), priced against
+    the step's GPU time measured here: a wave64 VALU instruction holds its SIMD for 4 cycles, 1024 SIMDs at 2.4 GHz."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ks = [k for k in json.load(f).get("kernels", {}).values() if k.get("config") == config_key]
+        insts = sum(k.get("valu_insts_per_launch", 0.0) for k in ks)
+        lds = sum(k.get("lds_active_cycles_per_launch", 0.0) for k in ks)
+        if not insts:
+            return None
+        valu_ms = insts * 4.0 / (256 * 4) / 2.4e9 * 1e3
+        lds_ms = lds / 256 / 2.4e9 * 1e3
+        return {"valu_wave_insts_per_step": insts, "valu_issue_ms": valu_ms, "valu_issue_frac_of_step": valu_ms / step_gpu_ms,
+                "lds_active_ms_per_cu": lds_ms, "lds_active_frac_of_step": lds_ms / step_gpu_ms,
+                "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_LDS_IDX_ACTIVE, tools/r2_final.sh)"}
+    except (OSError, ValueError):
+        return None
+
+
 def make_inputs(cfg, rank, world, scaling):
     """Synthetic batch of this rank (numpy): weak = `batch` images per rank, strong = the rank's share of ONE batch."""
     import numpy as np
@@ -397,7 +417,8 @@ def main():
                          "frac": tflops / FP32_PEAK_TFLOPS, "alg_flops_per_edge_px": alg_flops_per_edge_px(cfg),
                          "note": "SURVEY's DIRECT flop count over the step's GPU time; the dense-tile kernels do "
                                  "fewer real flops, so this is throughput in reference-equivalent flops, not "
-                                 "VALU utilisation (see profiles/ for SQ_INSTS_VALU)"}}
+                                 "VALU utilisation (`issued` has the instructions actually issued)",
+                         "issued": pmc_issue(args.config, step_gpu_ms)}}
             if not args.no_module and not args.no_ssg_output:
                 mm = module_time_ms(cfg, sr, gt, mask, n_edges, it)
                 res["module"] = {"what": "ssl_amd.SSGLoss forward + autograd backward (drop-in path)",

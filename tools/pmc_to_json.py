@@ -19,7 +19,7 @@ for cfg in ("c2", "c5"):
     for f in glob.glob(os.path.join(src, "pmc_" + cfg, "p*", "pmc_counter_collection.csv")):
         per = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE") and "ssg_" in r["Kernel_Name"]:
+            if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE") and "ssg_" in r["Kernel_Name"]:
                 per[(r["Kernel_Name"], r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
         for (k, _), d in per.items():
             for c, v in d.items():
@@ -28,8 +28,11 @@ for cfg in ("c2", "c5"):
         name = k.replace("void ssg::", "").split("(")[0].replace(" ", "")
         fetch = sum(d.get("FETCH_SIZE", [0])) / max(len(d.get("FETCH_SIZE", [1])), 1) * 1024
         write = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [1])), 1) * 1024
+        mean = lambda c: sum(d.get(c, [0])) / max(len(d.get(c, [1])), 1)
         out["kernels"][name] = {"config": cfg, "fetch_bytes_raw": fetch, "write_bytes_raw": write,
-                                "hbm_bytes_per_launch": write + 2 * fetch}
+                                "hbm_bytes_per_launch": write + 2 * fetch,
+                                "valu_insts_per_launch": mean("SQ_INSTS_VALU"),          # wave-instructions
+                                "lds_active_cycles_per_launch": mean("SQ_LDS_IDX_ACTIVE")}  # summed over the CUs
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 tot = collections.defaultdict(float)
 for k, v in out["kernels"].items():
