@@ -1,0 +1,25 @@
+"""Time the direct forward kernels at C2 (rows outside the dense tiles) under their profiling ablations."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from ssl_amd import engine, synth, _lib
+dev = torch.device("cuda:0")
+L = _lib.lib()
+sr_np, gt_np, mask_np = synth.make_batch(16, 256, 256)
+sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
+n = int(mask_np.sum())
+step = engine.LossStep(16, 3, 256, 256, 25, 9, 1.0, 1e-10, True, 1e3, 1e3, device=dev, capacity=n + 1024)
+step(sr, gt, mask); torch.cuda.synchronize()
+p = engine._ptr
+st = torch.cuda.current_stream().cuda_stream
+el = engine.edge_list(mask=mask, capacity=n + 1024, ks=25)
+def fwd():
+    _lib.check(L.ssg_map_forward(p(sr), p(gt), 16, 3, 256, 256, p(el.edges), p(el.order), p(el.rank), p(el.plan), p(el.counts),
+                                 n, 25, 9, 1.0, 1e-10, 1, p(step.ssg_sr), p(step.ssg_gt), None, st))
+base = 1 << 25   # skip the dense forward launch
+for name, bits in (("full", 0), ("no fill", 1), ("no main loop", 2), ("no epilogue", 4), ("no fill, no main loop", 3),
+                   ("only launch + job setup", 7)):
+    L.ssg_set_profile_mask(base | bits)
+    fwd(); torch.cuda.synchronize()
+    print(f"direct forward (2 launches), {name:26s}: {bench.event_time_ms(fwd, 20):.3f} ms")
+L.ssg_set_profile_mask(0)
