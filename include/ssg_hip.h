@@ -275,6 +275,12 @@ int ssg_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slot
  * F.pad raises); odd kernel size <= 63; scratch >= ssg_usm_scratch_bytes (3 planes of the batch).  Reference defaults:
  * radius 50, sigma 0, weight 0.5, threshold 10.  Floating point: within 2e-6 of the fp64 evaluation except where
  * |residual| * 255 is within rounding of `threshold` (the mask bit is then not determined at fp32). */
+/* filter2D (basicsr/utils/img_process_util.py:7-31; the blur steps of the degradation chain,
+ * realesrganssl_model.py:173,212,245,281,294): out[b,c] = reflect-padded img[b,c] correlated with kernels[b] (n_kernels
+ * == B) or kernels[0] (n_kernels == 1); kernels (n_kernels, k, k) fp32, k odd <= 21 (ValueError for even k in the
+ * reference: SSG_E_BADARG); H, W > k / 2; out != img.  Within 2e-6 of the fp64 evaluation for blur kernels (sum 1). */
+int ssg_filter2d(const float *img, const float *kernels, float *out, int B, int C, int H, int W, int k, int n_kernels,
+                 ssg_stream_t stream);
 size_t ssg_usm_scratch_bytes(int B, int C, int H, int W);
 int ssg_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int radius, float sigma, float weight,
                   float threshold, void *scratch, size_t scratch_bytes, ssg_stream_t stream);

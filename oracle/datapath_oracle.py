@@ -96,3 +96,23 @@ def usm_sharp(img, radius=50, sigma=0.0, weight=0.5, threshold=10.0, return_part
     sharp = np.clip(img + weight * residual, 0, 1)
     out = soft * sharp + (1 - soft) * img
     return (out, residual, mask) if return_parts else out
+
+
+def filter2d(img, kernels):
+    """img_process_util.py:7-31 `filter2D`: img (B,C,H,W), kernels (B,k,k) or (1,k,k), k odd; reflect-pad by k//2 and
+    correlate (F.conv2d does not flip) every plane of sample b with kernel b (the shared one).  float64."""
+    img = np.asarray(img, np.float64)
+    kernels = np.asarray(kernels, np.float64)
+    k = kernels.shape[-1]
+    if k % 2 != 1:
+        raise ValueError("Wrong kernel size")
+    r = k // 2
+    B, C, H, W = img.shape
+    p = np.pad(img, ((0, 0), (0, 0), (r, r), (r, r)), mode="reflect")
+    out = np.zeros_like(img)
+    for b in range(B):
+        kb = kernels[0 if kernels.shape[0] == 1 else b]
+        for ky in range(k):
+            for kx in range(k):
+                out[b] += kb[ky, kx] * p[b, :, ky:ky + H, kx:kx + W]
+    return out

@@ -38,6 +38,7 @@ PROTOTYPES = {
                                _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ssg_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ssg_loss_rows_bytes": (_sz, [_i, _i]),
+    "ssg_filter2d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssg_usm_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ssg_usm_sharp": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _sz, _vp]),
     "ssg_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,

@@ -53,6 +53,8 @@ int launch_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C
                         const int *params, hipStream_t st);
 int launch_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, hipStream_t st);
 size_t usm_scratch_bytes(int B, int C, int H, int W);
+int launch_filter2d(const float *img, const float *kernels, float *out, int B, int C, int H, int W, int k, int nk,
+                    hipStream_t st);
 int launch_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int ksize, float sigma, float weight,
                      float threshold, void *scratch, hipStream_t st);
 int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st);
@@ -619,6 +621,15 @@ int ssg_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int 
   if (scratch_bytes < usm_scratch_bytes(B, C, H, W)) return SSG_E_WORKSPACE;
   const int ksize = radius % 2 == 0 ? radius + 1 : radius;   // img_process_util.py:67-68
   const int rc = launch_usm_sharp(img, out, B, C, H, W, ksize, sigma, weight, threshold, scratch, (hipStream_t)stream);
+  return rc == -1 ? SSG_E_BADARG : rc == -4 ? SSG_E_IMAGESMALL : rc;
+}
+
+int ssg_filter2d(const float *img, const float *kernels, float *out, int B, int C, int H, int W, int k, int n_kernels,
+                 ssg_stream_t stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0) return SSG_E_BADARG;
+  if (B == 0) return 0;
+  if (!img || !kernels || !out || img == out) return SSG_E_BADARG;
+  const int rc = launch_filter2d(img, kernels, out, B, C, H, W, k, n_kernels, (hipStream_t)stream);
   return rc == -1 ? SSG_E_BADARG : rc == -4 ? SSG_E_IMAGESMALL : rc;
 }
 

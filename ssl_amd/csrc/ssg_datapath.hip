@@ -259,4 +259,69 @@ int launch_usm_sharp(const float *img, float *out, int B, int C, int H, int W, i
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------ filter2D ----
+// img_process_util.py:7-31 `filter2D`: reflect-pad by k/2, correlate every (b, c) plane with kernel b (or the one shared
+// kernel) -- the blur steps of the degradation chain (realesrganssl_model.py:173,212,245,281,294).  Tile of 16 x 64
+// outputs per workgroup with its halo in LDS, the k x k taps (zero-padded to K x 24) beside it; a thread owns 4
+// consecutive outputs of a row and per tap row reads its K + 3 inputs and the K taps as 16-byte LDS reads: 4 K FMAs
+// per (K + 3) / 2 reads.  K = 9 or 21: a k x k kernel is centred in the next of the two (the extra taps are zero, so
+// the wider reflect halo they see does not matter).
+template <int K>
+__global__ __launch_bounds__(256) void filter2d_kernel(const float *img, const float *kernels, float *out, int C, int H,
+                                                       int W, int k, int nk) {
+  constexpr int TX = 64, TY = 16, R = K / 2, TW = TX + 2 * R, TS = (TW + 3) & ~3, KP = (K + 3 + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float tile[(TY + 2 * R) * TS];
+  __shared__ __attribute__((aligned(16))) float taps[K * KP];
+  const int plane_i = blockIdx.z, b = plane_i / C;
+  const size_t plane = (size_t)plane_i * H * W;
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  const float *kp = kernels + (size_t)(nk == 1 ? 0 : b) * k * k;
+  const int off = (K - k) / 2;
+  for (int i = threadIdx.x; i < K * KP; i += 256) {
+    const int ky = i / KP - off, kx = i % KP - off;
+    taps[i] = (ky >= 0 && ky < k && kx >= 0 && kx < k) ? kp[ky * k + kx] : 0.f;
+  }
+  for (int i = threadIdx.x; i < (TY + 2 * R) * TS; i += 256) {
+    const int ly = i / TS, lx = i - ly * TS;
+    int gy = reflect_idx(ty0 + ly - R, H), gx = reflect_idx(tx0 + lx - R, W);
+    gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);   // (beyond one reflection: only under zero taps or unwritten outputs)
+    gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    tile[i] = img[plane + (size_t)gy * W + gx];
+  }
+  __syncthreads();
+  const int lx = 4 * (threadIdx.x & 15), ly = threadIdx.x >> 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 3
+  for (int ky = 0; ky < K; ++ky) {
+    float v[KP], t[KP];
+    const float4 *rv = (const float4 *)(tile + (ly + ky) * TS + lx), *rt = (const float4 *)(taps + ky * KP);
+#pragma unroll
+    for (int q = 0; q < KP / 4; ++q) {
+      const float4 a = rv[q], c = rt[q];
+      v[4 * q] = a.x, v[4 * q + 1] = a.y, v[4 * q + 2] = a.z, v[4 * q + 3] = a.w;
+      t[4 * q] = c.x, t[4 * q + 1] = c.y, t[4 * q + 2] = c.z, t[4 * q + 3] = c.w;
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(t[kx], v[j + kx], acc[j]);
+  }
+  const int y = ty0 + ly, x = tx0 + lx;
+  if (y < H)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (x + j < W) out[plane + (size_t)y * W + x + j] = acc[j];
+}
+
+int launch_filter2d(const float *img, const float *kernels, float *out, int B, int C, int H, int W, int k, int nk,
+                    hipStream_t st) {
+  if (k < 1 || k > 21 || !(k & 1) || (nk != 1 && nk != B)) return -1;
+  if (H <= k / 2 || W <= k / 2) return -4;
+  if ((size_t)B * C * H * W == 0) return 0;
+  const dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 15) / 16), (unsigned)(B * C));
+  if (k <= 9) hipLaunchKernelGGL((filter2d_kernel<9>), grid, dim3(256), 0, st, img, kernels, out, C, H, W, k, nk);
+  else hipLaunchKernelGGL((filter2d_kernel<21>), grid, dim3(256), 0, st, img, kernels, out, C, H, W, k, nk);
+  return (int)hipGetLastError();
+}
+
 }  // namespace ssg

@@ -141,3 +141,22 @@ class USMSharp(torch.nn.Module):
                                        float(threshold), scratch.data_ptr(), nb, torch.cuda.current_stream().cuda_stream))
         return out.to(img.dtype)
 
+
+@torch.no_grad()
+def filter2D(img, kernel):
+    """basicsr/utils/img_process_util.py:7-31 on the HIP engine (ssg_filter2d): img (b,c,h,w) float32 CUDA, kernel (b,k,k)
+    or (1,k,k), k odd (ValueError otherwise, like the reference) and <= 21."""
+    if not (img.is_cuda and kernel.is_cuda):
+        raise RuntimeError("ssl_amd.datapath.filter2D: tensors must be on the GPU (there is no CPU path)")
+    k = kernel.size(-1)
+    if k % 2 != 1:
+        raise ValueError('Wrong kernel size')
+    x = img.detach().to(torch.float32).contiguous()
+    kk = kernel.detach().to(torch.float32).contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ssg_filter2d(x.data_ptr(), kk.data_ptr(), out.data_ptr(), B, C, H, W, k, kk.size(0),
+                                           torch.cuda.current_stream().cuda_stream))
+    return out.to(img.dtype)
+

@@ -600,8 +600,45 @@ def f12_usm():
     save("f12_usm", **out)
 
 
+def f13_filter2d():
+    """F13: the reference's filter2D (basicsr/utils/img_process_util.py:7-31), imported by path (the
+    module imports cv2 at the top; filter2D itself uses torch only, so an empty stub module suffices) and run on the
+    CPU in fp32 and fp64: per-sample 9 x 9 blur kernels (this fork's padded size, my_realesrgan_image_mask_dataset.py:
+    108-109), per-sample 21 x 21 kernels (Real-ESRGAN's) with a sinc-like sign-changing one among them, one shared
+    7 x 7 kernel, on an image whose sides are not multiples of the tile."""
+    saved = sys.modules.get("cv2")
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    spec = importlib.util.spec_from_file_location("ref_img_process_util2",
+                                                  "/root/reference/GAN-Based-SR/basicsr/utils/img_process_util.py")
+    ipu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ipu)
+    if saved is not None:
+        sys.modules["cv2"] = saved
+    else:
+        del sys.modules["cv2"]
+    rng = np.random.default_rng(1313)
+    img = (np.round(rng.random((3, 3, 45, 83)) * 255) / 255).astype(np.float32)
+    out = dict(img=img)
+
+    def blur(k):
+        a = rng.random((3, k, k)) ** 3
+        return (a / a.sum(axis=(1, 2), keepdims=True)).astype(np.float32)
+
+    k21 = blur(21)
+    yy, xx = np.mgrid[-10:11, -10:11]
+    rr = np.sqrt(yy * yy + xx * xx) + 1e-6
+    sinc = np.sin(1.2 * rr) / rr
+    k21[1] = (sinc / sinc.sum()).astype(np.float32)
+    for tag, kern in (("k9", blur(9)), ("k21", k21), ("k7s", blur(7)[:1])):
+        o32 = ipu.filter2D(torch.as_tensor(img), torch.as_tensor(kern)).numpy()
+        o64 = ipu.filter2D(torch.as_tensor(img).double(), torch.as_tensor(kern).double()).numpy()
+        out["kern_" + tag], out["out32_" + tag], out["out64_" + tag] = kern, o32, o64
+        print("f13", tag, "fp32 vs fp64:", np.abs(o32 - o64).max())
+    save("f13_filter2d", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12"]
+    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     torch.manual_seed(0)
     if "f1" in which:
         f1_c1()
@@ -627,5 +664,7 @@ if __name__ == "__main__":
         f11_datapath()
     if "f12" in which:
         f12_usm()
+    if "f13" in which:
+        f13_filter2d()
     if "time" in which:
         cpu_reference_timing()

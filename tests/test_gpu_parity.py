@@ -1246,3 +1246,29 @@ def test_module_backward_with_two_different_upstream_gradients(dev):
     ref = 2.0 * g_l1 + 3.0 * g_kl
     assert float(ref.abs().max()) > 0
     assert float((g_mixed - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_f13_filter2d_vs_oracle_and_reference(dev, golden):
+    """ssg_filter2d / datapath.filter2D against the reference's fp64 run (fixture F13: 3e-6, the sinc
+    kernel's taps sum to 1 with |taps| summing to ~4) and its fp32 run (both sides round), shared and per-sample
+    kernels, sizes that are not multiples of the tile; refusals: even k (ValueError like the reference), k > 21, image
+    side <= k / 2, in place, CPU tensors."""
+    from ssl_amd import _lib, datapath, engine
+    g = golden("f13_filter2d")
+    x = T(g["img"], dev)
+    for tag in ("k9", "k21", "k7s"):
+        y = datapath.filter2D(x, T(g["kern_" + tag], dev)).cpu().numpy()
+        assert np.abs(y - g["out64_" + tag]).max() <= 3e-6, tag
+        assert np.abs(y - g["out32_" + tag]).max() <= 4e-6, tag
+    with pytest.raises(ValueError):
+        datapath.filter2D(x, torch.ones(1, 4, 4, device=dev))
+    with pytest.raises(RuntimeError):
+        datapath.filter2D(x.cpu(), torch.ones(1, 3, 3))
+    L = _lib.lib()
+    out = torch.empty_like(x)
+    kern = torch.ones(1, 23, 23, device=dev)
+    B, C, H, W = x.shape
+    call = lambda src, dst, k, h: L.ssg_filter2d(engine._ptr(src), engine._ptr(kern), engine._ptr(dst), B, C, h, W, k, 1,
+                                                 engine._stream())
+    assert call(x, out, 23, H) == -1 and call(x, x, 9, H) == -1 and call(x, out, 21, 10) == -4

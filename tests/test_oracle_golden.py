@@ -270,3 +270,14 @@ def test_f12_usm_oracle_vs_reference(golden):
     _close(dp.usm_sharp(g["img"]), g["out32_r50"], 2e-6)
     _close(dp.usm_sharp(g["img"], radius=9, sigma=1.5, weight=0.8, threshold=4), g["out32_r9"], 2e-6)
     assert np.abs(g["out32_r50"] - g["img"]).max() > 0.02   # (the sharpening does something on this input)
+
+
+def test_f13_filter2d_oracle_vs_reference(golden):
+    """filter2D: the numpy restatement against the reference's own function run in fp64 (fixture
+    F13: per-sample 9 x 9 and 21 x 21 kernels, a sign-changing sinc among them, one shared 7 x 7) -- 1e-13."""
+    from oracle import datapath_oracle as dp
+    g = golden("f13_filter2d")
+    for tag in ("k9", "k21", "k7s"):
+        _close(dp.filter2d(g["img"], g["kern_" + tag]), g["out64_" + tag], 1e-13)
+    with pytest.raises(ValueError):
+        dp.filter2d(g["img"], np.ones((1, 4, 4)))
