@@ -281,6 +281,15 @@ int ssg_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slot
  * reference: SSG_E_BADARG); H, W > k / 2; out != img.  Within 2e-6 of the fp64 evaluation for blur kernels (sum 1). */
 int ssg_filter2d(const float *img, const float *kernels, float *out, int B, int C, int H, int W, int k, int n_kernels,
                  ssg_stream_t stream);
+/* DiffJPEG(differentiable=False).forward (basicsr/utils/diffjpeg.py:449-487; realesrganssl_model.py:34,201,240,285,
+ * 290): the JPEG simulation of the degradation chain on (B,3,H,W) fp32 RGB in [0,1] -- zero padding to multiples of
+ * 16, YCbCr, 2x2 chroma average, 8x8 DCT, quantisation with torch.round at factor = quality_to_factor(quality),
+ * inverse path, clamp, crop -- fused into one kernel (one wave per 16x16 macroblock).  quality_dev: B device floats
+ * (the reference's tensor branch), or NULL to use the host scalar `quality` for every sample.  out may alias img.
+ * Floating point: a DCT coefficient whose quotient lies within fp32 rounding of k + 1/2 may round the other way than in
+ * another fp32 implementation (the reference's own included); everywhere else within 3e-6 of the fp64 evaluation. */
+int ssg_diffjpeg(const float *img, float *out, int B, int H, int W, const float *quality_dev, float quality,
+                 ssg_stream_t stream);
 size_t ssg_usm_scratch_bytes(int B, int C, int H, int W);
 int ssg_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int radius, float sigma, float weight,
                   float threshold, void *scratch, size_t scratch_bytes, ssg_stream_t stream);

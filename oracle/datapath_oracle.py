@@ -116,3 +116,61 @@ def filter2d(img, kernels):
             for kx in range(k):
                 out[b] += kb[ky, kx] * p[b, :, ky:ky + H, kx:kx + W]
     return out
+
+
+# ---- DiffJPEG(differentiable=False) (basicsr/utils/diffjpeg.py), float64 with the module's float32 parameters ----
+_JPEG_Y = np.array([[16, 11, 10, 16, 24, 40, 51, 61], [12, 12, 14, 19, 26, 58, 60, 55], [14, 13, 16, 24, 40, 57, 69, 56],
+                    [14, 17, 22, 29, 51, 87, 80, 62], [18, 22, 37, 56, 68, 109, 103, 77], [24, 35, 55, 64, 81, 104, 113, 92],
+                    [49, 64, 78, 87, 103, 121, 120, 101], [72, 92, 95, 98, 112, 100, 103, 99]], np.float32).T   # :14-19
+_JPEG_C = np.full((8, 8), 99, np.float32)                                                                      # :20-23
+_JPEG_C[:4, :4] = np.array([[17, 18, 24, 47], [18, 21, 26, 66], [24, 26, 56, 99], [47, 66, 99, 99]]).T
+
+
+def jpeg_quality_to_factor(quality):
+    """diffjpeg.py:32-46."""
+    quality = 5000. / quality if quality < 50 else 200. - quality * 2
+    return quality / 100.
+
+
+def diffjpeg(x, quality, return_quotients=False):
+    """DiffJPEG(differentiable=False).forward (diffjpeg.py:449-487) on x (B,3,H,W) in [0,1]; quality: scalar or (B,).
+    float64 arithmetic on the module's float32 constants (what `.double()` leaves them as).  return_quotients: also
+    the pre-rounding quotients of every coefficient, (B, Hp, Wp) for Y and (B, Hp/2, Wp/2) x 2 for chroma, so that
+    a caller can see which roundings are decided at fp32."""
+    x = np.asarray(x, np.float64)
+    B, _, H, W = x.shape
+    q = np.broadcast_to(np.asarray(quality, np.float64), (B,))
+    # (the tensor branch evaluates quality_to_factor in float32, :465-466)
+    factor = np.array([np.float32(np.float32(5000.) / np.float32(v)) / np.float32(100.) if v < 50
+                       else np.float32(np.float32(200.) - np.float32(v) * np.float32(2)) / np.float32(100.) for v in q],
+                      np.float64) if np.ndim(quality) else np.full(B, jpeg_quality_to_factor(float(quality)))
+    hp, wp = (16 - H % 16) % 16, (16 - W % 16) % 16
+    img = np.pad(x, ((0, 0), (0, 0), (0, hp), (0, wp))) * 255                                   # :474-480, :232
+    M1 = np.array([[0.299, 0.587, 0.114], [-0.168736, -0.331264, 0.5], [0.5, -0.418688, -0.081312]], np.float32).astype(np.float64)
+    ycc = np.einsum("bchw,jc->bjhw", img, M1) + np.array([0., 128., 128.])[None, :, None, None]  # :52-70
+    Hp, Wp = H + hp, W + wp
+    planes = [ycc[:, 0], ycc[:, 1].reshape(B, Hp // 2, 2, Wp // 2, 2).mean((2, 4)),
+              ycc[:, 2].reshape(B, Hp // 2, 2, Wp // 2, 2).mean((2, 4))]                            # :86-95
+    cosv = np.array([[np.cos((2 * a + 1) * u * np.pi / 16) for u in range(8)] for a in range(8)])
+    T = np.einsum("xu,yv->xyuv", cosv, cosv).astype(np.float32).astype(np.float64)                # :125-128
+    alpha = np.array([1. / np.sqrt(2)] + [1] * 7)
+    scale = (np.outer(alpha, alpha) * 0.25).astype(np.float32).astype(np.float64)                 # :129-131
+    alpha2 = np.outer(alpha, alpha).astype(np.float32).astype(np.float64)                         # :301-302
+    Ti = np.einsum("ux,vy->xyuv", cosv, cosv).astype(np.float32).astype(np.float64)               # :303-306
+    rec, quots = [], []
+    for k, pl in enumerate(planes):
+        h, w = pl.shape[1:]
+        blocks = pl.reshape(B, h // 8, 8, w // 8, 8).transpose(0, 1, 3, 2, 4)                      # :110-118
+        coef = scale * np.einsum("bmnxy,xyuv->bmnuv", blocks - 128, T)                            # :142-145
+        tab = (_JPEG_Y if k == 0 else _JPEG_C).astype(np.float64)[None, None, None] * factor[:, None, None, None, None]
+        quot = coef / tab                                                                          # :163-170
+        quots.append(quot.transpose(0, 1, 3, 2, 4).reshape(B, h, w))
+        deq = np.round(quot) * tab                                                                 # np.round = half to even = torch.round
+        pix = 0.25 * np.einsum("bmnxy,xyuv->bmnuv", deq * alpha2, Ti) + 128                       # :317-321
+        rec.append(pix.transpose(0, 1, 3, 2, 4).reshape(B, h, w))                                  # :338-345
+    up = lambda c: np.repeat(np.repeat(c, 2, axis=1), 2, axis=2)                                   # :362-372
+    ycc2 = np.stack([rec[0], up(rec[1]), up(rec[2])], 1) + np.array([0., -128., -128.])[None, :, None, None]
+    M2 = np.array([[1., 0., 1.402], [1, -0.344136, -0.714136], [1, 1.772, 0]], np.float32).astype(np.float64)
+    rgb = np.clip(np.einsum("bchw,jc->bjhw", ycc2, M2), 0, 255) / 255                             # :394-398, :445-446
+    out = rgb[:, :, :H, :W]
+    return (out, quots) if return_quotients else out

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "ssg_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ssg_loss_rows_bytes": (_sz, [_i, _i]),
     "ssg_filter2d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ssg_diffjpeg": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _vp]),
     "ssg_usm_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ssg_usm_sharp": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _sz, _vp]),
     "ssg_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,

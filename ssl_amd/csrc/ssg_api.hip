@@ -53,6 +53,8 @@ int launch_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C
                         const int *params, hipStream_t st);
 int launch_pool_swap(void *queue, void *batch, size_t sample_bytes, const int *slots, int b, hipStream_t st);
 size_t usm_scratch_bytes(int B, int C, int H, int W);
+int launch_jpeg(const float *img, float *out, int B, int H, int W, const float *quality_dev, float quality_host,
+                hipStream_t st);
 int launch_filter2d(const float *img, const float *kernels, float *out, int B, int C, int H, int W, int k, int nk,
                     hipStream_t st);
 int launch_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int ksize, float sigma, float weight,
@@ -631,6 +633,14 @@ int ssg_filter2d(const float *img, const float *kernels, float *out, int B, int 
   if (!img || !kernels || !out || img == out) return SSG_E_BADARG;
   const int rc = launch_filter2d(img, kernels, out, B, C, H, W, k, n_kernels, (hipStream_t)stream);
   return rc == -1 ? SSG_E_BADARG : rc == -4 ? SSG_E_IMAGESMALL : rc;
+}
+
+int ssg_diffjpeg(const float *img, float *out, int B, int H, int W, const float *quality_dev, float quality,
+                 ssg_stream_t stream) {
+  if (B < 0 || H <= 0 || W <= 0) return SSG_E_BADARG;
+  if (B == 0) return 0;
+  if (!img || !out || (!quality_dev && !(quality > 0.f))) return SSG_E_BADARG;
+  return launch_jpeg(img, out, B, H, W, quality_dev, quality, (hipStream_t)stream);
 }
 
 const char *ssg_kernel_name(int ks, int kw, int backward) {

@@ -324,4 +324,128 @@ int launch_filter2d(const float *img, const float *kernels, float *out, int B, i
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- JPEG ----
+// DiffJPEG(differentiable=False).forward (basicsr/utils/diffjpeg.py:449-487), the JPEG simulation of the degradation
+// chain (realesrganssl_model.py:34,201,240,285,290): zero-pad to multiples of 16, x 255, RGB -> YCbCr (:49-70), 2 x 2
+// chroma average (:73-95), per 8 x 8 block DCT (:121-145), divide by table * factor and torch.round (:148-205),
+// multiply back (:247-294), IDCT (:297-321), chroma repeat (:348-375), YCbCr -> RGB (:378-398), clamp, / 255, crop.
+// One wave per 16 x 16 macroblock (4 luma blocks + Cb + Cr), everything between the load and the store on chip: lane
+// (u, v) holds the 64 basis products cos((2x+1)u pi/16) cos((2y+1)v pi/16) of its coefficient (and the transposed
+// set of its pixel for the inverse) as the reference builds them -- fp64 product rounded to fp32 -- and walks the
+// block through LDS broadcasts.  factor = quality_to_factor(quality[b]) (:32-46) in fp32 like the tensor branch.
+__device__ const double kJpegCos[8][8] = {   // np.cos((2x+1) u pi / 16) [x][u], repr of the doubles numpy computes (diffjpeg.py:127)
+    {1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196023, 0.38268343236508984, 0.19509032201612833},
+    {1.0, 0.8314696123025452, 0.38268343236508984, -0.1950903220161282, -0.7071067811865475, -0.9807852804032304, -0.9238795325112868, -0.5555702330196022},
+    {1.0, 0.5555702330196023, -0.3826834323650897, -0.9807852804032304, -0.7071067811865477, 0.1950903220161283, 0.9238795325112865, 0.8314696123025455},
+    {1.0, 0.19509032201612833, -0.9238795325112867, -0.5555702330196022, 0.7071067811865474, 0.8314696123025455, -0.3826834323650899, -0.9807852804032307},
+    {1.0, -0.1950903220161282, -0.9238795325112868, 0.5555702330196018, 0.7071067811865477, -0.8314696123025451, -0.38268343236509056, 0.9807852804032304},
+    {1.0, -0.555570233019602, -0.38268343236509034, 0.9807852804032304, -0.7071067811865467, -0.19509032201612803, 0.9238795325112867, -0.831469612302545},
+    {1.0, -0.8314696123025453, 0.38268343236509, 0.19509032201612878, -0.7071067811865471, 0.9807852804032307, -0.9238795325112864, 0.5555702330196015},
+    {1.0, -0.9807852804032304, 0.9238795325112865, -0.8314696123025451, 0.7071067811865466, -0.5555702330196015, 0.38268343236508956, -0.19509032201612858}};
+__device__ const float kJpegY[8][8] = {{16, 11, 10, 16, 24, 40, 51, 61},     {12, 12, 14, 19, 26, 58, 60, 55},
+                                       {14, 13, 16, 24, 40, 57, 69, 56},     {14, 17, 22, 29, 51, 87, 80, 62},
+                                       {18, 22, 37, 56, 68, 109, 103, 77},   {24, 35, 55, 64, 81, 104, 113, 92},
+                                       {49, 64, 78, 87, 103, 121, 120, 101}, {72, 92, 95, 98, 112, 100, 103, 99}};
+__device__ const float kJpegC[4][4] = {{17, 18, 24, 47}, {18, 21, 26, 66}, {24, 26, 56, 99}, {47, 66, 99, 99}};
+
+__global__ __launch_bounds__(64) void jpeg_kernel(const float *img, float *out, int H, int W, const float *quality,
+                                                  float quality_host) {
+  __shared__ float blk[6][64];   // 0..3 luma blocks (row-major 2 x 2), 4 Cb, 5 Cr -- pixels, then coefficients, then pixels
+  const int lane = threadIdx.x, u = lane >> 3, v = lane & 7;
+  const int b = blockIdx.z, y0 = 16 * blockIdx.y, x0 = 16 * blockIdx.x;
+  const size_t plane = (size_t)H * W;
+  const float *src = img + (size_t)b * 3 * plane;
+  float q = quality ? quality[b] : quality_host;
+  q = q < 50.f ? 5000.f / q : 200.f - q * 2.f;   // quality_to_factor, fp32 like the tensor branch (diffjpeg.py:465-466)
+  const float factor = q / 100.f;
+  // ---- load 2 x 2 pixels per lane (zero beyond the image: F.pad constant 0), x 255, RGB -> YCbCr, chroma average ----
+  {
+    float cbs = 0.f, crs = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int py = 2 * u + (d >> 1), px = 2 * v + (d & 1), gy = y0 + py, gx = x0 + px;
+      float r = 0.f, g = 0.f, bl = 0.f;
+      if (gy < H && gx < W) {
+        const size_t o = (size_t)gy * W + gx;
+        r = src[o] * 255.f, g = src[plane + o] * 255.f, bl = src[2 * plane + o] * 255.f;
+      }
+      const float yy = (r * 0.299f + g * 0.587f) + bl * 0.114f;   // tensordot over the 3 channels + shift (0,128,128)
+      const float cb = ((r * -0.168736f + g * -0.331264f) + bl * 0.5f) + 128.f;
+      const float cr = ((r * 0.5f + g * -0.418688f) + bl * -0.081312f) + 128.f;
+      blk[2 * (py >> 3) + (px >> 3)][8 * (py & 7) + (px & 7)] = yy;
+      cbs += cb;
+      crs += cr;
+    }
+    blk[4][lane] = cbs * 0.25f;   // avg_pool2d 2 x 2 (exact division by 4)
+    blk[5][lane] = crs * 0.25f;
+  }
+  // basis products of this lane: forward T[x][y] = C[x][u] C[y][v]; inverse T2[i][j] = C[u][i] C[v][j] (lane = pixel)
+  float tf[64], ti[64];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      tf[8 * i + j] = (float)(kJpegCos[i][u] * kJpegCos[j][v]);
+      ti[8 * i + j] = (float)(kJpegCos[u][i] * kJpegCos[v][j]);
+    }
+  const float au = u == 0 ? 0.70710678118654746f : 1.f, av = v == 0 ? 0.70710678118654746f : 1.f;
+  const float scale = (float)((u == 0 ? 0.70710678118654746 : 1.0) * (v == 0 ? 0.70710678118654746 : 1.0) * 0.25);
+  const float alpha = (float)((u == 0 ? 0.70710678118654746 : 1.0) * (v == 0 ? 0.70710678118654746 : 1.0));
+  (void)au; (void)av;
+  __syncthreads();
+  float coef[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) acc = __builtin_fmaf(blk[k][e] - 128.f, tf[e], acc);
+    const float tab = (k < 4 ? kJpegY[v][u] : (u < 4 && v < 4 ? kJpegC[v][u] : 99.f)) * factor;   // tables stored transposed (:19,23)
+    const float qv = rintf((scale * acc) / tab);                                                  // torch.round: half to even
+    coef[k] = (qv * tab) * alpha;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) blk[k][lane] = coef[k];
+  __syncthreads();
+  float pix[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) acc = __builtin_fmaf(blk[k][e], ti[e], acc);
+    pix[k] = 0.25f * acc + 128.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) blk[k][lane] = pix[k];
+  __syncthreads();
+  // ---- chroma repeat, YCbCr -> RGB, clamp, / 255: lane writes its 2 x 2 pixels ----
+  float *dst = out + (size_t)b * 3 * plane;
+  const float cb = blk[4][lane] - 128.f, cr = blk[5][lane] - 128.f;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int py = 2 * u + (d >> 1), px = 2 * v + (d & 1), gy = y0 + py, gx = x0 + px;
+    if (gy >= H || gx >= W) continue;
+    const float yy = blk[2 * (py >> 3) + (px >> 3)][8 * (py & 7) + (px & 7)];
+    float r = (yy * 1.f + cb * 0.f) + cr * 1.402f;
+    float g = (yy * 1.f + cb * -0.344136f) + cr * -0.714136f;
+    float bl = (yy * 1.f + cb * 1.772f) + cr * 0.f;
+    r = fminf(255.f, fmaxf(0.f, r));
+    g = fminf(255.f, fmaxf(0.f, g));
+    bl = fminf(255.f, fmaxf(0.f, bl));
+    const size_t o = (size_t)gy * W + gx;
+    dst[o] = r / 255.f;
+    dst[plane + o] = g / 255.f;
+    dst[2 * plane + o] = bl / 255.f;
+  }
+}
+
+int launch_jpeg(const float *img, float *out, int B, int H, int W, const float *quality_dev, float quality_host,
+                hipStream_t st) {
+  if ((size_t)B * H * W == 0) return 0;
+  const dim3 grid((unsigned)((W + 15) / 16), (unsigned)((H + 15) / 16), (unsigned)B);
+  hipLaunchKernelGGL(jpeg_kernel, grid, dim3(64), 0, st, img, out, H, W, quality_dev, quality_host);
+  return (int)hipGetLastError();
+}
+
 }  // namespace ssg

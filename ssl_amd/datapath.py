@@ -160,3 +160,35 @@ def filter2D(img, kernel):
                                            torch.cuda.current_stream().cuda_stream))
     return out.to(img.dtype)
 
+
+class DiffJPEG(torch.nn.Module):
+    """basicsr/utils/diffjpeg.py:449-487 on the HIP engine (ssg_diffjpeg), non-differentiable rounding only -- the
+    configuration the model uses (`DiffJPEG(differentiable=False)`, realesrganssl_model.py:34).  forward(x, quality):
+    x (B,3,H,W) float32 CUDA in [0,1]; quality a number or a (B,) tensor.  Unlike the reference, a quality tensor is not
+    overwritten with its compression factors."""
+
+    def __init__(self, differentiable=False):
+        super().__init__()
+        if differentiable:
+            raise NotImplementedError("ssl_amd.datapath.DiffJPEG: only differentiable=False (torch.round) is built")
+
+    @torch.no_grad()
+    def forward(self, x, quality):
+        if not x.is_cuda:
+            raise RuntimeError("ssl_amd.datapath.DiffJPEG: tensor must be on the GPU (there is no CPU path)")
+        xi = x.detach().to(torch.float32).contiguous()
+        B, C, H, W = xi.shape
+        if C != 3:
+            raise ValueError("DiffJPEG expects RGB images (B,3,H,W)")
+        out = torch.empty_like(xi)
+        if isinstance(quality, (int, float)):
+            qd, qh = None, float(quality)
+        else:
+            qd, qh = quality.detach().to(device=xi.device, dtype=torch.float32).contiguous(), 0.0
+            if qd.numel() != B:
+                raise ValueError("quality tensor needs one entry per sample")
+        with torch.cuda.device(xi.device):
+            _lib.check(_lib.lib().ssg_diffjpeg(xi.data_ptr(), out.data_ptr(), B, H, W, None if qd is None else qd.data_ptr(),
+                                               qh, torch.cuda.current_stream().cuda_stream))
+        return out.to(x.dtype)
+

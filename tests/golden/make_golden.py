@@ -637,8 +637,27 @@ def f13_filter2d():
     save("f13_filter2d", **out)
 
 
+def f14_diffjpeg():
+    """F14: the reference's DiffJPEG(differentiable=False) (basicsr/utils/diffjpeg.py -- pure torch,
+    imported by path) on a batch whose sides are not multiples of 16, with a per-sample quality tensor (the model's
+    call, realesrganssl_model.py:199-201) and with a scalar quality (fp32 runs)."""
+    spec = importlib.util.spec_from_file_location("ref_diffjpeg", "/root/reference/GAN-Based-SR/basicsr/utils/diffjpeg.py")
+    dj = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dj)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from ssl_amd import synth
+    img = np.stack([synth.natural_like(1400 + i, 40, 52, 0.15, 0.05) for i in range(3)]).astype(np.float32)
+    qual = np.array([30.0, 72.5, 95.0], np.float32)
+    out = dict(img=img, quality=qual)
+    m32 = dj.DiffJPEG(differentiable=False)   # (fp32 only: the quantisers' image.float() rules out a .double() run)
+    with torch.no_grad():
+        out["out32_t"] = m32(torch.as_tensor(img), quality=torch.as_tensor(qual.copy())).numpy()
+        out["out32_s"] = m32(torch.as_tensor(img), quality=50).numpy()
+    save("f14_diffjpeg", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
+    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14"]
     torch.manual_seed(0)
     if "f1" in which:
         f1_c1()
@@ -666,5 +685,7 @@ if __name__ == "__main__":
         f12_usm()
     if "f13" in which:
         f13_filter2d()
+    if "f14" in which:
+        f14_diffjpeg()
     if "time" in which:
         cpu_reference_timing()

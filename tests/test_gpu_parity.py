@@ -1272,3 +1272,40 @@ def test_f13_filter2d_vs_oracle_and_reference(dev, golden):
     call = lambda src, dst, k, h: L.ssg_filter2d(engine._ptr(src), engine._ptr(kern), engine._ptr(dst), B, C, h, W, k, 1,
                                                  engine._stream())
     assert call(x, out, 23, H) == -1 and call(x, x, 9, H) == -1 and call(x, out, 21, 10) == -4
+
+
+@pytest.mark.gpu
+def test_f14_diffjpeg_vs_oracle_and_reference(dev, golden):
+    """ssg_diffjpeg / datapath.DiffJPEG against the fp64 oracle and the reference's own fp32 output
+    (fixture F14: no rounding tie in it, so 3e-6 everywhere), tensor and scalar quality, output aliasing the input;
+    then a 3 x 3 x 100 x 135 random batch where the macroblocks holding a quotient within 2e-4 of k + 1/2 (torch.round
+    not decided at fp32) are left out -- they must be few -- and the rest agrees to 3e-6."""
+    from oracle import datapath_oracle as dp
+    from ssl_amd import _lib, datapath, engine
+    g = golden("f14_diffjpeg")
+    x = T(g["img"], dev)
+    jp = datapath.DiffJPEG(differentiable=False)
+    q = T(g["quality"], dev)
+    y = jp(x, q).cpu().numpy()
+    assert torch.equal(q.cpu(), torch.as_tensor(g["quality"]))          # (not overwritten with the factors)
+    assert np.abs(y - dp.diffjpeg(g["img"], g["quality"])).max() <= 3e-6 and np.abs(y - g["out32_t"]).max() <= 3e-6
+    y = jp(x, 50).cpu().numpy()
+    assert np.abs(y - dp.diffjpeg(g["img"], 50)).max() <= 3e-6 and np.abs(y - g["out32_s"]).max() <= 3e-6
+    x2 = x.clone()
+    _lib.check(_lib.lib().ssg_diffjpeg(engine._ptr(x2), engine._ptr(x2), 3, 40, 52, None, 50.0, engine._stream()))
+    assert np.array_equal(x2.cpu().numpy(), y)
+    rng = np.random.default_rng(14)
+    big = (np.round(rng.random((3, 3, 100, 135)) ** 2 * 255) / 255).astype(np.float32)
+    qual = np.array([15.0, 60.0, 88.0], np.float32)
+    ref, quots = dp.diffjpeg(big, qual, return_quotients=True)
+    yb = jp(T(big, dev), T(qual, dev)).cpu().numpy()
+    tie = np.zeros((3, 112 // 16, 144 // 16), bool)
+    for k, qq in enumerate(quots):
+        near = np.abs(qq - np.floor(qq) - 0.5) < 2e-4
+        s = 16 if k == 0 else 8
+        tie |= near.reshape(3, near.shape[1] // s, s, near.shape[2] // s, s).any((2, 4))
+    keep = ~np.repeat(np.repeat(tie, 16, 1), 16, 2)[:, None, :100, :135]
+    assert tie.mean() < 0.25 and np.abs((yb - ref) * keep).max() <= 3e-6
+    with pytest.raises(NotImplementedError):
+        datapath.DiffJPEG(differentiable=True)
+    assert _lib.lib().ssg_diffjpeg(engine._ptr(x), engine._ptr(x2), 3, 40, 52, None, 0.0, engine._stream()) == -1

@@ -281,3 +281,18 @@ def test_f13_filter2d_oracle_vs_reference(golden):
         _close(dp.filter2d(g["img"], g["kern_" + tag]), g["out64_" + tag], 1e-13)
     with pytest.raises(ValueError):
         dp.filter2d(g["img"], np.ones((1, 4, 4)))
+
+
+def test_f14_diffjpeg_oracle_vs_reference(golden):
+    """DiffJPEG(differentiable=False): the fp64 numpy restatement against the reference's module run
+    in fp32 (fixture F14: per-sample quality tensor 30 / 72.5 / 95 and scalar quality 50, 40 x 52 images -> padded to
+    48 x 64).  No quotient of this input lies within 1e-4 of a rounding boundary, so every torch.round agrees and the
+    outputs differ by fp32 rounding only."""
+    from oracle import datapath_oracle as dp
+    g = golden("f14_diffjpeg")
+    out, quots = dp.diffjpeg(g["img"], g["quality"], return_quotients=True)
+    assert min(np.abs(q - np.floor(q) - 0.5).min() for q in quots) > 1e-4
+    _close(out, g["out32_t"], 1e-6)
+    _close(dp.diffjpeg(g["img"], 50), g["out32_s"], 1e-6)
+    assert np.abs(g["out32_t"][0] - g["img"][0]).max() > 0.02 > np.abs(g["out32_t"][2] - g["img"][2]).mean()
+    assert abs(dp.jpeg_quality_to_factor(20) - 2.5) < 1e-12 and abs(dp.jpeg_quality_to_factor(90) - 0.2) < 1e-12
