@@ -290,22 +290,36 @@ __global__ __launch_bounds__(256) void filter2d_kernel(const float *img, const f
   }
   __syncthreads();
   const int lx = 4 * (threadIdx.x & 15), ly = threadIdx.x >> 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // packed fp32: outputs (0,1) and (2,3) are two register pairs; tap kx multiplies the input pair (kx, kx+1) [+2] --
+  // even kx: the pairs as read, odd kx: the pairs shifted by one input, built once per tap row
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f2v acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
 #pragma unroll 3
   for (int ky = 0; ky < K; ++ky) {
-    float v[KP], t[KP];
+    f2v ve[KP / 2], vo[KP / 2];
+    float t[KP];
     const float4 *rv = (const float4 *)(tile + (ly + ky) * TS + lx), *rt = (const float4 *)(taps + ky * KP);
 #pragma unroll
     for (int q = 0; q < KP / 4; ++q) {
       const float4 a = rv[q], c = rt[q];
-      v[4 * q] = a.x, v[4 * q + 1] = a.y, v[4 * q + 2] = a.z, v[4 * q + 3] = a.w;
+      ve[2 * q] = f2v{a.x, a.y}, ve[2 * q + 1] = f2v{a.z, a.w};
       t[4 * q] = c.x, t[4 * q + 1] = c.y, t[4 * q + 2] = c.z, t[4 * q + 3] = c.w;
     }
 #pragma unroll
-    for (int kx = 0; kx < K; ++kx)
+    for (int m = 0; m + 1 < KP / 2; ++m) vo[m] = f2v{ve[m].y, ve[m + 1].x};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(t[kx], v[j + kx], acc[j]);
+    for (int kx = 0; kx < K; ++kx) {
+      const f2v tt = {t[kx], t[kx]};
+      if (kx % 2 == 0) {
+        acc01 = __builtin_elementwise_fma(tt, ve[kx / 2], acc01);
+        acc23 = __builtin_elementwise_fma(tt, ve[kx / 2 + 1], acc23);
+      } else {
+        acc01 = __builtin_elementwise_fma(tt, vo[kx / 2], acc01);
+        acc23 = __builtin_elementwise_fma(tt, vo[kx / 2 + 1], acc23);
+      }
+    }
   }
+  const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
   const int y = ty0 + ly, x = tx0 + lx;
   if (y < H)
 #pragma unroll
