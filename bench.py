@@ -278,8 +278,8 @@ def make_inputs(cfg, rank, world, scaling):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 16 images per GPU; strong: the 16 images split over the GPUs (SURVEY 8e)")
