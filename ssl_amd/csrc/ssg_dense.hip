@@ -159,10 +159,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int which = blockIdx.x / p.max_tiles, tslot = blockIdx.x - which * p.max_tiles;
-  if (tslot >= *p.n_dense) return;
+  if (tslot >= dense_tile_count(p.n_dense)) return;
   const int H = p.H, W = p.W;
   const int tx_n = (W + DT_X - 1) / DT_X, ty_n = (H + DT_Y - 1) / DT_Y;
-  const int tile = p.tiles[tslot];
+  const int tile = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
   const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
   const int ty0 = (tr / tx_n) * DT_Y, tx0 = (tr % tx_n) * DT_X;
   const int nrows = rows_to_do(p.n_dev, p.n_host);

@@ -189,7 +189,7 @@ __device__ __forceinline__ int super_tile_of(int b, int y, int x, int H, int W, 
 
 
 // one wave per super-tile: count its edge pixels (rank map), flag it dense at >= thr and append it to the dense
-// list (plan[1] = count, zeroed by edge_scan)
+// list (plan[1] / plan[3] = counts of heavy / light tiles, zeroed by edge_scan)
 __global__ __launch_bounds__(256) void plan_count(const int *rank, int B, int H, int W, int sty, int thr, int *dflag,
                                                   int *plan, int *dense_ids) {
   const int sx_n = (W + 31) / 32, sy_n = (H + sty - 1) / sty;
@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void plan_count(const int *rank, int B, int H,
   if (lane == 0) {
     const int dense = thr > 0 && n >= thr;
     dflag[st] = dense;
-    if (dense) dense_ids[atomicAdd(&plan[1], 1)] = st;
+    if (dense) {   // heavy tiles from the front, light ones from the back (dense_tile_at, ssg_common.hpp)
+      if (n > 64) dense_ids[atomicAdd(&plan[1], 1)] = st;
+      else dense_ids[B * sy_n * sx_n - 1 - atomicAdd(&plan[3], 1)] = st;
+    }
     if (st == 0) plan[2] = sty;
   }
 }
@@ -347,7 +350,7 @@ size_t edge_scratch_bytes(int B, int H, int W) {
   return (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64;
 }
 
-// forward plan: [0] n_sparse, [1] n_dense, [2..3] -, [4, 4+ns) the dense kernel's super-tile ids (ns =
+// forward plan: [0] n_sparse, [1] n_heavy, [2] tile rows, [3] n_light, [4, 4+ns) the dense kernels' super-tile ids (heavy from the front, light from the back; ns =
 // n_super_tiles), then (capacity) the tile-major order of the rows left to the direct kernels
 int fwd_plan_order_offset(int B, int H, int W) { return 4 + (int)n_super_tiles(B, H, W); }
 

@@ -11,7 +11,7 @@ for dens in (0.16, 0.3, 0.5, 1.0):
     m = (rng.random((4, 1, 256, 256)) < dens).astype(np.float32)
     sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, m))
     el = engine.edge_list(mask=mask)
-    n = int(el.counts[0]); nd = int(el.plan[1])
+    n = int(el.counts[0]); nd = int(el.plan[1]) + int(el.plan[3])
     L = _lib.lib(); P = engine._ptr
     s1 = torch.empty((n, 625), device=dev); s2 = torch.empty((n, 625), device=dev)
     def f():
