@@ -242,26 +242,36 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // tiles that overhang a small image are never used, but must stay in bounds) ----
   {
     const float *src = p.img[which] + (size_t)b * C * H * W;
-    constexpr int CPLF = (RWD + 15) / 16;    // 16 lanes per row, CPLF consecutive pixels each
+    // 16 lanes per region row, lane lx takes columns lx, lx + 16, ... (neighbouring lanes read neighbouring pixels);
+    // two row passes are loaded before the first is stored, so that a workgroup pays the L2 latency ~6 instead of
+    // ~11 times in a row
+    constexpr int CPLF = (RWD + 15) / 16, RPP = NT / 16;
     const int lx = tid % 16, lr = tid / 16;
-    for (int R0 = 0; R0 < C * RH; R0 += NT / 16) {
-      const int R = R0 + lr;
-      if (R < C * RH) {
-        const int c = R / RH, ry = R - c * RH;
+    for (int R0 = 0; R0 < C * RH; R0 += 2 * RPP) {
+      float v[2][CPLF];
+      int dst[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int R = R0 + h * RPP + lr;
+        const bool on = R < C * RH;
+        const int Rc = on ? R : 0;
+        const int c = Rc / RH, ry = Rc - c * RH;
         int gy = reflect_idx(ty0 - HALO + ry, H);
         gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
         const float *srow = src + ((size_t)c * H + gy) * W;
-        float v[CPLF];
+        dst[h] = on ? (c * RH + ry) * RS : -1;
 #pragma unroll
         for (int k = 0; k < CPLF; ++k) {
-          int gx = reflect_idx(tx0 - HALO + lx * CPLF + k, W);
+          int gx = reflect_idx(tx0 - HALO + lx + 16 * k, W);
           gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-          v[k] = srow[gx];
+          v[h][k] = srow[gx];
         }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int k = 0; k < CPLF; ++k)
-          if (lx * CPLF + k < RWD) reg[(c * RH + ry) * RS + lx * CPLF + k] = v[k];
-      }
+          if (dst[h] >= 0 && lx + 16 * k < RWD) reg[dst[h] + lx + 16 * k] = v[h][k];
     }
   }
   __syncthreads();
