@@ -157,7 +157,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
 
     f_edges()
     torch.cuda.synchronize()
-    out = {"edge_list+order+plan (13 launches)": event_time_ms(f_edges, iters)}
+    out = {"edge_list+order+plan (12 launches)": event_time_ms(f_edges, iters)}
     f_fwd()
     f_bwd()
     torch.cuda.synchronize()

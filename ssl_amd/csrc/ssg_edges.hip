@@ -191,17 +191,39 @@ __device__ __forceinline__ int super_tile_of(int b, int y, int x, int H, int W, 
 // one wave per super-tile: count its edge pixels (rank map), flag it dense at >= thr and append it to the dense
 // list (plan[1] / plan[3] = counts of heavy / light tiles, zeroed by edge_scan)
 __global__ __launch_bounds__(256) void plan_count(const int *rank, int B, int H, int W, int sty, int thr, int *dflag,
-                                                  int *plan, int *dense_ids) {
+                                                  int *plan, int *dense_ids, int *tcnt) {
   const int sx_n = (W + 31) / 32, sy_n = (H + sty - 1) / sty;
   const int st = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (st >= B * sy_n * sx_n) return;
   const int b = st / (sy_n * sx_n), t = st - b * sy_n * sx_n;
   const int y0 = (t / sx_n) * sty, x0 = (t % sx_n) * 32;
   int n = 0;
-  for (int i = lane; i < sty * 32; i += 64) {
-    const int y = y0 + i / 32, x = x0 + i % 32;
-    const bool on = y < H && x < W && rank[((size_t)b * H + y) * W + x] >= 0;
-    n += __popcll(__ballot(on));
+  if (sty == OT) {
+    // 8-row super-tiles are four 8 x 8 order tiles side by side: chunk k of the wave IS order tile k, so the same
+    // four loads (all in flight together) also give tile_count_sparse's counts -- one launch less
+    bool on[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = y0 + lane / OT, x = x0 + OT * k + lane % OT;
+      on[k] = y < H && x < W && rank[((size_t)b * H + y) * W + x] >= 0;
+    }
+    int cnt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cnt[k] = __popcll(__ballot(on[k]));
+      n += cnt[k];
+    }
+    const int dense = thr > 0 && n >= thr;
+    if (tcnt && lane < 4) {
+      const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT, tx = x0 / OT + lane;
+      if (tx < tx_n) tcnt[(b * ty_n + y0 / OT) * tx_n + tx] = dense ? 0 : cnt[lane];   // (cnt[lane]: 4 selects)
+    }
+  } else {
+    for (int i = lane; i < sty * 32; i += 64) {
+      const int y = y0 + i / 32, x = x0 + i % 32;
+      const bool on = y < H && x < W && rank[((size_t)b * H + y) * W + x] >= 0;
+      n += __popcll(__ballot(on));
+    }
   }
   if (lane == 0) {
     const int dense = thr > 0 && n >= thr;
@@ -389,8 +411,9 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
     const int ns_max = (int)n_super_tiles(B, H, W), ns = B * ((H + sty - 1) / sty) * ((W + 31) / 32);
     int *dflag = toff + nt, *order2 = plan + 4 + ns_max;
     hipLaunchKernelGGL(plan_count, dim3((ns + 3) / 4), dim3(256), 0, st, rank, B, H, W, sty, dense_thr, dflag, plan,
-                       plan + 4);
-    hipLaunchKernelGGL(tile_count_sparse, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, sty, dflag, tcnt);
+                       plan + 4, sty == OT ? tcnt : nullptr);
+    if (sty != OT)   // (8-row super-tiles: plan_count has counted the order tiles as well)
+      hipLaunchKernelGGL(tile_count_sparse, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, sty, dflag, tcnt);
     hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, plan);
     hipLaunchKernelGGL(tile_scatter, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, toff, order2, capacity, dflag,
                        sty);
