@@ -1309,3 +1309,68 @@ def test_f14_diffjpeg_vs_oracle_and_reference(dev, golden):
     with pytest.raises(NotImplementedError):
         datapath.DiffJPEG(differentiable=True)
     assert _lib.lib().ssg_diffjpeg(engine._ptr(x), engine._ptr(x2), 3, 40, 52, None, 0.0, engine._stream()) == -1
+
+
+@pytest.mark.gpu
+def test_datapath_kernels_at_their_size_limits(dev):
+    """USM / filter2D / JPEG at the smallest legal sizes and on exact tile multiples, against the fp64 oracle: reflect
+    halos as wide as the image allows, single-plane batches, images smaller than one JPEG macroblock, a quality
+    tensor straddling 50 (the two branches of quality_to_factor)."""
+    from oracle import datapath_oracle as dp
+    from ssl_amd import datapath
+    rng = np.random.default_rng(41)
+    q8 = lambda *s: (np.round(rng.random(s) * 255) / 255).astype(np.float32)
+    # USM: sides radius/2 + 1 = 26 (every halo pixel is a reflection) and an exact 64 x 128 tile multiple
+    for shape in ((1, 1, 26, 26), (2, 3, 64, 128)):
+        x = q8(*shape)
+        ref, res, _ = dp.usm_sharp(x, return_parts=True)
+        tie = (np.abs(np.abs(res) * 255 - 10) < 1e-3).sum()
+        y = datapath.USMSharp()(T(x, dev)).cpu().numpy()
+        assert np.abs(y - ref).max() <= 2e-6 + 0.004 * tie and tie < 10, shape
+    # filter2D: k = 21 on an 11 x 11 image (pad 10 < 11), k = 3 and k = 1
+    for shape, k, nk in (((2, 1, 11, 11), 21, 2), ((1, 3, 9, 70), 3, 1), ((2, 2, 5, 5), 1, 2)):
+        x = q8(*shape)
+        kern = rng.random((nk, k, k)).astype(np.float32)
+        kern /= kern.sum(axis=(1, 2), keepdims=True)
+        y = datapath.filter2D(T(x, dev), T(kern, dev)).cpu().numpy()
+        assert np.abs(y - dp.filter2d(x, kern)).max() <= 3e-6, (shape, k)
+    # JPEG: smaller than a macroblock, exact multiples of 16, qualities on both sides of 50 and exactly 50
+    for shape, qual in (((3, 3, 7, 5), [10.0, 50.0, 99.0]), ((2, 3, 32, 48), [49.0, 51.0])):
+        x = q8(*shape)
+        qv = np.asarray(qual, np.float32)
+        ref, quots = dp.diffjpeg(x, qv, return_quotients=True)
+        y = datapath.DiffJPEG()(T(x, dev), T(qv, dev)).cpu().numpy()
+        Hp, Wp = quots[0].shape[1:]
+        tie = np.zeros((shape[0], Hp // 16, Wp // 16), bool)
+        for kq, qq in enumerate(quots):
+            s = 16 if kq == 0 else 8
+            near = np.abs(qq - np.floor(qq) - 0.5) < 2e-4
+            tie |= near.reshape(shape[0], Hp // 16, s, Wp // 16, s).any((2, 4))
+        keep = ~np.repeat(np.repeat(tie, 16, 1), 16, 2)[:, None, :shape[2], :shape[3]]
+        assert np.abs((y - ref) * keep).max() <= 3e-6 and tie.mean() < 0.3, shape
+
+
+@pytest.mark.gpu
+def test_fused_module_mask_kinds_and_empty_batch(dev):
+    """SSGLoss (fused forward) with float, uint8, bool and 3-channel masks gives the same losses and gradients, and
+    an all-empty mask gives (0, 0) with a zero gradient (ddpmssl.py:492-493)."""
+    from ssl_amd import SSGLoss, synth
+    gt = np.stack([synth.natural_like(510 + i, 48, 64) for i in range(2)])
+    sr = np.stack([synth.degrade(gt[i], 520 + i) for i in range(2)])
+    m = np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(2)])[:, None]
+    crit = SSGLoss(11, 5, 0.05, True, 1e3, 1e3, deterministic=True)
+
+    def run(mask):
+        x = T(sr, dev).requires_grad_(True)
+        a, b = crit(x, T(gt, dev), mask)
+        (a + b).backward()
+        return float(a), float(b), x.grad.clone()
+
+    base = run(T(m.astype(np.float32), dev))
+    assert base[0] > 0 and float(base[2].abs().max()) > 0
+    for mk in (T(m.astype(np.uint8), dev), T(m.astype(np.uint8), dev).bool(),
+               T(np.repeat(m, 3, axis=1).astype(np.float32), dev)):
+        r = run(mk)
+        assert r[0] == base[0] and r[1] == base[1] and torch.equal(r[2], base[2])
+    z = run(torch.zeros(2, 1, 48, 64, device=dev))
+    assert z[0] == 0.0 and z[1] == 0.0 and float(z[2].abs().max()) == 0.0
