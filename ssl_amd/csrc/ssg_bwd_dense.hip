@@ -41,6 +41,33 @@ __device__ __forceinline__ float dpp_row_shr(float v) {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// Window sums out[i] = v[lo + i] + ... + v[hi + i], i < N, of a register array: the first one explicitly, the others
+// by sliding (out[i+1] = out[i] - v[lo+i] + v[hi+1+i]) when that is fewer operations.  G is signed, so unlike the
+// forward's sums of non-negative terms nothing is lost by subtracting: the error stays a few ulps of the partial sums
+// either way (measured by the F10 gradient tests).
+template <int N, int LO, int HI, int NV>
+__device__ __forceinline__ void window_sums(const float (&v)[NV], float (&out)[N]) {
+  static_assert(LO >= 0 && HI >= LO && HI + N - 1 < NV, "windows inside the array");
+  constexpr int Wd = HI - LO + 1;
+  if constexpr (Wd + 2 * (N - 1) - 1 < N * (Wd - 1)) {
+    float t = v[LO];
+#pragma unroll
+    for (int m = LO + 1; m <= HI; ++m) t += v[m];
+    out[0] = t;
+#pragma unroll
+    for (int i = 1; i < N; ++i) out[i] = (out[i - 1] - v[LO + i - 1]) + v[HI + i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float t = v[LO + i];
+#pragma unroll
+      for (int m = LO + i + 1; m <= HI + i; ++m) t += v[m];
+      out[i] = t;
+    }
+  }
+}
+
+
 // Inclusive prefix over 8 tile rows held 2 lanes apart in a 16-lane DPP row, for 5 values at once: 15 in-place DPP
 // adds (a lane whose source lies outside its row keeps its value).  The leading s_nop covers the VALU-write ->
 // DPP-read wait states the assembler does not insert for inline asm; inside the block 4 instructions separate a
@@ -224,13 +251,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
 #pragma unroll
     for (int m = M0; m <= M1; ++m) v[m] = f[hsrc + m];
     float out[HOUT];
-#pragma unroll
-    for (int i = 0; i < HOUT; ++i) {
-      float t = v[i + HK - XHI];
-#pragma unroll
-      for (int m = i + HK - XHI + 1; m <= i + HK - XLO; ++m) t += v[m];
-      out[i] = t;
-    }
+    window_sums<HOUT, HK - XHI, HK - XLO>(v, out);
     // inclusive prefix over the tile rows (adjacent lanes); the 0/1 factors stop a row group from reading
     // its neighbour's lanes
     if constexpr (REGW && HOUT == 5) {
@@ -505,13 +526,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       }
       // ---- next offset: horizontal sums over its column taps, vertical prefix ----
       float out[HOUT];
-#pragma unroll
-      for (int i = 0; i < HOUT; ++i) {
-        float t = v[i + HK - nhi];
-#pragma unroll
-        for (int m = i + HK - nhi + 1; m <= i + HK - nlo; ++m) t += v[m];
-        out[i] = t;
-      }
+      window_sums<HOUT, HK - nhi, HK - nlo>(v, out);
       if constexpr (REGW && HOUT == 5) {
         dpp_prefix8x5(out);
       } else {
