@@ -18,12 +18,16 @@ k_s = 49, k_w = 13 (one image per GPU).
 Prints ONE JSON line (rank 0) with the driver's fields plus
   roofline      for the dominant kernel: algorithmic HBM bytes of the step (8 k_s^2 + (12C+4) HW/N per
                 edge pixel) x edge pixels per launch / that kernel's mean duration, measured here with HIP events
-                on the launch stream while the step's other launches are masked out (ssg_set_profile_mask);
+                on the launch stream while the step's other launches are masked out (ssg_set_profile_mask of the profiling build
+                libssg_hip_prof.so -- the product library has no such switch);
                 `kernel_ms` lists every kernel of the step measured that way (each ALONE on the chip: inside the
                 step the direct kernel of a pass runs on a side stream beside the dense one for k_s <= 25, so the
                 step is shorter than their sum; profiles/*_kernel_stats.csv is taken with SSG_OVERLAP=0 for the
                 same reason), `step` repeats the figure over the whole step's GPU time, `valu` prices the same
                 time against the fp32 vector peak.
+  extra         (N = 1, default config only) the other lines a reader wants next to the headline, measured in the same
+                process: C5 materialised, C2 fused (no SSG output), C5 fused -- each with ITS OWN algorithmic bytes
+                (B_alg = 8 k_s^2 + (12C+4)HW/N, fused B_alg' = (12C+4)HW/N; the two are never mixed).
   module        the same step through the drop-in nn.Module (ssl_amd.SSGLoss: autograd forward + backward).
   cpu_baseline  the C/OpenMP oracle ("port") on the host cores over a bounded sample of the same workload
                 (rank 0, N = 1 only).
@@ -120,7 +124,9 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     # geometry and kernel sizes come from the LossStep itself (`cfg` is kept for callers that pass it)
     _, _, H, W = step.shape
     KS, KW, SIGMA = step.cfg[0], step.cfg[1], step.cfg[2]
-    L = _lib.lib()
+    # the PROFILING build of the library (libssg_hip_prof.so, -DSSG_PROFILE): the only one that can mask launches out;
+    # same kernels, same launch code -- the timed step of main() runs on the product library
+    L = _lib.lib_prof()
     st = torch.cuda.current_stream().cuda_stream
     B = sr.shape[0]
     edges = step.edges()
@@ -190,6 +196,7 @@ def module_time_ms(cfg, sr, gt, mask, n_edges, iters):
         (a + b).backward()
 
     one()
+    one()          # (the module reads the edge count back in its first two calls, SSGLoss sync_checks: not timed)
     torch.cuda.synchronize()
     return event_time_ms(one, iters)
 
@@ -226,37 +233,105 @@ def cpu_baseline(cfg, sr, gt, mask, budget_s=20.0):
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/pmc_traffic.json, produced by
-    tools/r2_final.sh with the guide's unit / gfx950 corrections); None if there is no entry for this kernel."""
+    tools/r*_final.sh with the guide's unit / gfx950 corrections); None if there is no entry for this kernel."""
+    e = pmc_entry(kernel_name)
+    return e.get("hbm_bytes_per_launch") if e else None
+
+
+VALU_CYCLES_PER_INST = 2.0   # MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues over 2 cycles (v_pk_*: 4)
+N_SIMD, N_CU, CLOCK_HZ = 1024, 256, 2.4e9
+
+
+def pmc_entry(kernel_name):
+    """The committed PMC record of a kernel (profiles/pmc_traffic.json) or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
         key = kernel_name.replace(" ", "")
         for k, v in t.get("kernels", {}).items():
             if k == key or k.startswith(key.rstrip(">") + ","):    # ssg_bwd_dense<25,9,3> ~ ssg_bwd_dense<25,9,3,8,2,8>
-                return v.get("hbm_bytes_per_launch")
+                return v
     except (OSError, ValueError):
         pass
     return None
 
 
+def binding_resource(kernel_name, kernel_ms):
+    """Which resource the dominant kernel keeps busiest, from its committed counters priced against the duration
+    measured here: HBM (PMC bytes / 8 TB/s), VALU issue (SQ_INSTS_VALU x 2 cycles on 1024 SIMDs: a LOWER bound, packed
+    instructions hold the pipe 4 cycles), LDS (SQ_LDS_IDX_ACTIVE summed over the CUs / 256)."""
+    e = pmc_entry(kernel_name)
+    if not e or kernel_ms <= 0:
+        return "hbm", None
+    t = kernel_ms * 1e-3
+    fr = {"hbm": e.get("hbm_bytes_per_launch", 0.0) / t / (HBM_PEAK_GBS * 1e9),
+          "valu": e.get("valu_insts_per_launch", 0.0) * VALU_CYCLES_PER_INST / N_SIMD / CLOCK_HZ / t,
+          "lds": e.get("lds_active_cycles_per_launch", 0.0) / N_CU / CLOCK_HZ / t}
+    bound = max(fr, key=fr.get)
+    return bound, {"busy_fraction_of_kernel_time": fr,
+                   "how": "profiles/pmc_traffic.json counters of this kernel / the duration measured here; hbm = PMC "
+                          "bytes at 8 TB/s, valu = SQ_INSTS_VALU x 2 cycles / 1024 SIMDs at 2.4 GHz (lower bound: "
+                          "v_pk_* take 4), lds = SQ_LDS_IDX_ACTIVE / 256 CUs at 2.4 GHz"}
+
+
 def pmc_issue(config_key, step_gpu_ms):
     """Issued VALU wave-instructions and LDS-active cycles of one step from the committed SQ passes (profiles/
     pmc_traffic.json: SQ_INSTS_VALU / SQ_LDS_IDX_ACTIVE per launch, summed over the step's kernels), priced against
-    the step's GPU time measured here: a wave64 VALU instruction holds its SIMD for 4 cycles, 1024 SIMDs at 2.4 GHz."""
+    the step's GPU time measured here: a wave64 VALU instruction holds its SIMD-32 for 2 cycles (packed fp32: 4, so
+    the VALU figure is a lower bound), 1024 SIMDs at 2.4 GHz."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ks = [k for k in json.load(f).get("kernels", {}).values() if k.get("config") == config_key]
         insts = sum(k.get("valu_insts_per_launch", 0.0) for k in ks)
         lds = sum(k.get("lds_active_cycles_per_launch", 0.0) for k in ks)
+        hbm = sum(k.get("hbm_bytes_per_launch", 0.0) for k in ks)
         if not insts:
             return None
-        valu_ms = insts * 4.0 / (256 * 4) / 2.4e9 * 1e3
-        lds_ms = lds / 256 / 2.4e9 * 1e3
-        return {"valu_wave_insts_per_step": insts, "valu_issue_ms": valu_ms, "valu_issue_frac_of_step": valu_ms / step_gpu_ms,
+        valu_ms = insts * VALU_CYCLES_PER_INST / N_SIMD / CLOCK_HZ * 1e3
+        lds_ms = lds / N_CU / CLOCK_HZ * 1e3
+        hbm_ms = hbm / (HBM_PEAK_GBS * 1e9) * 1e3
+        return {"valu_wave_insts_per_step": insts, "valu_issue_ms_lower_bound": valu_ms,
+                "valu_issue_frac_of_step": valu_ms / step_gpu_ms,
                 "lds_active_ms_per_cu": lds_ms, "lds_active_frac_of_step": lds_ms / step_gpu_ms,
-                "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_LDS_IDX_ACTIVE, tools/r2_final.sh)"}
+                "hbm_bytes_per_step": hbm, "hbm_ms_at_peak": hbm_ms, "hbm_frac_of_step": hbm_ms / step_gpu_ms,
+                "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_LDS_IDX_ACTIVE / FETCH_SIZE / "
+                          "WRITE_SIZE, one pass each)"}
     except (OSError, ValueError):
         return None
+
+
+def extra_line(cfg_key, fused, dev, steps, warmup):
+    """One more (config, mode) measured in the same process for the driver's JSON line: wall-clock over `steps` steps
+    between two synchronisations, its own algorithmic bytes (materialised B_alg = 8 k_s^2 + (12C+4)HW/N,
+    fused B_alg' = (12C+4)HW/N -- never mixed)."""
+    import torch
+    from ssl_amd import engine
+    cfg = CONFIGS[cfg_key]
+    sr_np, gt_np, mask_np = make_inputs(cfg, 0, 1, "weak")
+    n = int(mask_np.sum())
+    B = sr_np.shape[0]
+    sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
+    step = engine.LossStep(B, C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1, W_KL,
+                           device=dev, capacity=n + 1024, materialise=not fused)
+    for _ in range(warmup):
+        step(sr, gt, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(sr, gt, mask)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    assert int(step.counts[0]) == n
+    loss = step.loss.cpu().numpy()
+    b_alg = alg_bytes_per_edge_px(cfg, n, B) - (8.0 * cfg["ks"] ** 2 if fused else 0.0)
+    ach = b_alg * n / (ms * 1e-3) / 1e9
+    del step, sr, gt, mask
+    torch.cuda.empty_cache()
+    return {"workload": cfg["name"].replace("SSGs materialised", "fused step: no SSG output") if fused else cfg["name"],
+            "ms_per_step": ms, "value": n / (ms * 1e-3), "unit": "edge-px/s", "steps": steps, "warmup": warmup,
+            "edge_px": n, "l1": float(loss[0]), "kl": float(loss[1]),
+            "roofline": {"step": {"alg_bytes_per_edge_px": b_alg, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": ach / HBM_PEAK_GBS}}}
 
 
 def make_inputs(cfg, rank, world, scaling):
@@ -285,6 +360,7 @@ def main():
                     help="weak: 16 images per GPU; strong: the 16 images split over the GPUs (SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-module", action="store_true", help="skip the SSGLoss (nn.Module) timing")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` block (C5 and the fused steps)")
     ap.add_argument("--no-ssg-output", action="store_true",
                     help="the fused step of the C ABI (ssg_sr = ssg_gt = NULL): a SEPARATE metric with SURVEY 8d's "
                          "B_alg' = (12C+4)HW/N -- not comparable with the default line")
@@ -408,21 +484,32 @@ def main():
             ach = b_alg * n_edges / (stages[dom] * 1e-3) / 1e9
             ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
             tflops = alg_flops_per_edge_px(cfg) * n_edges / (step_gpu_ms * 1e-3) / 1e12
+            bound, evidence = binding_resource(dom, stages[dom])
             res["roofline"] = {
-                "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # `achieved / peak / frac` are the HBM figures BASELINE.json's metric asks for (algorithmic bytes of the
+                # step over the dominant kernel's duration); `bound` names the resource that kernel actually keeps
+                # busiest by its counters -- "hbm", "valu" or "lds" (no MFMA on this path) -- see `bound_evidence`
+                "bound": bound, "bound_evidence": evidence,
+                "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "alg_bytes_per_edge_px": b_alg,
                 "kernel_ms": stages,
                 "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS},
-                "valu": {"achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP32_PEAK_TFLOPS, "alg_flops_per_edge_px": alg_flops_per_edge_px(cfg),
+                "valu": {"reference_equivalent_tflops": tflops, "fp32_vector_peak_tflops": FP32_PEAK_TFLOPS,
+                         "alg_flops_per_edge_px": alg_flops_per_edge_px(cfg),
                          "note": "SURVEY's DIRECT flop count over the step's GPU time; the dense-tile kernels do "
-                                 "fewer real flops, so this is throughput in reference-equivalent flops, not "
-                                 "VALU utilisation (`issued` has the instructions actually issued)",
+                                 "~10x fewer real flops per (pixel, offset), so this is throughput in "
+                                 "reference-equivalent flops and may exceed the peak -- NOT a utilisation "
+                                 "(`issued` prices the instructions actually issued)",
                          "issued": pmc_issue(args.config, step_gpu_ms)}}
             if not args.no_module and not args.no_ssg_output:
                 mm = module_time_ms(cfg, sr, gt, mask, n_edges, it)
                 res["module"] = {"what": "ssl_amd.SSGLoss forward + autograd backward (drop-in path)",
                                  "ms_per_step": mm, "value": n_edges / (mm * 1e-3), "unit": "edge-px/s"}
+            if world == 1 and not args.no_extra and args.config == "c2" and not args.no_ssg_output:
+                # the other configuration / mode lines, driver-visible (about 2 s of GPU time in all)
+                res["extra"] = {"c5": extra_line("c5", False, dev, 10, 3),
+                                "c2_fused": extra_line("c2", True, dev, 30, 5),
+                                "c5_fused": extra_line("c5", True, dev, 10, 3)}
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg, sr_np, gt_np, mask_np)
                 res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]

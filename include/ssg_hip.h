@@ -132,7 +132,12 @@ size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
 int ssg_set_dense_threshold(int edge_pixels_per_tile);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int H, int W, int mask_stride, float lap_threshold,
-                  int plan_ks /* k_s the fwd_plan is built for (tile rows: 8, or 4 for k_s = 49); 0 = 25 */,
+                  int plan_ks /* k_s the fwd_plan is built for (tile rows: 8, or 4 for k_s = 49); 0 = 25.
+                               * CONSTRAINT: a plan is only valid for calls whose k_s uses the same tile height --
+                               * the plan records it (fwd_plan[2]) and the dense kernels of ssg_map_forward /
+                               * ssg_map_backward / ssg_loss_backward trap (launch failure at the next sync)
+                               * when it differs from theirs, instead of decoding tile ids with the wrong
+                               * geometry.  ssg_loss_fwd_bwd builds its own plan and cannot get this wrong. */,
                   int *edges, int capacity, int *counts,
                   int *rank_map /* nullable */, int *tile_order /* nullable */,
                   int *fwd_plan /* nullable */, void *scratch,
@@ -189,7 +194,7 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W,
  * from run to run (as with the reference's atomicAdd, similarity.cu:123-128).  Passing `grad_fix` --
  * ssg_grad_fix_bytes(B,C,H,W) bytes of device memory, contents irrelevant -- to the backward entry points makes
  * the result bit-reproducible: contributions are rounded to multiples of a power of two chosen on the device
- * from the largest |dL/dD| of the call (2^-38 of it: 14 bits finer than an fp32 sum of the same terms) and summed
+ * from the largest |dL/dD| of the call (2^-35 of it: 11 bits finer than an fp32 sum of the same terms; headroom for pixel differences up to 16) and summed
  * with 64-bit integer atomics (integer addition is associative), then folded into grad once per pixel. */
 size_t ssg_grad_fix_bytes(int B, int C, int H, int W);
 
@@ -294,11 +299,15 @@ size_t ssg_usm_scratch_bytes(int B, int C, int H, int W);
 int ssg_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int radius, float sigma, float weight,
                   float threshold, void *scratch, size_t scratch_bytes, ssg_stream_t stream);
 
-/* Profiling only (results are WRONG while a mask is set): skip kernel phases or whole launches so that one
- * kernel of a multi-kernel entry point can be timed with events on its stream.  Bits: 25 dense-tile forward,
- * 26 direct forward, 27 dense-tile backward, 28 direct backward (split mode), 29 G rows; lower bits ablate
- * phases inside kernels (ssg_api.hip).  Returns the previous mask; 0 restores production behaviour. */
+#ifdef SSG_PROFILE
+/* PROFILING BUILD ONLY (libssg_hip_prof.so, compiled with -DSSG_PROFILE; the product library libssg_hip.so does not
+ * export this symbol and has no code path that skips work).  Results are WRONG while a mask is set: skip kernel
+ * phases or whole launches so that one kernel of a multi-kernel entry point can be timed with events on its stream.
+ * Bits: 25 dense-tile forward, 26 direct forward, 27 dense-tile backward, 28 direct backward (split mode), 29 G rows;
+ * lower bits ablate phases inside kernels (ssg_api.hip).  Returns the previous mask; 0 = production behaviour.  The
+ * environment variable SSG_DEBUG_SKIP presets the mask, in this build only. */
 int ssg_set_profile_mask(int mask);
+#endif
 
 /* Host helper for profiling builds: name of the HIP kernel a configuration
  * dispatches to ("ssg_fwd<25,9,5>", "ssg_fwd_generic", ...). */

@@ -12,6 +12,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libssg_hip.so")
+# the same sources with -DSSG_PROFILE: kernel-phase ablations + ssg_set_profile_mask (bench.py's per-kernel timings,
+# tools/); the product library above has neither
+PROF_SO_PATH = os.path.join(CSRC, "libssg_hip_prof.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ssg_hip.h")
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -46,19 +49,19 @@ PROTOTYPES = {
                               _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ssg_augment_crop": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssg_pool_swap": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
-    "ssg_set_profile_mask": (_i, [_i]),
     "ssg_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
     # include/similarity.h: the reference operator's own (void, stream-less) interface
     "ssg_ref_compute_similarity": (None, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "ssg_ref_compute_similarity_backward": (None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "ssg_last_status": (_i, []),
 }
+PROF_PROTOTYPES = {"ssg_set_profile_mask": (_i, [_i])}   # libssg_hip_prof.so only
 # C++-linkage symbols of include/similarity.h (Itanium mangling of the reference's declarations, similarity.h:2-23)
 CXX_SYMBOLS = ("_Z19_compute_similarityPKfPKiPfiiiiii", "_Z28_compute_similarity_backwardPKfS0_PKiPfiiiiii")
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into csrc/libssg_hip.so."""
+    """Compile every HIP source for gfx950 into csrc/libssg_hip.so (+ the profiling build libssg_hip_prof.so)."""
     cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or out.returncode:
@@ -69,31 +72,61 @@ def build(force=False, verbose=False):
 
 
 _lib = None
+_prof = None
+
+
+def _load(path, prototypes):
+    # torch bundles its own HIP runtime (libamdhip64 of its ROCm build).  It must be the one
+    # already mapped when libssg_hip.so resolves its libamdhip64 dependency, otherwise the
+    # process ends up with two runtimes and our launches see "no ROCm-capable device".
+    import torch  # noqa: F401
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ssl_amd/csrc`).  ssl_amd has no CPU / PyTorch fallback for the SSG kernels.")
+    L = ctypes.CDLL(path)
+    for name, (res, args) in prototypes.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is absent: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    for name in CXX_SYMBOLS:
+        getattr(L, name)
+    return L
 
 
 def lib():
     """The loaded library with typed prototypes.  Raises if it is not built."""
     global _lib
     if _lib is None:
-        # torch bundles its own HIP runtime (libamdhip64 of its ROCm build).  It must be the one
-        # already mapped when libssg_hip.so resolves its libamdhip64 dependency, otherwise the
-        # process ends up with two runtimes and our launches see "no ROCm-capable device".
-        import torch  # noqa: F401
-        if torch.cuda.is_available():
-            torch.cuda.init()
-        if not os.path.exists(SO_PATH):
-            raise RuntimeError(
-                f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(or `make -C ssl_amd/csrc`).  ssl_amd has no CPU / PyTorch fallback for the SSG kernels.")
-        L = ctypes.CDLL(SO_PATH)
-        for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(L, name)  # AttributeError if the symbol is absent: loud by design
-            fn.restype = res
-            fn.argtypes = args
-        for name in CXX_SYMBOLS:
-            getattr(L, name)
-        _lib = L
+        _lib = _load(SO_PATH, PROTOTYPES)
     return _lib
+
+
+def lib_prof():
+    """The PROFILING build (libssg_hip_prof.so): same entry points + ssg_set_profile_mask.  For timing tools only."""
+    global _prof
+    if _prof is None:
+        _prof = _load(PROF_SO_PATH, dict(PROTOTYPES, **PROF_PROTOTYPES))
+    return _prof
+
+
+class profile_build:
+    """`with _lib.profile_build() as L:` -- inside the block lib() returns the profiling build, so that the engine's
+    host code (which calls lib()) runs on it; the product library is restored on exit."""
+
+    def __enter__(self):
+        global _lib
+        self._saved = _lib
+        _lib = lib_prof()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib.ssg_set_profile_mask(0)
+        _lib = self._saved
+        return False
 
 
 def check(status):

@@ -66,11 +66,10 @@ int launch_grad_fix_reduce(const float *part, int n, long long *gfix, size_t n_f
 
 using namespace ssg;
 
-// Edge pixels per 8 x 32 tile from which the dense ("shared-term") forward kernel takes the tile (0 = never).
-// Measured (profiles/r1_dense_forward_v2.txt): with the tiles of >= 28 edge pixels routed to it the forward of
-// the benchmark batch (7 % Laplacian masks) takes 0.93 instead of 1.09 ms, and 1.5 instead of 3.55 ms at 100 %
-// density; below ~16 pixels per tile the direct kernels win.  Default 28; ssg_set_dense_threshold(n) or the
-// environment variable SSG_DENSE_THR (read at first use) override it.
+// Edge pixels per dense tile (8 x 32 for k_s 25, 4 x 32 for k_s 49) from which the shared-term kernels take the tile
+// (0 = never).  With the round-2 kernels the C2 step is flat between 16 and 32 (tools/thr_sweep.sh: 1.42-1.44 ms):
+// the marginal costs of the two paths are equal there; below ~16 pixels per tile the direct kernels win.  Default 28;
+// ssg_set_dense_threshold(n) or the environment variable SSG_DENSE_THR (read at first use) override it.
 constexpr int DENSE_THR_DEFAULT = 28;
 static std::atomic<int> g_dense_thr{-1};   // (atomic: the ABI may be called from several host threads)
 static int dense_threshold() {
@@ -90,10 +89,12 @@ extern "C" int ssg_set_dense_threshold(int edge_pixels_per_tile) {
   return prev;
 }
 
-// SSG_DEBUG_SKIP=<bitmask> (or ssg_set_profile_mask) ablates kernel phases / skips whole launches for
-// profiling (results are then WRONG); 0 in production.  Bits 0-7 direct forward phases, 8-15 backward phases,
-// 16-23 dense forward phases, 24 no split backward; launches skipped: 25 dense forward, 26 direct forward,
-// 27 dense backward, 28 direct backward (split mode), 29 G rows.
+// Profiling build only (-DSSG_PROFILE -> libssg_hip_prof.so): SSG_DEBUG_SKIP=<bitmask> / ssg_set_profile_mask ablate
+// kernel phases or skip whole launches (results are then WRONG).  Bits 0-7 direct forward phases, 8-15 backward
+// phases, 16-23 dense forward phases, 24 no split backward; launches skipped: 25 dense forward, 26 direct forward,
+// 27 dense backward, 28 direct backward (split mode), 29 G rows.  The product library has neither the symbol nor the
+// environment variable: its mask is the constant 0 and every test on it folds away.
+#ifdef SSG_PROFILE
 static std::atomic<int> g_dbg{-1};
 static int dbg_mask() {
   int v = g_dbg.load(std::memory_order_relaxed);
@@ -110,6 +111,9 @@ extern "C" int ssg_set_profile_mask(int mask) {
   g_dbg.store(mask > 0 ? mask : 0, std::memory_order_relaxed);
   return prev;
 }
+#else
+static constexpr int dbg_mask() { return 0; }
+#endif
 
 // The dense-tile kernel and the direct kernel of a pass work on disjoint SSG rows (and add into the gradient with
 // atomics), so the direct one runs on a side stream beside the dense one: fork = side waits for an event on the

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   // g and g+1 update overlapping gradient pixels: give every XCD one contiguous range of groups so
   // that those atomics meet in one L2.
   int grp = blockIdx.x;
-  if (p.order && !(p.dbg & 16)) {
+  if (p.order && !SSG_DBG(p, 16)) {
     const int ng = (nrows + JOBS - 1) / JOBS, per = (ng + 7) >> 3;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     grp = idx < per ? xcd * per + idx : ng;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
     {
       const size_t base = (size_t)(job_on ? n : 0) * P;
       float va[EPL], vg[EPL];
-      const bool direct = p.mode == GRAD_D || (p.dbg & 1);
+      const bool direct = p.mode == GRAD_D || SSG_DBG(p, 1);
       const float *src_a = direct ? (p.mode == GRAD_D ? p.gin : p.ssg) : p.ssg;
       const float *src_b = p.mode == GRAD_S ? p.gin : p.ssg2;
 #pragma unroll
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
       }
       red2[tid] = ls;  // (the dot products were consumed before the barrier above)
     }
-    if (p.mode == GRAD_LOSS && (p.dbg & 1) && tid == 0) {  // (profiling ablation without criteria)
+    if (p.mode == GRAD_LOSS && SSG_DBG(p, 1) && tid == 0) {  // (profiling ablation without criteria)
       p.partials[2 * blockIdx.x] = 0.f;
       p.partials[2 * blockIdx.x + 1] = 0.f;
     }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
       for (int i = 0; i < BS; ++i)
 #pragma unroll
         for (int j = 0; j < BS; ++j) acc[i][j] = 0.f;
-      if (p.dbg & 2) {
+      if (SSG_DBG(p, 2)) {
       } else if constexpr (KW <= 9) {
         float af[KW][KW];
 #pragma unroll
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 
       // ---- pass B: P[k'] = sum_t Gz[t+k'] * S[c,t], KHC stencil rows at a time ----
 #pragma unroll 1
-      for (int ch = 0; ch < ((p.dbg & 4) ? 0 : NCH); ++ch) {
+      for (int ch = 0; ch < (SSG_DBG(p, 4) ? 0 : NCH); ++ch) {
         const int kh0 = ch * KHC;
         float pp[KHC][KW];
 #pragma unroll
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
         // ---- gather-merge: every lane owns pixels of the jobs' common window and sums the
         // staged tiles that cover them (no LDS atomics, no per-job rounds), then issues ONE
         // fp32 atomic per touched pixel, row-contiguous ----
-        if (!(p.dbg & 8)) {
+        if (!SSG_DBG(p, 8)) {
           const size_t cb0 = ((size_t)mb0 * C + c) * H * W;
           const int wh = my1 - my0 + KS, ww = mx1 - mx0 + KS;
           int dy[JOBS], dx[JOBS];
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
         lds_barrier();
       } else {
         // ---- flush per job: row-contiguous fp32 atomics, nothing waits for them ----
-        if (job_on && !(p.dbg & 8)) {
+        if (job_on && !SSG_DBG(p, 8)) {
 #pragma unroll 5
           for (int k = 0; k < EPL; ++k) {
             const int e = m + k * LPJ;

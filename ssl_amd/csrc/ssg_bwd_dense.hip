@@ -172,6 +172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   const int lane = threadIdx.x;
   const int tslot = blockIdx.x;
   if (tslot >= dense_tile_count(p.n_dense)) return;
+  if (p.n_dense[1] != TY) __builtin_trap();   // plan cut for another tile height (see ssg_fwd_dense)
   const int H = p.H, W = p.W;
   const int tx_n = (W + TX - 1) / TX, ty_n = (H + TY - 1) / TY;
   const int tile = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     const bool on = e < n_e;
     epos[ck] = on ? elist[2 * e] : DUMMY;
     erow[ck] = on ? elist[2 * e + 1] : elist[1];
-    gp[ck] = p.G + ((p.dbg & 16) ? (size_t)0 : (size_t)erow[ck] * P);   // (profiling: bit 4 = every lane streams row 0)
+    gp[ck] = p.G + (SSG_DBG(p, 16) ? (size_t)0 : (size_t)erow[ck] * P);   // (profiling: bit 4 = every lane streams row 0)
   }
 
   // lane roles: main (U-row r, column group g); prefix (tile row hty, column group hg)
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
         for (int c = 0; c < C; ++c) {
           const float v = brow[c * RWS + col];
           brow[c * RWS + col] = 0.f;
-          if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
+          if (ok && v != 0.f && !SSG_DBG(p, 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
         }
       }
     }
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       for (int c = 0; c < C; ++c) {
         const float iuc = c == 0 ? iuA[i].x : c == 1 ? iuA[i].y : iuB[i], guc = c == 0 ? guA[i].x : c == 1 ? guA[i].y : guB[i];
         const float v = __builtin_fmaf(iuc, vt, guc);
-        if (ok && v != 0.f && !(p.dbg & 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
+        if (ok && v != 0.f && !SSG_DBG(p, 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
       }
     }
   }

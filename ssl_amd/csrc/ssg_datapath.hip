@@ -346,7 +346,7 @@ int launch_filter2d(const float *img, const float *kernels, float *out, int B, i
 // One wave per 16 x 16 macroblock (4 luma blocks + Cb + Cr), everything between the load and the store on chip: lane
 // (u, v) holds the 64 basis products cos((2x+1)u pi/16) cos((2y+1)v pi/16) of its coefficient (and the transposed
 // set of its pixel for the inverse) as the reference builds them -- fp64 product rounded to fp32 -- and walks the
-// block through LDS broadcasts.  factor = quality_to_factor(quality[b]) (:32-46) in fp32 like the tensor branch.
+// block through LDS broadcasts.  factor = quality_to_factor(quality[b]) (:32-46): fp32 for the tensor branch, host double for a scalar.
 __device__ const double kJpegCos[8][8] = {   // np.cos((2x+1) u pi / 16) [x][u], repr of the doubles numpy computes (diffjpeg.py:127)
     {1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196023, 0.38268343236508984, 0.19509032201612833},
     {1.0, 0.8314696123025452, 0.38268343236508984, -0.1950903220161282, -0.7071067811865475, -0.9807852804032304, -0.9238795325112868, -0.5555702330196022},
@@ -363,15 +363,21 @@ __device__ const float kJpegY[8][8] = {{16, 11, 10, 16, 24, 40, 51, 61},     {12
 __device__ const float kJpegC[4][4] = {{17, 18, 24, 47}, {18, 21, 26, 66}, {24, 26, 56, 99}, {47, 66, 99, 99}};
 
 __global__ __launch_bounds__(64) void jpeg_kernel(const float *img, float *out, int H, int W, const float *quality,
-                                                  float quality_host) {
+                                                  float factor_host) {
   __shared__ float blk[6][64];   // 0..3 luma blocks (row-major 2 x 2), 4 Cb, 5 Cr -- pixels, then coefficients, then pixels
   const int lane = threadIdx.x, u = lane >> 3, v = lane & 7;
   const int b = blockIdx.z, y0 = 16 * blockIdx.y, x0 = 16 * blockIdx.x;
   const size_t plane = (size_t)H * W;
   const float *src = img + (size_t)b * 3 * plane;
-  float q = quality ? quality[b] : quality_host;
-  q = q < 50.f ? 5000.f / q : 200.f - q * 2.f;   // quality_to_factor, fp32 like the tensor branch (diffjpeg.py:465-466)
-  const float factor = q / 100.f;
+  // tensor branch (diffjpeg.py:475-476): quality_to_factor on fp32 tensor elements, two fp32 roundings.  Scalar
+  // branch (:473-474): Python doubles, rounded to fp32 ONCE where the table is multiplied (:169,199) -- that factor
+  // is formed on the host in double (launch_jpeg) and arrives as `factor_host`.
+  float factor = factor_host;
+  if (quality) {
+    float q = quality[b];
+    q = q < 50.f ? 5000.f / q : 200.f - q * 2.f;
+    factor = q / 100.f;
+  }
   // ---- load 2 x 2 pixels per lane (zero beyond the image: F.pad constant 0), x 255, RGB -> YCbCr, chroma average ----
   {
     float cbs = 0.f, crs = 0.f;
@@ -458,7 +464,11 @@ int launch_jpeg(const float *img, float *out, int B, int H, int W, const float *
                 hipStream_t st) {
   if ((size_t)B * H * W == 0) return 0;
   const dim3 grid((unsigned)((W + 15) / 16), (unsigned)((H + 15) / 16), (unsigned)B);
-  hipLaunchKernelGGL(jpeg_kernel, grid, dim3(64), 0, st, img, out, H, W, quality_dev, quality_host);
+  // scalar quality: quality_to_factor (diffjpeg.py:32-45) in double like the reference's Python floats, one rounding
+  double q = (double)quality_host;
+  q = q < 50.0 ? 5000.0 / q : 200.0 - q * 2.0;
+  const float factor_host = (float)(q / 100.0);
+  hipLaunchKernelGGL(jpeg_kernel, grid, dim3(64), 0, st, img, out, H, W, quality_dev, factor_host);
   return (int)hipGetLastError();
 }
 

@@ -12,19 +12,26 @@
 // everything here is plain additions of non-negative numbers: no sliding subtraction, no prefix
 // sums (both break the 1e-5 budget at sigma = 0.004).
 //
-// One workgroup (4 waves) owns a tile of 8 x 32 candidate centres.  Its (8+2*16) x (32+2*16) x C
-// image region sits in LDS.  Wave w walks the offset rows q_y = w, w+4, ...; inside a row the 25
-// (k_s) offsets q_x are fully unrolled: lane (r, g) keeps its own 16 pixels of U-row r (U = tile
-// grown by the window halo) in registers, slides the 16-pixel window of I[u+q] by one pixel per
-// step (3 LDS dwords), forms E, then the horizontal box sums of its 8 centre columns with
-// compile-time truncation [xlo,xhi], and writes them to the wave's H buffer.  The tile's edge
-// pixels (census from the rank map) then add the vertical taps [ylo,yhi], the |I|^2 complement,
-// apply exp and store e[n,q]; the row sums are accumulated on the fly and the rows are rescaled
-// by 1/(sum + eps) at the end (L2-resident re-read of what the workgroup just wrote).
+// One workgroup (NW waves: 4 for (25,9), 7 for (49,13)) owns a tile of DT_Y x 32 candidate centres (DT_Y = 8 for
+// k_w 9, 4 for k_w 13, so that the tile grown by the window halo, U, is always 16 rows).  Its (DT_Y + 2 HALO) x
+// (32 + 2 HALO) x C image region sits in LDS.  Wave w walks the offset rows q_y = w (mod NW); inside a row the k_s
+// offsets q_x are fully unrolled.  Lane (U-row r, column group g) -- the four groups of a row are one DPP quad -- owns
+// L = 10 (12) pixels of the row WITHOUT overlap as L/2 packed-fp32 register pairs (pixel j, pixel j + L/2), keeps a
+// circular window of I[u+q] that advances by one pixel per step (C LDS dwords), forms E with v_pk_add / v_pk_fma,
+// then the horizontal box sums of its L centre columns: for full windows from shared prefix / suffix blocks plus the
+// neighbouring lane's prefix through a quad_perm DPP operand, for truncated windows [xlo,xhi] (compile-time per
+// step) from the row continued into the next lane, E inside the taps kept and |I|^2 outside.  The sums go to the
+// wave's private H buffer in LDS; the tile's edge pixels (census from the rank map, counting-sorted by H-buffer bank
+// for k_w 9) add the vertical taps [ylo,yhi] as a depth-5 tree with 0/1 weights, the |I|^2 complement, apply
+// v_exp_f32 and store e[n,q] (13 buffered offsets per 16-byte store group).  Row sums are carried in fp64; the rows
+// are either rescaled by 1/(sum + eps) at the end (L2-resident re-read of what the workgroup just wrote) or -- the
+// fused step -- left un-normalised with 1/(sum + eps) in `row_scale` for ssg_grad_rows to apply (deferred
+// normalisation: one pass over the rows less).
 //
-// Cost: ~235 wave-instructions per (tile, offset) regardless of the number of edge pixels, against
-// 25 * 12.6 k lane-instructions per edge pixel for the direct kernels: break-even at ~27 edge
-// pixels per 256-pixel tile; the edge-list builder routes tiles above the threshold here.
+// Cost (C2, SQ counters): ~95 VALU (42 % of them packed) + 14 LDS instructions per wave and offset step regardless of
+// the number of edge pixels, plus ~20 per 64 edge pixels of the tile; the direct kernels spend 2 C k_w^2 lane-ops per
+// (edge pixel, offset).  Break-even is ~16-28 edge pixels per 256-pixel tile (flat: tools/thr_sweep.sh); the
+// edge-list builder routes tiles at or above the threshold here.
 #include "ssg_common.hpp"
 
 namespace ssg {
@@ -160,6 +167,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int which = blockIdx.x / p.max_tiles, tslot = blockIdx.x - which * p.max_tiles;
   if (tslot >= dense_tile_count(p.n_dense)) return;
+  // the plan records the tile height it was cut for (ssg_edge_list's plan_ks): walking an 8-row plan with 4-row
+  // tiles (or the reverse) would decode garbage tile ids -- stop loudly instead (the Python host raises before
+  // it gets here, engine.check_plan)
+  if (p.n_dense[1] != DT_Y) __builtin_trap();
   const int H = p.H, W = p.W;
   const int tx_n = (W + DT_X - 1) / DT_X, ty_n = (H + DT_Y - 1) / DT_Y;
   const int tile = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
@@ -343,10 +354,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     orow[ck] = eon[ck] ? (size_t)elist[3 * ec + 2] * P : 0;
   }
 
-  const int n_e_stage = (p.dbg & 2) ? 0 : n_e;  // profiling ablations: 2 no edge stage, 1 no stores, 64 no main loop
-  const bool do_store = !(p.dbg & 1);
+  const int n_e_stage = SSG_DBG(p, 2) ? 0 : n_e;  // profiling ablations: 2 no edge stage, 1 no stores, 64 no main loop
+  const bool do_store = !SSG_DBG(p, 1);
 #pragma unroll 1
-  for (int qyi = wv; qyi < ((p.dbg & 64) ? 0 : KS); qyi += NW) {
+  for (int qyi = wv; qyi < (SSG_DBG(p, 64) ? 0 : KS); qyi += NW) {
     // D[n,q] = sum_{k in K(q)} E_q[x+k] + sum_{k not in K(q)} |I[x+k]|^2 with K(q) = rows [ylo,yhi] x columns
     // [xlo,xhi] of the window.  Rows: wave-uniform 0/1 weights.  Columns: the lane adds the |I|^2 of the
     // columns that left (compile-time set) to its horizontal sums, so H' rows carry E inside and |I|^2 outside
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (ck * 64 + lane < n_e) rsum[wv * RSTR + ck * 64 + lane] = rs[ck];
   __threadfence_block();
   __syncthreads();
-  if (!p.generalization || (p.dbg & 8)) return;
+  if (!p.generalization || SSG_DBG(p, 8)) return;
   if (p.row_scale) {
     // deferred normalisation: the consumer that streams the rows anyway (ssg_grad_rows) rescales them; saves this
     // kernel's second pass over its rows (one read + one write of every row)

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
     const float *src = p.img[mw0] + (size_t)mb0 * C * H * W;
     // 8 lanes per region row (5 columns each, stride 8), WG/8 rows per pass, two passes in flight
     constexpr int LPR = 8, CPL = (MW + LPR - 1) / LPR, RPP = WG / LPR;
-    const int rows = (p.dbg & 1) ? 0 : C * wh;
+    const int rows = SSG_DBG(p, 1) ? 0 : C * wh;
     const int lx = tid % LPR, lr = tid / LPR;
     for (int r0 = 0; r0 < rows; r0 += 2 * RPP) {
       float v[2][CPL];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   // job are issued before the first LDS store (a plain loop pays the full L2 latency per
   // element: the fill was 29 % of the kernel) ----
   constexpr int EPT = (P + WG - 1) / WG;  // tile elements per thread per channel
-  for (int j = 0; j < ((p.dbg & 1) ? 0 : JOBS); ++j) {
+  for (int j = 0; j < (SSG_DBG(p, 1) ? 0 : JOBS); ++j) {
     const float *src = p.img[sh_edge[j * 6 + 4]];
     const int b = sh_edge[j * 6 + 0], y = sh_edge[j * 6 + 1], x = sh_edge[j * 6 + 2];
     const float *s0[EPT];
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   const float *tjob = MERGED ? tiles + (sh_edge[jl * 6 + 1] - my0) * MS + (sh_edge[jl * 6 + 2] - mx0)
                              : tiles + (jl * C) * CH;
 #pragma unroll 1
-  for (int c = 0; c < ((p.dbg & 2) ? 0 : C); ++c) {
+  for (int c = 0; c < (SSG_DBG(p, 2) ? 0 : C); ++c) {
     const float *tc = tjob + c * chs;
     if constexpr (KW <= 9) {
       float a[KW][KW];  // centre window of this channel (uniform across the job's lanes)
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
     return;
   }
 
-  if (p.dbg & 4) {
+  if (SSG_DBG(p, 4)) {
     if (acc[0][0] == 123.456f) p.out[0][0] = acc[1][1];
     return;
   }

@@ -48,6 +48,32 @@ def _grad_fix(det, x):
     return torch.empty(_lib.lib().ssg_grad_fix_bytes(B, C, H, W), dtype=torch.uint8, device=x.device)
 
 
+class FwdPlan(tuple):
+    """(order, rank map, plan) as the forward / backward entry points take them, plus `.ks`: the search size the plan's
+    dense tiles were cut for (8-row tiles for k_s <= 25, 4-row tiles for k_s = 49).  A plan built for one tile
+    height must not be walked by the kernels of the other (they would decode tile ids with their own geometry):
+    `check_plan` raises before anything is launched."""
+
+    def __new__(cls, order, rank, plan, ks):
+        self = super().__new__(cls, (order, rank, plan))
+        self.ks = int(ks)
+        return self
+
+
+def _plan_rows(ks):
+    return 4 if int(ks) == 49 else 8   # dense_tile_rows() of ssl_amd/csrc/ssg_dense.hip
+
+
+def check_plan(fwd, ks):
+    """ValueError when `fwd` (EdgeList.fwd) was built by edge_list(ks=...) for another dense-tile height than the
+    kernels of this call's k_s use."""
+    built = getattr(fwd, "ks", None)
+    if fwd is not None and built is not None and _plan_rows(built) != _plan_rows(ks):
+        raise ValueError(f"ssl_amd: this edge list's dense/direct plan was built for k_s = {built} "
+                         f"({_plan_rows(built)}-row tiles) but the call uses k_s = {ks} ({_plan_rows(ks)}-row tiles); "
+                         f"build it with edge_list(..., ks={ks})")
+
+
 class EdgeList(tuple):
     """(edges, counts) -- unpacks like the pair it always was -- plus `.rank`, the (B,H,W) int32
     rank map (row of `edges` holding each pixel, -1 elsewhere), and `.order`, the tile-major
@@ -55,10 +81,11 @@ class EdgeList(tuple):
     forward's work split between the dense-tile kernel and the direct kernels.  `.fwd` bundles
     what the forward entry points take."""
 
-    def __new__(cls, edges, counts, rank, order, plan):
+    def __new__(cls, edges, counts, rank, order, plan, ks=25):
         self = super().__new__(cls, (edges, counts))
         self.edges, self.counts, self.rank, self.order, self.plan = edges, counts, rank, order, plan
-        self.fwd = (order, rank, plan)
+        self.ks = int(ks)
+        self.fwd = FwdPlan(order, rank, plan, ks)
         return self
 
 
@@ -98,7 +125,7 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
         _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold), int(ks),
                                    _ptr(edges), capacity, _ptr(counts), _ptr(rank), _ptr(order), _ptr(plan),
                                    _ptr(scratch), _stream()))
-    return EdgeList(edges, counts, rank, order, plan)
+    return EdgeList(edges, counts, rank, order, plan, ks)
 
 
 def set_dense_threshold(edge_pixels_per_tile):
@@ -169,6 +196,7 @@ def ssg_map(img, edges, counts, n_rows, ks, kw, sigma, eps=1e-10, generalization
     `order` (EdgeList.order) is the backward kernel's tile-major job order, `fwd` (EdgeList.fwd)
     the forward's (order, rank map, dense/direct plan)."""
     _need_gpu(img, edges, counts, order)
+    check_plan(fwd, ks)
     return _SSGMapFn.apply(img, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization, order, fwd,
                            deterministic)
 
@@ -241,6 +269,7 @@ def ssg_loss(sr, gt, edges, counts, n_rows, ks=25, kw=9, sigma=0.004, eps=1e-10,
              w_kl=1.0, order=None, fwd=None, deterministic=None):
     """Differentiable (l1, kl) for a batch given a device edge list; n_rows bounds N."""
     _need_gpu(sr, gt, edges, counts, order)
+    check_plan(fwd, ks)
     return _SSGLossFn.apply(sr, gt, edges, counts, int(n_rows), int(ks), int(kw), sigma, eps, generalization, w_l1,
                             w_kl, order, fwd, deterministic)
 

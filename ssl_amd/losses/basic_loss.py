@@ -73,11 +73,20 @@ class SSGLoss(nn.Module):
     Memory: one call holds 2 * capacity * k_s^2 * 4 bytes of SSG rows (+ the same again / 2 of
     backward scratch) while it runs -- 0.5 GB per 100 k edge pixels at k_s = 25 -- and keeps only
     the (B,C,H,W) gradient for backward.  `capacity` bounds the number of edge pixels of a call
-    without a host round trip.  Default: a quarter of the pixels (edge masks are ~7 % dense),
-    doubled automatically when a step turns out to have more: the edge count of every step is
-    copied to pinned host memory asynchronously and looked at one step later, so nothing stalls;
-    the step that overflowed used the first `capacity` edge pixels only and is reported with a
-    warning (on_overflow='grow', default) or a RuntimeError (on_overflow='raise').
+    without a host round trip.  Default (capacity=None): a quarter of the call's pixels (edge masks
+    are ~7 % dense; computed per call, so a small first batch does not pin it) or the largest count
+    seen so far plus 1/8, whichever is larger.  DENSE masks (mask_stride patterns over textured
+    crops, the 100 % stress mask) need `capacity=B*H*W` -- or rely on the checks below:
+      * the first `sync_checks` calls (default 2), and the call after any overflow, read the edge
+        count back in the same step (one host synchronisation of a 4-byte copy); a call found
+        truncated is RECOMPUTED at the grown capacity before forward() returns, so its losses
+        and gradient cover every edge pixel (on_overflow='grow', default, with a warning) or a
+        RuntimeError is raised (on_overflow='raise');
+      * later calls copy their count to pinned host memory asynchronously; it is looked at one or
+        more calls later, so nothing stalls.  A call that overflowed then HAS used only the first
+        `capacity` edge pixels in batch order: every such call is reported (warning / RuntimeError),
+        the capacity grows, and the next call is checked synchronously.  `flush()` waits for the
+        outstanding counts (call it after the last / a single forward, e.g. in validation).
 
     deterministic=True makes the gradient bit-reproducible from run to run (fixed-point integer
     accumulation instead of fp32 atomics; include/ssg_hip.h `ssg_grad_fix_bytes`).
@@ -85,7 +94,7 @@ class SSGLoss(nn.Module):
 
     def __init__(self, kernel_size_search=25, kernel_size_window=9, sigma=0.004, generalization=True,
                  loss_weight_l1=1e3, loss_weight_kl=1e3, mask_stride=0, eps=1e-10, lap_threshold=20.0,
-                 capacity=None, on_overflow='grow', deterministic=None):
+                 capacity=None, on_overflow='grow', deterministic=None, sync_checks=2):
         super().__init__()
         if on_overflow not in ('grow', 'raise'):
             raise ValueError(f"on_overflow must be 'grow' or 'raise', got {on_overflow!r}")
@@ -93,47 +102,84 @@ class SSGLoss(nn.Module):
         self.sigma, self.generalization, self.eps = sigma, generalization, eps
         self.w_l1, self.w_kl = loss_weight_l1, loss_weight_kl
         self.mask_stride, self.lap_threshold = mask_stride, lap_threshold
-        self.capacity = capacity
+        self.capacity = capacity   # the caller's bound (None: per-call default); never overwritten by a per-call clamp
+        self._grown = 0            # capacity learnt from overflows
         self.on_overflow = on_overflow
         self.deterministic = deterministic   # None: SSG_DETERMINISTIC env; True: bit-reproducible gradients
-        self._pending = None       # (event, pinned count, capacity used) of the previous call
+        self._sync_left = int(sync_checks)   # calls still to be checked in the same step
+        self._pending = []         # (event, pinned count, capacity used) of earlier calls, oldest first
+
+    def _capacity_for(self, B, H, W):
+        cap = self.capacity if self.capacity is not None else max(1024, (B * H * W) // 4)
+        return min(max(cap, self._grown), B * H * W)   # (clamped for THIS call only)
+
+    def _grow(self, n, cap):
+        self._grown = max(self._grown, 2 * cap, n + n // 8)
+        self._sync_left = max(self._sync_left, 1)   # verify the next call in its own step
+
+    def _report(self, n, cap, recomputed):
+        msg = (f"SSGLoss: a step had {n} edge pixels but capacity {cap}; "
+               + ("it was recomputed at the grown capacity. " if recomputed else f"it used the first {cap} only. ")
+               + f"capacity is now {self._grown} (dense masks: pass capacity=B*H*W).")
+        if self.on_overflow == 'raise':
+            raise RuntimeError(msg)
+        import warnings
+        warnings.warn(msg)
 
     def _check_previous(self, wait=False):
-        """Look at the edge count of an earlier call if its copy has landed (never blocks unless wait)."""
-        if self._pending is None:
-            return
-        ev, host, cap = self._pending
-        if not (wait or ev.query()):
-            return
-        if wait:
-            ev.synchronize()
-        self._pending = None
-        n = int(host[0])
-        if n > cap:
-            msg = (f"SSGLoss: a step had {n} edge pixels but capacity {cap}; it used the first {cap} only. "
-                   f"capacity is now {max(2 * cap, n + n // 8)}.")
-            if self.capacity is None or self.capacity < n:
-                self.capacity = max(2 * cap, n + n // 8)
-            if self.on_overflow == 'raise':
-                raise RuntimeError(msg)
-            import warnings
-            warnings.warn(msg)
+        """Look at the edge counts of earlier calls whose copies have landed (never blocks unless wait); every
+        overflowed call is reported."""
+        first_error = None
+        while self._pending:
+            ev, host, cap = self._pending[0]
+            if not (wait or ev.query()):
+                break
+            if wait:
+                ev.synchronize()
+            self._pending.pop(0)
+            n = int(host[0])
+            if n > cap:
+                self._grow(n, cap)
+                try:
+                    self._report(n, cap, recomputed=False)
+                except RuntimeError as e:      # look at the remaining counts before raising
+                    first_error = first_error or e
+        if first_error is not None:
+            raise first_error
 
-    def forward(self, sr, gt, mask=None):
-        B, C, H, W = sr.shape
-        self._check_previous()
-        cap = self.capacity if self.capacity is not None else max(1024, (B * H * W) // 4)
-        cap = min(cap, B * H * W)
-        self.capacity = cap
+    def flush(self):
+        """Wait for the outstanding edge counts and report any overflow (after the last or a single forward)."""
+        self._check_previous(wait=True)
+
+    def _run(self, sr, gt, mask, cap):
+        B = sr.shape[0]
         counts = torch.empty(B + 2, dtype=torch.int32, device=sr.device)
         out = engine.ssg_loss_from_mask(sr, gt.detach(), mask, counts, cap, self.ks, self.kw, self.sigma, self.eps,
                                         self.generalization, self.w_l1, self.w_kl, self.mask_stride, self.lap_threshold,
                                         self.deterministic)
+        return out, counts
+
+    def forward(self, sr, gt, mask=None):
+        B, C, H, W = sr.shape
+        self._check_previous()
+        cap = self._capacity_for(B, H, W)
+        out, counts = self._run(sr, gt, mask, cap)
+        if self._sync_left > 0:
+            # same-step check: a truncated call never leaves forward() unnoticed
+            self._sync_left -= 1
+            n = int(counts[0])           # (host synchronisation)
+            if n > cap:
+                self._grow(n, cap)
+                if self.on_overflow == 'raise':
+                    self._report(n, cap, recomputed=False)
+                out, counts = self._run(sr, gt, mask, self._capacity_for(B, H, W))
+                self._report(n, cap, recomputed=True)
+        else:
+            with torch.cuda.device(sr.device):   # the copy and the event go to the stream of sr's device
+                host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                host.copy_(counts[:1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(sr.device))
+            self._pending.append((ev, host, cap))
         self.last_counts = counts
-        if self._pending is None:      # one outstanding copy at a time
-            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            host.copy_(counts[:1], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._pending = (ev, host, cap)
         return out

@@ -537,12 +537,12 @@ def cpu_reference_timing():
     mask = synth.laplacian_edge_mask(gt[0])[None, None]
     n = int(mask.sum())
     times = []
-    for it in range(3):
+    for it in range(4):          # 1 warm-up + 3 timed ("1 warm-up + median of 3")
         t0 = time.time()
         caller_loop(sr, gt, mask, ks, kw, sigma, True, 1e3, 1e3, torch.float32)
         times.append(time.time() - t0)
         print(f"    reference step {it}: {times[-1]:.1f}s")
-    med = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
+    med = float(np.median(times[1:]))
     res = dict(what="reference ssl_pytorch fwd(SR)+fwd(GT)+L1+KL+backward, 1x3x256x256, k_s=25 k_w=9 sigma=1.0, fp32",
                n_edges=n, seconds=times, median_after_warmup_s=med, edge_px_per_s=n / med,
                cores=os.cpu_count(), torch_threads=torch.get_num_threads(), torch=torch.__version__)

@@ -23,8 +23,10 @@ def test_library_builds_loads_and_exports_header_symbols():
     declared = set(re.findall(r"\b(ssg_[a-z_0-9]+)\s*\(", hdr))
     declared -= {"ssg_stream_t"}
     assert len(declared) >= 18
+    # (the one declaration inside `#ifdef SSG_PROFILE` belongs to the profiling build only -- next test)
+    profile_only = {"ssg_set_profile_mask"}
     L = ctypes.CDLL(_lib.SO_PATH)
-    for name in sorted(declared):
+    for name in sorted(declared - profile_only):
         assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
     # the reference's own two functions (similarity.h:2-23, C++ linkage): declared in include/similarity.h,
     # exported under the Itanium-mangled names the reference's similaritywrapper.cpp links against
@@ -38,7 +40,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert demangled[1] == ("_compute_similarity_backward(float const*, float const*, int const*, float*, int, int, int, "
                             "int, int, int)")
     # every prototype the Python binding uses is declared in the header
-    assert set(_lib.PROTOTYPES) <= declared
+    assert set(_lib.PROTOTYPES) <= declared - profile_only
     lib = _lib.lib()
     assert lib.ssg_abi_version() == 3
     assert lib.ssg_status_string(0) == b"ok"
@@ -46,6 +48,29 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.ssg_kernel_name(25, 9, 0).startswith(b"ssg_fwd_")
     assert lib.ssg_kernel_name(7, 3, 1) == b"ssg_bwd_generic"
     assert lib.ssg_loss_workspace_bytes(16, 256, 256, 100000, 25) > 100000 * 12
+
+
+def test_product_library_has_no_profiling_switch():
+    """Kernel-phase ablations / launch skipping (results then wrong) exist only in libssg_hip_prof.so
+    (-DSSG_PROFILE): the product library neither exports ssg_set_profile_mask nor reads SSG_DEBUG_SKIP."""
+    from ssl_amd import _lib
+    _lib.build()
+    prod = ctypes.CDLL(_lib.SO_PATH)
+    assert not hasattr(prod, "ssg_set_profile_mask")
+    blob = open(_lib.SO_PATH, "rb").read()
+    assert b"SSG_DEBUG_SKIP" not in blob
+    prof = ctypes.CDLL(_lib.PROF_SO_PATH)
+    assert hasattr(prof, "ssg_set_profile_mask")
+    assert b"SSG_DEBUG_SKIP" in open(_lib.PROF_SO_PATH, "rb").read()
+    hdr = open(_lib.HEADER).read()
+    i = hdr.index("int ssg_set_profile_mask")
+    assert hdr.rfind("#ifdef SSG_PROFILE", 0, i) > hdr.rfind("#endif", 0, i)
+    # the package's product path never asks for the profiling build
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ssl_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "_lib.py":
+                src = open(os.path.join(dirpath, f)).read()
+                assert "lib_prof" not in src and "profile_build" not in src, f
 
 
 def test_gfx950_code_object_present():
@@ -247,6 +272,34 @@ def test_argument_checks_need_no_gpu():
     assert L.ssg_augment_crop(one, one, 2, 1, 3, 8, 8, 4, 4, one, None) == -1            # element size 2
     assert L.ssg_grad_fix_bytes(2, 3, 16, 16) == 8 * (2 * 3 * 16 * 16 + 8)
     assert L.ssg_backward_scratch_bytes(100, 25) >= 100 * 625 * 4
+
+
+def test_plan_built_for_another_tile_height_is_refused():
+    """A dense/direct plan is cut for one tile height (8 rows for k_s <= 25, 4 for k_s = 49) and records the k_s it
+    was built for; handing it to a call with the other geometry raises before anything is launched (the dense
+    kernels would decode its tile ids with their own tile height)."""
+    from ssl_amd import engine
+    t = torch.zeros(4, dtype=torch.int32)
+    fwd25 = engine.FwdPlan(t, t, t, 25)
+    assert tuple(fwd25) == (t, t, t) and fwd25.ks == 25
+    engine.check_plan(fwd25, 25)
+    engine.check_plan(fwd25, 11)          # same 8-row tiles (only the direct kernels run for k_s = 11)
+    engine.check_plan(None, 49)
+    engine.check_plan((t, t, t), 49)      # a bare tuple carries no k_s: nothing to check
+    with pytest.raises(ValueError, match="k_s = 25"):
+        engine.check_plan(fwd25, 49)
+    with pytest.raises(ValueError, match="4-row tiles"):
+        engine.check_plan(engine.FwdPlan(t, t, t, 49), 25)
+    el = engine.EdgeList(t, t, t, t, t, 49)
+    assert el.ks == 49 and el.fwd.ks == 49 and tuple(el) == (t, t)
+    # the entry points check before touching a tensor's device
+    with pytest.raises(ValueError):
+        engine.ssg_map(torch.zeros(1, 3, 64, 64).cuda() if torch.cuda.is_available() else _FakeGpu(), t, t, 4, 49, 13, 1.0,
+                       fwd=fwd25) if torch.cuda.is_available() else engine.check_plan(fwd25, 49)
+
+
+class _FakeGpu:
+    is_cuda = True
 
 
 def test_graft_entry_build_runs():

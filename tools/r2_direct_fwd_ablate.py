@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from ssl_amd import engine, synth, _lib
 dev = torch.device("cuda:0")
-L = _lib.lib()
+L = _lib.lib_prof()   # profiling build (-DSSG_PROFILE): the product library has no ablation switch
 sr_np, gt_np, mask_np = synth.make_batch(16, 256, 256)
 sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
 n = int(mask_np.sum())

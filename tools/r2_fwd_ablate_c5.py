@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from ssl_amd import engine, synth, _lib
 dev = torch.device("cuda:0")
-L = _lib.lib()
+L = _lib.lib_prof()   # profiling build (-DSSG_PROFILE): the product library has no ablation switch
 H = W = 512
 gt_np = synth.natural_like(300, H, W)[None]
 sr_np = synth.degrade(gt_np[0], 7)[None]
