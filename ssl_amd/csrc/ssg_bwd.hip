@@ -337,11 +337,13 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
         for (int j = 0; j < BS; ++j) acc[i][j] = 0.f;
       if (SSG_DBG(p, 2)) {
       } else if constexpr (KW <= 9) {
+        // flipped stencil, one row per patch row: row kh is live during r = kh .. kh + BS - 1 only (see ssg_fwd.hip)
         float af[KW][KW];
-#pragma unroll
-        for (int kh = 0; kh < KW; ++kh)
+        auto load_af = [&](int kh) {
 #pragma unroll
           for (int kx = 0; kx < KW; ++kx) af[kh][kx] = ac[(KW - 1 - kh) * KW + (KW - 1 - kx)];
+        };
+        load_af(0);
         float bn[PW];
         load_grow<G>(tg, zrow, ry0, cx0, bn);
 #pragma unroll
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
 #pragma unroll
           for (int j = 0; j < PW; ++j) bv[j] = bn[j];
           if (r + 1 < PW) load_grow<G>(tg, zrow, ry0 + r + 1, cx0, bn);
+          if (r + 1 < KW) load_af(r + 1);
 #pragma unroll
           for (int i = 0; i < BS; ++i) {
             const int kh = r - i;

@@ -214,11 +214,18 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   for (int c = 0; c < (SSG_DBG(p, 2) ? 0 : C); ++c) {
     const float *tc = tjob + c * chs;
     if constexpr (KW <= 9) {
-      float a[KW][KW];  // centre window of this channel (uniform across the job's lanes)
-#pragma unroll
-      for (int kh = 0; kh < KW; ++kh)
+      // centre window of this channel (uniform across the job's lanes: LDS broadcast reads).  Window row kh meets
+      // patch row r for the block rows i = r - kh, i.e. during r = kh .. kh + BS - 1 only: it is fetched one patch row
+      // ahead of its first use and dead BS rows later, so BS + 1 of the k_w rows are live at a time (54 instead of
+      // 81 registers at k_w 9: the kernel drops under 128 VGPRs, 4 waves per SIMD instead of 3 -- a wave issues a
+      // VALU instruction at most every ~4 cycles while the SIMD-32 takes one every 2, so the waves in flight are
+      // what fills the pipe)
+      float a[KW][KW];
+      auto load_a = [&](int kh) {
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) a[kh][kx] = tc[(HP - HK + kh) * rs + (HP - HK + kx)];
+      };
+      load_a(0);
       // software pipeline: patch row r+1 is in flight while row r is consumed;
       // pin_block keeps hipcc from hoisting every row's loads to the top (which blew
       // the VGPR budget and spilled ~380 dwords per lane).
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
 #pragma unroll
         for (int j = 0; j < PW; ++j) bv[j] = bn[j];
         if (r + 1 < PW) load_row<G>(tc, rs, zrow, ry0 + r + 1, cx0, colv, bn);
+        if (r + 1 < KW) load_a(r + 1);
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
           const int kh = r - i;
