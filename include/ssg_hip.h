@@ -299,6 +299,36 @@ size_t ssg_usm_scratch_bytes(int B, int C, int H, int W);
 int ssg_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int radius, float sigma, float weight,
                   float threshold, void *scratch, size_t scratch_bytes, ssg_stream_t stream);
 
+/* The element-wise / gather stages of the degradation chain (realesrganssl_model.py:168-297) between the kernels above
+ * (ssl_amd/csrc/ssg_degrade.hip).  All take device pointers, launch on `stream`, never synchronise.
+ *
+ * ssg_resize: torch.nn.functional.interpolate(img, scale_factor=s | size=(Ho, Wo), mode) as the model calls it
+ *   (:185,203,224,255,280,293; align_corners=False, antialias=False): mode 0 'area' (adaptive average pooling),
+ *   1 'bilinear', 2 'bicubic' (A = -0.75).  scale_factor_h / _w: the scale_factor the caller would have passed to
+ *   F.interpolate (the source coordinates then use 1 / scale_factor like torch, not Hi / Ho), or 0 for the size= form;
+ *   Ho, Wo are always given (floor(Hi * scale_factor) for the scale_factor form).  out != img. */
+int ssg_resize(const float *img, float *out, int B, int C, int Hi, int Wi, int Ho, int Wo, int mode,
+               double scale_factor_h, double scale_factor_w, ssg_stream_t stream);
+/* clip && rounds: torch.clamp((x * 255.0).round(), 0, 255) / 255. (realesrganssl_model.py:206,297; round half to even);
+ * clip only: clamp(x, 0, 1); rounds only: (x * 255).round() / 255 -- the tail of add_*_noise_pt, degradations.py:501-507. */
+int ssg_clamp_round(const float *img, float *out, size_t n, int clip, int rounds, ssg_stream_t stream);
+/* add_gaussian_noise_pt (basicsr/data/degradations.py:455-507) with the random fields passed in: field_color (B,C,H,W) =
+ * the torch.randn(b,c,h,w) draw, field_gray (H,W) = the torch.randn(h,w) draw (one field for the whole batch, as the
+ * reference's broadcast has it) or NULL when no sample has gray noise; sigma (B), gray (B) in {0,1} on the device. */
+int ssg_gaussian_noise(const float *img, float *out, const float *field_color, const float *field_gray,
+                       const float *sigma, const float *gray, int B, int C, int H, int W, int clip, int rounds,
+                       ssg_stream_t stream);
+/* add_poisson_noise_pt (degradations.py:601-674) around the torch.poisson draws.  ssg_poisson_rates: the per-sample
+ * level census (the reference's torch.unique, a host loop there), vals = 2^ceil(log2(levels)) -> vals (B,2) =
+ * (colour, gray), and the rates img_r * vals the draws are taken from (rate_gray (B,1,H,W) nullable: only when a
+ * sample has gray noise; C must be 3 then).  ssg_poisson_noise: the arithmetic after the draws. */
+size_t ssg_poisson_scratch_bytes(int B);
+int ssg_poisson_rates(const float *img, float *rate_color, float *rate_gray, float *vals, void *scratch, int B, int C,
+                      int H, int W, ssg_stream_t stream);
+int ssg_poisson_noise(const float *img, float *out, const float *draw_color, const float *draw_gray, const float *vals,
+                      const float *scale, const float *gray, int B, int C, int H, int W, int clip, int rounds,
+                      ssg_stream_t stream);
+
 #ifdef SSG_PROFILE
 /* PROFILING BUILD ONLY (libssg_hip_prof.so, compiled with -DSSG_PROFILE; the product library libssg_hip.so does not
  * export this symbol and has no code path that skips work).  Results are WRONG while a mask is set: skip kernel

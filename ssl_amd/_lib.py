@@ -49,6 +49,12 @@ PROTOTYPES = {
                               _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ssg_augment_crop": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssg_pool_swap": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
+    "ssg_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),
+    "ssg_clamp_round": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
+    "ssg_gaussian_noise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ssg_poisson_scratch_bytes": (_sz, [_i]),
+    "ssg_poisson_rates": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ssg_poisson_noise": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssg_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
     # include/similarity.h: the reference operator's own (void, stream-less) interface
     "ssg_ref_compute_similarity": (None, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),

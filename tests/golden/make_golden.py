@@ -656,8 +656,248 @@ def f14_diffjpeg():
     save("f14_diffjpeg", **out)
 
 
+def f15_resize():
+    """F15: the resizes of the degradation chain exactly as the reference calls them
+    (realesrganssl_model.py:185,203,224,255,280,293): torch.nn.functional.interpolate(out, scale_factor=s | size=(h, w),
+    mode='area' | 'bilinear' | 'bicubic') -- torch itself is the implementation the reference runs, so the fixture is
+    torch's own CPU result, in fp32 (what a CPU run of the reference produces) and fp64 (the yardstick)."""
+    rng = np.random.default_rng(1515)
+    img = (np.round(rng.random((1, 3, 37, 45)) * 255) / 255).astype(np.float32)
+    img = np.concatenate([img, img[:, ::-1, ::-1, ::-1] * np.float32(0.5)], 0)[:, :2]     # (2 samples, 2 channels)
+    out = dict(img=img)
+    cases = [("sf0.37", dict(scale_factor=0.37)), ("sf1.43", dict(scale_factor=1.43)), ("sf0.15", dict(scale_factor=0.15)),
+             ("sf0.9", dict(scale_factor=0.9)), ("sf1", dict(scale_factor=1)), ("sz9x11", dict(size=(9, 11))),
+             ("sz50x61", dict(size=(50, 61))), ("sz37x45", dict(size=(37, 45)))]
+    out["cases"] = np.array([c[0] for c in cases])
+    for mode in ("area", "bilinear", "bicubic"):
+        for tag, kw in cases:
+            o32 = F.interpolate(torch.as_tensor(img), mode=mode, **kw).numpy()
+            o64 = F.interpolate(torch.as_tensor(img).double(), mode=mode, **kw).numpy()
+            out[f"{mode}_{tag}_32"] = o32
+            if tag in ("sf0.37", "sf1.43", "sz9x11"):      # (fp64 results for three cases per mode: fixture size)
+                out[f"{mode}_{tag}_64"] = o64
+    save("f15_resize", **out)
+
+
+class _Recorder:
+    """Proxy for a module (torch / numpy.random / random): the listed callables are logged (name, result) in call
+    order, everything else passes through."""
+
+    def __init__(self, mod, names, log, prefix):
+        self._mod, self._names, self._log, self._prefix = mod, set(names), log, prefix
+
+    def __getattr__(self, name):
+        attr = getattr(self._mod, name)
+        if name in self._names:
+            def wrapped(*a, **k):
+                r = attr(*a, **k)
+                self._log.append((self._prefix + name, r.clone() if torch.is_tensor(r) else r))
+                return r
+            return wrapped
+        return attr
+
+
+def _load_degradations(log):
+    """basicsr/data/degradations.py imported by path.  cv2 (unused by the *_pt functions) is an empty stub;
+    torchvision's rgb_to_grayscale (not installed) is restated with its documented formula (0.2989 R + 0.587 G +
+    0.114 B); the module's `torch` is a recorder for randn / rand / poisson."""
+    saved = {k: sys.modules.get(k) for k in ("cv2", "torchvision", "torchvision.transforms",
+                                             "torchvision.transforms.functional_tensor")}
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    ft = types.ModuleType("torchvision.transforms.functional_tensor")
+    ft.rgb_to_grayscale = lambda img, num_output_channels=1: (0.2989 * img[..., 0:1, :, :] + 0.587 * img[..., 1:2, :, :] +
+                                                               0.114 * img[..., 2:3, :, :]).to(img.dtype)
+    for name in ("torchvision", "torchvision.transforms"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.transforms.functional_tensor"] = ft
+    spec = importlib.util.spec_from_file_location("ref_degradations", "/root/reference/GAN-Based-SR/basicsr/data/degradations.py")
+    deg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(deg)
+    for k, v in saved.items():
+        if v is not None:
+            sys.modules[k] = v
+        else:
+            sys.modules.pop(k, None)
+    deg.torch = _Recorder(torch, ("randn", "rand", "poisson"), log, "torch.")
+    return deg
+
+
+def f16_noise():
+    """F16: the reference's random_add_gaussian_noise_pt / random_add_poisson_noise_pt
+    (basicsr/data/degradations.py:544-548, 714-720 and what they call) run on the CPU in fp32 with every torch.rand /
+    torch.randn / torch.poisson draw recorded, for batches with and without gray-noise samples."""
+    log = []
+    deg = _load_degradations(log)
+    rng = np.random.default_rng(1616)
+    img = (rng.random((3, 3, 20, 28)) * 1.1 - 0.05).astype(np.float32)      # (un-clamped input, like the chain's)
+    out = dict(img=img)
+    for tag, fn, kw in (("gauss_gray", deg.random_add_gaussian_noise_pt, dict(sigma_range=[1, 30], gray_prob=0.6)),
+                        ("gauss_color", deg.random_add_gaussian_noise_pt, dict(sigma_range=[1, 30], gray_prob=0.0)),
+                        ("gauss_round", deg.random_add_gaussian_noise_pt, dict(sigma_range=[1, 30], gray_prob=0.6, rounds=True)),
+                        ("poisson_gray", deg.random_add_poisson_noise_pt, dict(scale_range=[0.05, 3], gray_prob=0.6)),
+                        ("poisson_color", deg.random_add_poisson_noise_pt, dict(scale_range=[0.05, 3], gray_prob=0.0))):
+        for seed in range(100):
+            torch.manual_seed(1600 + seed)
+            del log[:]
+            o = fn(torch.as_tensor(img), clip=True, **kw)
+            names = [n for n, _ in log]
+            want_gray = "gray" in tag or "round" in tag
+            has_gray = len(names) == 4
+            if has_gray == want_gray and (not want_gray or 0 < float((log[1][1] < kw["gray_prob"]).sum()) < 3):
+                break
+        out[tag + "_out"] = o.numpy()
+        out[tag + "_draws"] = np.array(names)
+        for i, (n, v) in enumerate(log):
+            out[f"{tag}_d{i}"] = v.numpy()
+        out[tag + "_range"] = np.array(kw.get("sigma_range", kw.get("scale_range")), np.float64)
+        out[tag + "_gray_prob"] = kw["gray_prob"]
+        print("f16", tag, names, o.shape)
+    save("f16_noise", **out)
+
+
+def f17_feed_data():
+    """F17: the reference's `feed_data` (basicsr/models/realesrganssl_model.py:148-316) itself -- the
+    method's source is read from the reference at generation time and executed on a bare object on the CPU (fp32),
+    with the reference's own filter2D / USMSharp (img_process_util.py), DiffJPEG (diffjpeg.py), noise functions
+    (degradations.py) and paired_random_crop_img_mask (transforms.py) bound into its namespace, and EVERY random draw
+    (random.choices / choice / randint, np.random.uniform, torch.rand / randn / poisson / randperm, the JPEG quality
+    tensors) recorded in call order.  Run A uses the options of options/train/RealESRGANSSL/train_RealESRGANSSL_x4.yml
+    (Use_sharpen unset); run B switches USM sharpening on and widens the ranges so that the other noise kind, gray
+    noise and the other JPEG / resize-back order are exercised.  Third-party stand-ins as in F12 / F16: cv2's Gaussian
+    kernel and flip, torchvision's rgb_to_grayscale, by their documented formulas."""
+    import inspect
+    import random
+    import re
+    from oracle import datapath_oracle as dorc
+    log = []
+    deg = _load_degradations(log)
+    cv2 = types.ModuleType("cv2")
+    cv2.getGaussianKernel = lambda ksize, sigma: dorc.gaussian_kernel_1d(int(ksize), float(sigma)).reshape(-1, 1)
+    saved = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    ipu = load("ref_ipu17", "/root/reference/GAN-Based-SR/basicsr/utils/img_process_util.py")
+    dj = load("ref_dj17", "/root/reference/GAN-Based-SR/basicsr/utils/diffjpeg.py")
+    tr = load("ref_tr17", "/root/reference/GAN-Based-SR/basicsr/data/transforms.py")
+    if saved is not None:
+        sys.modules["cv2"] = saved
+    else:
+        del sys.modules["cv2"]
+    tr.random = _Recorder(random, ("randint",), log, "random.")
+    src = open("/root/reference/GAN-Based-SR/basicsr/models/realesrganssl_model.py").read()
+
+    def method(name):
+        m = re.search(r"    def %s\(self.*?\):.*?(?=\n    def |\n    @)" % name, src, re.S)
+        return inspect.cleandoc("\n" + m.group(0)).replace(".cuda()", "")
+
+    ns = {"torch": _Recorder(torch, ("randperm",), log, "torch."), "F": F,
+          "np": types.SimpleNamespace(random=_Recorder(np.random, ("uniform",), log, "np.random.")),
+          "random": _Recorder(random, ("choices", "choice"), log, "random."),
+          # (.contiguous(): DiffJPEG returns a permuted view and, on the CPU, reflect-padding it keeps that layout, which
+          # filter2D's .view() refuses; values are unaffected)
+          "filter2D": lambda img, k: ipu.filter2D(img.contiguous(), k), "random_add_gaussian_noise_pt": deg.random_add_gaussian_noise_pt,
+          "random_add_poisson_noise_pt": deg.random_add_poisson_noise_pt,
+          "paired_random_crop_img_mask": tr.paired_random_crop_img_mask}
+    exec(method("feed_data"), ns)
+    exec(method("_dequeue_and_enqueue"), ns)
+    jpeger = dj.DiffJPEG(differentiable=False)
+
+    def jpeg(x, quality):
+        log.append(("jpeg_q", quality.clone()))      # (the module overwrites `quality` with its factors)
+        return jpeger(x, quality=quality)
+
+    base = dict(degradation_order="two", scale=4, Use_sharpen=None, Sharpen_before_degra=False,
+                resize_prob=[0.1, 0.85, 0.05], resize_range=[0.9, 1.1], gaussian_noise_prob=0.5, noise_range=[1, 8],
+                poisson_scale_range=[0.05, 0.5], gray_noise_prob=0.2, jpeg_range=[85, 95], second_blur_prob=0.8,
+                resize_prob2=[0.1, 0.85, 0.05], resize_range2=[0.9, 1.1], gaussian_noise_prob2=0.5, noise_range2=[0, 4],
+                poisson_scale_range2=[0, 0.3], gray_noise_prob2=0.2, jpeg_range2=[87, 95], queue_size=4,
+                datasets=dict(train=dict(gt_size=64)))
+    wide = dict(base, Use_sharpen=True, Sharpen_before_degra=True, resize_prob=[0.3, 0.5, 0.2], resize_range=[0.5, 1.4],
+                noise_range=[1, 30], poisson_scale_range=[0.05, 3], gray_noise_prob=0.5, jpeg_range=[30, 95],
+                resize_prob2=[0.3, 0.4, 0.3], resize_range2=[0.4, 1.2], noise_range2=[1, 25],
+                poisson_scale_range2=[0.05, 2.5], gray_noise_prob2=0.5, jpeg_range2=[30, 95])
+    rng = np.random.default_rng(1717)
+    B, S = 2, 96
+    gt = np.stack([synth.natural_like(1700 + i, S, S, 0.12, 0.04) for i in range(B)]).astype(np.float32)
+    mask = np.stack([synth.laplacian_edge_mask(gt[i])[None] for i in range(B)]).astype(np.float32)
+
+    def kern():
+        a = rng.random((B, 9, 9)) ** 4
+        return (a / a.sum(axis=(1, 2), keepdims=True)).astype(np.float32)
+
+    k1, k2 = kern(), kern()
+    yy, xx = np.mgrid[-4:5, -4:5]
+    rr = np.sqrt(yy * yy + xx * xx) + 1e-6
+    sinc = np.sin(1.6 * rr) / rr
+    sk = np.stack([sinc / sinc.sum(), np.eye(81)[40].reshape(9, 9)]).astype(np.float32)   # a sinc filter and the pulse
+    out = dict(gt=gt, mask=mask, kernel1=k1, kernel2=k2, sinc_kernel=sk)
+
+    def run(opt, seed):
+        del log[:]
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        obj = types.SimpleNamespace(device="cpu", opt=opt, queue_size=opt["queue_size"], jpeger=jpeg,
+                                    usm_sharpener=ipu.USMSharp())
+        obj._dequeue_and_enqueue = lambda: ns["_dequeue_and_enqueue"](obj)
+        data = {k: torch.as_tensor(v.copy()) for k, v in (("gt", gt), ("gt_mask", mask), ("kernel1", k1),
+                                                          ("kernel2", k2), ("sinc_kernel", sk))}
+        with torch.no_grad():            # (the method's @torch.no_grad() decorator is not part of the extracted source)
+            ns["feed_data"](obj, data)
+        return obj, list(log)
+
+    def pattern(lg):
+        names = [n for n, _ in lg]
+        u = [v for n, v in lg if n == "np.random.uniform"]
+        return names, u
+
+    want = {"A": lambda names, lg: names.count("torch.randn") >= 1 and names.count("torch.poisson") >= 1,
+            "B": lambda names, lg: names.count("torch.poisson") == 2 or names.count("torch.randn") == 2}
+    for tag, opt in (("A", base), ("B", wide)):
+        for seed in range(1700, 1900):
+            obj, lg = run(opt, seed)
+            names = [n for n, _ in lg]
+            # A: one Gaussian and one Poisson stage; B: a stage with gray noise (4 tensor draws) and the JPEG-first order
+            if tag == "A":
+                i = names.index("jpeg_q", names.index("jpeg_q") + 1)
+                resize_first = names[i - 1] == "random.choice"                # [resize back + sinc] before the JPEG
+                if not (names.count("torch.randn") >= 1 and names.count("torch.poisson") >= 1 and resize_first):
+                    continue
+            if tag == "B":
+                i = names.index("jpeg_q", names.index("jpeg_q") + 1)          # second JPEG: directly followed by the
+                jpeg_first = names[i + 1:i + 2] == ["random.choice"]          # resize-back mode draw <=> JPEG first
+                gray = any(names[j:j + 4] in (["torch.rand", "torch.rand", "torch.randn", "torch.randn"],
+                                               ["torch.rand", "torch.rand", "torch.poisson", "torch.poisson"])
+                           for j in range(len(names)))
+                if not (jpeg_first and gray):
+                    continue
+            break
+        else:
+            raise RuntimeError("no seed with the wanted draw pattern for run " + tag)
+        print(f"f17 run {tag}: seed {seed}, {len(lg)} draws:", [n.split('.')[-1] for n in names])
+        out[f"{tag}_seed"] = seed
+        out[f"{tag}_opt"] = np.array([repr(opt)])
+        out[f"{tag}_draw_names"] = np.array(names)
+        for i, (n, v) in enumerate(lg):
+            if torch.is_tensor(v):
+                v = v.numpy()
+            elif isinstance(v, list):
+                v = np.array(v)
+            out[f"{tag}_d{i}"] = np.asarray(v)
+        out[f"{tag}_lq"], out[f"{tag}_gt"], out[f"{tag}_mask"] = obj.lq.numpy(), obj.gt.numpy(), obj.gt_mask.numpy()
+        if opt["Use_sharpen"] is not None:
+            out[f"{tag}_gt_usm"] = obj.gt_usm.numpy()
+    save("f17_feed_data", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14"]
+    which = sys.argv[1:] or ["f1", "f2s", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16", "f17"]
     torch.manual_seed(0)
     if "f1" in which:
         f1_c1()
@@ -687,5 +927,11 @@ if __name__ == "__main__":
         f13_filter2d()
     if "f14" in which:
         f14_diffjpeg()
+    if "f15" in which:
+        f15_resize()
+    if "f16" in which:
+        f16_noise()
+    if "f17" in which:
+        f17_feed_data()
     if "time" in which:
         cpu_reference_timing()

@@ -296,3 +296,78 @@ def test_f14_diffjpeg_oracle_vs_reference(golden):
     _close(dp.diffjpeg(g["img"], 50), g["out32_s"], 1e-6)
     assert np.abs(g["out32_t"][0] - g["img"][0]).max() > 0.02 > np.abs(g["out32_t"][2] - g["img"][2]).mean()
     assert abs(dp.jpeg_quality_to_factor(20) - 2.5) < 1e-12 and abs(dp.jpeg_quality_to_factor(90) - 0.2) < 1e-12
+
+
+def _f15_kwargs(tag):
+    return dict(scale_factor=float(tag[2:])) if tag.startswith("sf") else dict(size=tuple(int(v) for v in tag[2:].split("x")))
+
+
+def test_f15_resize_oracle_vs_torch(golden):
+    """F15: F.interpolate as the degradation chain calls it (three modes, scale_factor= and size= forms, down to 0.15x
+    and up to 1.43x).  The fp64 restatement reproduces torch's fp64 run to rounding (the semantics are right); the
+    fp32 one is within 3e-6 of torch's fp32 run -- the distance torch's own fp32 result keeps from its fp64 one (the
+    source coordinates are rounded to fp32)."""
+    from oracle import datapath_oracle as dorc
+    g = golden("f15_resize")
+    img = g["img"]
+    for mode in ("area", "bilinear", "bicubic"):
+        for tag in g["cases"]:
+            kw = _f15_kwargs(str(tag))
+            o32 = dorc.interpolate(img, mode=mode, **kw)
+            assert o32.shape == g[f"{mode}_{tag}_32"].shape
+            assert np.abs(o32 - g[f"{mode}_{tag}_32"]).max() <= 3e-6
+            if f"{mode}_{tag}_64" in g.files:
+                o64 = dorc.interpolate(img, mode=mode, dtype=np.float64, **kw)
+                assert np.abs(o64 - g[f"{mode}_{tag}_64"]).max() <= 1e-13
+
+
+def _f16_case(g, tag):
+    names = list(g[tag + "_draws"])
+    dr = [g[f"{tag}_d{i}"] for i in range(len(names))]
+    lo, hi = g[tag + "_range"]
+    par = (dr[0] * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)
+    gray = (dr[1] < float(g[tag + "_gray_prob"])).astype(np.float32)
+    return par, gray, dr[-1], (dr[2] if len(dr) == 4 else None)
+
+
+def test_f16_noise_oracle_vs_reference_bit_exact(golden):
+    """F16: random_add_gaussian_noise_pt / random_add_poisson_noise_pt of the reference's degradations.py with their
+    torch.rand / randn / poisson draws recorded: the fp32 restatement of the arithmetic around the draws is bit exact,
+    with and without gray-noise samples, clip and clip + rounds."""
+    from oracle import datapath_oracle as dorc
+    g = golden("f16_noise")
+    img = g["img"]
+    for tag in ("gauss_gray", "gauss_color", "gauss_round", "poisson_gray", "poisson_color"):
+        par, gray, fc, fg = _f16_case(g, tag)
+        assert (gray.sum() > 0) == (fg is not None)
+        if tag.startswith("gauss"):
+            o = dorc.gaussian_noise(img, par, gray, fc, fg, True, "round" in tag)
+        else:
+            o = dorc.poisson_noise(img, par, gray, fc, fg, True, False)
+        assert np.array_equal(o, g[tag + "_out"]), tag
+
+
+def _f17_run(g, tag):
+    from oracle import datapath_oracle as dorc
+    opt = eval(str(g[f"{tag}_opt"][0]), {"__builtins__": {}}, {})       # (a dict literal written by make_golden.py)
+    names = list(g[f"{tag}_draw_names"])
+    vals = [g[f"{tag}_d{i}"] for i in range(len(names))]
+    return opt, dorc.RecordedDraws(names, vals)
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_f17_feed_data_oracle_vs_reference(golden, tag):
+    """F17: the reference's feed_data (realesrganssl_model.py:148-316) executed on the CPU with every random draw
+    recorded; the composition of the oracle's stages, replaying the draws, reproduces its LQ batch pixel for pixel
+    (values are multiples of 1/255 after the final clamp-round), the GT / mask crops exactly and the sharpened GT to
+    fp32 rounding.  Run A: the training YAML's options, Gaussian then Poisson noise, [resize back + sinc] before the
+    JPEG; run B: USM sharpening on, wide ranges, gray Poisson noise, JPEG first."""
+    from oracle import datapath_oracle as dorc
+    g = golden("f17_feed_data")
+    opt, draws = _f17_run(g, tag)
+    r = dorc.feed_data(g["gt"], g["mask"], g["kernel1"], g["kernel2"], g["sinc_kernel"], opt, draws, np.float32)
+    assert draws.done()
+    assert np.abs(r["lq"] - g[f"{tag}_lq"]).max() * 255 <= 1e-3
+    assert np.array_equal(r["gt"].astype(np.float32), g[f"{tag}_gt"]) and np.array_equal(r["mask"], g[f"{tag}_mask"])
+    if opt["Use_sharpen"] is not None:
+        assert np.abs(r["gt_usm"] - g[f"{tag}_gt_usm"]).max() <= 3e-6
