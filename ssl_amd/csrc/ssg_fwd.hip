@@ -33,7 +33,10 @@ __device__ __forceinline__ void load_row(const float *tc, int rs, const float *z
   }
 }
 
-// MERGED = false: every job stages its own C x k_s x k_s search tile in LDS.
+// MERGED = false: every job stages its own k_s x k_s search tile in LDS, ONE CHANNEL AT A TIME (the channel loop below
+//                 refills the tiles: 13 KB instead of 40 KB per workgroup at k_s 25, i.e. the registers, not the LDS,
+//                 bound the waves per SIMD -- measured on this variant: 1.2 waves per SIMD on average and 32 % VALU
+//                 issue with all channels resident).
 // MERGED = true : the workgroup's jobs are edge pixels of ONE image within 8 rows x 16 columns
 //                 (the usual case in the tile-major job order): their search areas are read from
 //                 one shared LDS region of at most 32 x 40 pixels per channel -- 2.4x fewer fill
@@ -41,7 +44,7 @@ __device__ __forceinline__ void load_row(const float *tc, int rs, const float *z
 //                 SIMD).  Both variants are launched over the same job groups; a group runs in the
 //                 variant its geometry selects and exits at once in the other.
 template <class G, bool MERGED>
-__global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
+__global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void ssg_fwd_tiled(FwdParams p) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
   constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
   constexpr int JOBS = G::JOBS, PW = G::PW, S = G::S, CH = G::CH;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   float *tiles = smem + PADF;                                      // [JOBS][C][KS][S] or [C][MH][MS]
   // (merged: the shared region is reused to stage the JOBS output rows, whichever is larger)
   const int merged_floats = (C * MH * MS > JOBS * P ? C * MH * MS : JOBS * P + 1) & ~1;
-  float *zero = tiles + (MERGED ? merged_floats : JOBS * C * CH);  // ZROW zeros (also absorbs tail over-reads)
+  float *zero = tiles + (MERGED ? merged_floats : JOBS * CH);      // ZROW zeros (also absorbs tail over-reads)
   double *red = (double *)(zero + ((G::ZROW + 3) & ~3));           // [WG] row-sum scratch (8-byte aligned)
   int *sh_edge = (int *)(red + WG);                                // [JOBS][6]: b, y, x, row, which, pad
 
@@ -145,47 +148,32 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
           if (d[h] >= 0 && rx < ww) tiles[d[h] + rx] = v[h][k];
         }
     }
-  } else {
-  // ---- fill: JOBS x C x KS x KS floats, reflect by index mirroring.  All global loads of a
-  // job are issued before the first LDS store (a plain loop pays the full L2 latency per
-  // element: the fill was 29 % of the kernel) ----
-  constexpr int EPT = (P + WG - 1) / WG;  // tile elements per thread per channel
-  for (int j = 0; j < (SSG_DBG(p, 1) ? 0 : JOBS); ++j) {
-    const float *src = p.img[sh_edge[j * 6 + 4]];
-    const int b = sh_edge[j * 6 + 0], y = sh_edge[j * 6 + 1], x = sh_edge[j * 6 + 2];
-    const float *s0[EPT];
-    int d0[EPT];
+  }
+  // ---- single variant: the jobs' k_s x k_s tiles of ONE channel, reflect by index mirroring.  All global loads (JOBS x
+  // EPT per thread) are issued before the first LDS store (a plain loop pays the full L2 latency per element) ----
+  auto fill_channel = [&](int c) {
+    constexpr int EPT = (P + WG - 1) / WG;  // tile elements per thread
+    float v[JOBS][EPT];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int e = tid + k * WG;
-      const int ec = e < P ? e : P - 1;
-      const int ry = ec / KS, rx = ec - ry * KS;
-      s0[k] = src + ((size_t)b * C * H + reflect_idx(y - HP + ry, H)) * W + reflect_idx(x - HP + rx, W);
-      d0[k] = e < P ? (j * C) * CH + ry * S + rx : -1;
-    }
-    if (C == 3) {
-      float v[EPT][3];
+    for (int j = 0; j < JOBS; ++j) {
+      const float *src = p.img[sh_edge[j * 6 + 4]];
+      const int b = sh_edge[j * 6 + 0], y = sh_edge[j * 6 + 1], x = sh_edge[j * 6 + 2];
 #pragma unroll
-      for (int k = 0; k < EPT; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) v[k][c] = s0[k][(size_t)c * H * W];
-#pragma unroll
-      for (int k = 0; k < EPT; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          if (d0[k] >= 0) tiles[d0[k] + c * CH] = v[k][c];
-    } else {
-      for (int c = 0; c < C; ++c) {
-        float v[EPT];
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) v[k] = s0[k][(size_t)c * H * W];
-#pragma unroll
-        for (int k = 0; k < EPT; ++k)
-          if (d0[k] >= 0) tiles[d0[k] + c * CH] = v[k];
+      for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * WG;
+        const int ec = e < P ? e : P - 1;
+        const int ry = ec / KS, rx = ec - ry * KS;
+        v[j][k] = src[(((size_t)b * C + c) * H + reflect_idx(y - HP + ry, H)) * W + reflect_idx(x - HP + rx, W)];
       }
     }
-  }
-  }
+#pragma unroll
+    for (int j = 0; j < JOBS; ++j)
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * WG;
+        if (e < P) tiles[j * CH + (e / KS) * S + e % KS] = v[j][k];
+      }
+  };
   __syncthreads();
 
   // ---- per-lane block ----
@@ -208,11 +196,15 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
   const float *zrow = zero + HK;
   // per-job tile origin, row stride and channel stride inside LDS
   const int rs = MERGED ? MS : S, chs = MERGED ? MH * MS : CH;
-  const float *tjob = MERGED ? tiles + (sh_edge[jl * 6 + 1] - my0) * MS + (sh_edge[jl * 6 + 2] - mx0)
-                             : tiles + (jl * C) * CH;
+  const float *tjob = MERGED ? tiles + (sh_edge[jl * 6 + 1] - my0) * MS + (sh_edge[jl * 6 + 2] - mx0) : tiles + jl * CH;
 #pragma unroll 1
   for (int c = 0; c < (SSG_DBG(p, 2) ? 0 : C); ++c) {
-    const float *tc = tjob + c * chs;
+    if constexpr (!MERGED) {
+      if (c > 0) __syncthreads();               // every lane is done with the previous channel's tiles
+      if (!SSG_DBG(p, 1)) fill_channel(c);
+      __syncthreads();
+    }
+    const float *tc = MERGED ? tjob + c * chs : tjob;
     if constexpr (KW <= 9) {
       // centre window of this channel (uniform across the job's lanes: LDS broadcast reads).  Window row kh meets
       // patch row r for the block rows i = r - kh, i.e. during r = kh .. kh + BS - 1 only: it is fetched one patch row
@@ -347,7 +339,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
 #pragma unroll
       for (int j = 0; j < BS; ++j) acc[i][j] = (float)((double)acc[i][j] * scale);
   }
-  float *stage = tiles + (MERGED ? jl * P : (jl * C) * CH);  // >= P floats per job
+  float *stage = tiles + (MERGED ? jl * P : jl * CH);  // >= P floats per job
   if (lane_on) {
 #pragma unroll
     for (int i = 0; i < BS; ++i)
@@ -362,7 +354,7 @@ __global__ __launch_bounds__(G::WG) void ssg_fwd_tiled(FwdParams p) {
     const int row = sh_edge[j * 6 + 3];
     if (row < 0) continue;
     float *o = p.out[sh_edge[j * 6 + 4]] + (size_t)row * P;
-    const float *sj = tiles + (MERGED ? j * P : (j * C) * CH);
+    const float *sj = tiles + (MERGED ? j * P : j * CH);
     for (int e = tid; e < P; e += WG) o[e] = sj[e];
   }
 }
@@ -425,7 +417,7 @@ static size_t fwd_lds_bytes(int C) {
   constexpr int PADF = (G::HK + 3) & ~3;
   constexpr int MH = G::KS + MERGE_ROWS - 1, MS = G::KS + MERGE_COLS;
   const size_t region = (size_t)C * MH * MS, rows = (size_t)G::JOBS * G::P;
-  const size_t tiles = MERGED ? ((region > rows ? region : rows + 1) & ~(size_t)1) : (size_t)G::JOBS * C * G::CH;
+  const size_t tiles = MERGED ? ((region > rows ? region : rows + 1) & ~(size_t)1) : (size_t)G::JOBS * G::CH;
   return sizeof(float) * (size_t)(PADF + tiles + ((G::ZROW + 3) & ~3) + 4 + 2 * G::WG) + sizeof(int) * 6 * G::JOBS;
 }
 

@@ -14,7 +14,9 @@ def run(name, sr, gt, mask, ks, kw, sigma, iters):
     n = int(mask.sum())
     step = engine.LossStep(B, C, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, capacity=n + 64)
     a, b, m = (torch.as_tensor(x, device=dev) for x in (sr, gt, mask))
-    step(a, b, m); torch.cuda.synchronize()
+    for _ in range(max(3, iters // 5)):     # warm-up like bench.py (the first steps after an idle GPU run ~15 % slower)
+        step(a, b, m)
+    torch.cuda.synchronize()
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
     for _ in range(iters):
@@ -29,12 +31,12 @@ def run(name, sr, gt, mask, ks, kw, sigma, iters):
 sr, gt, m = synth.uniform_case()
 run("C1  1x3x64x64 5% fixed mask k_s=11 k_w=5 sigma=1", sr, gt, m, 11, 5, 1.0, 50)
 sr, gt, m = synth.make_batch(16, 256, 256)
-run("C2  16x3x256x256 Laplacian mask k_s=25 k_w=9 sigma=1.0", sr, gt, m, 25, 9, 1.0, 10)
-run("C2' same, sigma=0.004 (training value)", sr, gt, m, 25, 9, 0.004, 10)
+run("C2  16x3x256x256 Laplacian mask k_s=25 k_w=9 sigma=1.0", sr, gt, m, 25, 9, 1.0, 50)
+run("C2' same, sigma=0.004 (training value)", sr, gt, m, 25, 9, 0.004, 50)
 rng = np.random.default_rng(0)
 for dens in (0.01, 0.04, 0.16, 0.5, 1.0):
     mm = (rng.random((4, 1, 256, 256)) < dens).astype(np.float32)
-    run(f"density sweep 4x3x256x256 Bernoulli {dens:4.2f} k_s=25 k_w=9", sr[:4], gt[:4], mm, 25, 9, 1.0, 3 if dens > 0.3 else 10)
+    run(f"density sweep 4x3x256x256 Bernoulli {dens:4.2f} k_s=25 k_w=9", sr[:4], gt[:4], mm, 25, 9, 1.0, 20 if dens > 0.3 else 50)
 g = synth.natural_like(2000, 512, 512)[None]
 s = synth.degrade(g[0], 2001)[None]
-run("C5  1x3x512x512 DENSE mask k_s=49 k_w=13 sigma=1", s, g, np.ones((1, 1, 512, 512), np.float32), 49, 13, 1.0, 2)
+run("C5  1x3x512x512 DENSE mask k_s=49 k_w=13 sigma=1", s, g, np.ones((1, 1, 512, 512), np.float32), 49, 13, 1.0, 10)
