@@ -20,7 +20,8 @@ const char *bwd_kernel_name(int ks, int kw);
 size_t edge_scratch_bytes(int B, int H, int W);
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
                      int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
-                     int plan_tile_rows, void *scratch, hipStream_t st);
+                     int plan_tile_rows, void *scratch, void *zero_a, size_t zero_a_bytes, void *zero_b,
+                     size_t zero_b_bytes, hipStream_t st);
 size_t fwd_plan_bytes(int B, int H, int W, int capacity);
 int fwd_plan_order_offset(int B, int H, int W);
 struct DenseParams {
@@ -192,7 +193,19 @@ static size_t split_scratch_bytes(int n_rows, int ks) {
 
 // Backward over a forward plan: G rows (+ criteria sums) by ssg_grad_rows, the dense tiles by the shared-term
 // kernel, the remaining rows by the direct kernel in GRAD_D mode.  `p` carries the sources as for launch_bwd.
-static int split_backward(BwdParams p, const int *rank, const int *plan, void *scratch, hipStream_t st) {
+// the loss finalize of a GRAD_LOSS step: it needs ssg_grad_rows' partial sums only, so it is queued on the side stream
+// ahead of the direct backward kernel instead of at the very end of the caller's stream (7 us off the critical path)
+struct FinalizeArgs {
+  const float *partials;
+  int nparts;
+  const int *n_dev;
+  int n_host, P;
+  float w_l1, w_kl;
+  float *loss_out;
+};
+
+static int split_backward(BwdParams p, const int *rank, const int *plan, void *scratch, hipStream_t st,
+                          const FinalizeArgs *fin = nullptr, bool *fin_done = nullptr) {
   float *G = (float *)scratch;
   float *sum_b = (float *)((char *)scratch + align_up(sizeof(float) * (size_t)p.n_host * p.ks * p.ks, 256));
   float *gmax_part = (float *)((char *)sum_b + align_up(sizeof(float) * (size_t)(p.n_host > 0 ? p.n_host : 1), 256));
@@ -241,6 +254,12 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   d.dbg = p.dbg;
   SideStream *fk = nullptr;
   hipStream_t st2 = (dbg_mask() & ((1 << 27) | (1 << 28))) ? st : fork_from(st, p.ks, fk);
+  if (fin && fk && st2 != st) {   // (only when there IS a side stream: on one stream it would only delay the backward)
+    rc = launch_loss_finalize(fin->partials, fin->nparts, fin->n_dev, fin->n_host, fin->P, fin->w_l1, fin->w_kl,
+                              fin->loss_out, st2);
+    if (rc) return rc;
+    if (fin_done) *fin_done = true;
+  }
   rc = (dbg_mask() & (1 << 27)) ? 0 : launch_bwd_dense(d, p.ks, p.kw, p.C, st);
   if (!rc && !(dbg_mask() & (1 << 28))) {
     BwdParams s = p;
@@ -256,10 +275,11 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
 }
 
 // Deterministic mode: the kernels add into the caller's zeroed fixed-point buffer; one flush folds it into grad.
-static int det_begin(BwdParams &p, void *grad_fix, hipStream_t st) {
+static int det_begin(BwdParams &p, void *grad_fix, hipStream_t st, bool prezeroed = false) {
   p.gfix = nullptr;
   if (!grad_fix || !p.grad) return 0;
   p.gfix = (long long *)grad_fix;
+  if (prezeroed) return 0;   // (the fused step: cleared by the edge-list builder's first kernel)
   return (int)hipMemsetAsync(grad_fix, 0, sizeof(long long) * ((size_t)p.B * p.C * p.H * p.W + 8), st);
 }
 static int det_end(const BwdParams &p, hipStream_t st) {
@@ -344,9 +364,10 @@ size_t ssg_edge_scratch_bytes(int B, int H, int W) { return edge_scratch_bytes(B
 
 size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity) { return fwd_plan_bytes(B, H, W, capacity); }
 
-int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
-                  float lap_threshold, int plan_ks, int *edges, int capacity, int *counts, int *rank_map,
-                  int *tile_order, int *fwd_plan, void *scratch, ssg_stream_t stream) {
+static int edge_list_impl(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
+                          float lap_threshold, int plan_ks, int *edges, int capacity, int *counts, int *rank_map,
+                          int *tile_order, int *fwd_plan, void *scratch, void *zero_a, size_t zero_a_bytes, void *zero_b,
+                          size_t zero_b_bytes, ssg_stream_t stream) {
   if (!mask || !edges || !counts || !scratch || B <= 0 || H <= 0 || W <= 0 || capacity < 0 || mask_kind < 0 ||
       mask_kind > 2 || mask_channels <= 0 || ((tile_order || fwd_plan) && !rank_map))
     return SSG_E_BADARG;
@@ -354,7 +375,14 @@ int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int
   // direct order -- so that the kernels consuming it never depend on the process-wide threshold)
   return launch_edge_list(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, edges, capacity,
                           counts, rank_map, tile_order, fwd_plan, dense_threshold(), dense_tile_rows(plan_ks), scratch,
-                          (hipStream_t)stream);
+                          zero_a, zero_a_bytes, zero_b, zero_b_bytes, (hipStream_t)stream);
+}
+
+int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
+                  float lap_threshold, int plan_ks, int *edges, int capacity, int *counts, int *rank_map,
+                  int *tile_order, int *fwd_plan, void *scratch, ssg_stream_t stream) {
+  return edge_list_impl(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, plan_ks, edges, capacity,
+                        counts, rank_map, tile_order, fwd_plan, scratch, nullptr, 0, nullptr, 0, stream);
 }
 
 int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_threshold, int mask_stride,
@@ -363,10 +391,10 @@ int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_thre
   return launch_edge_mask(gt, B, H, W, lap_threshold, mask_stride, mask_out, (hipStream_t)stream);
 }
 
-int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, int W, const int *edges,
-                    const int *tile_order, const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows,
-                    int ks, int kw, float sigma, float eps, int generalization, float *ssg, float *ssg2,
-                    double *row_scale, ssg_stream_t stream) {
+static int map_forward_impl(const float *img, const float *img2, int B, int C, int H, int W, const int *edges,
+                            const int *tile_order, const int *rank_map, const int *fwd_plan, const int *n_edges_dev,
+                            int n_rows, int ks, int kw, float sigma, float eps, int generalization, float *ssg,
+                            float *ssg2, double *row_scale, bool row_scale_zeroed, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -415,7 +443,7 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
     d.generalization = generalization;
     d.dbg = (dbg_mask() >> 16) & 0xff;
     d.row_scale = row_scale;
-    if (row_scale) {   // 0 = "this row is already normalised" (the rows of the direct kernels)
+    if (row_scale && !row_scale_zeroed) {   // 0 = "this row is already normalised" (the rows of the direct kernels)
       const int rc0 = (int)hipMemsetAsync(row_scale, 0, sizeof(double) * 2 * (size_t)n_rows, (hipStream_t)stream);
       if (rc0) return rc0;
     }
@@ -430,6 +458,14 @@ int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, in
     return rc ? rc : rcj;
   }
   return launch_fwd(p, (hipStream_t)stream);
+}
+
+int ssg_map_forward(const float *img, const float *img2, int B, int C, int H, int W, const int *edges,
+                    const int *tile_order, const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows,
+                    int ks, int kw, float sigma, float eps, int generalization, float *ssg, float *ssg2,
+                    double *row_scale, ssg_stream_t stream) {
+  return map_forward_impl(img, img2, B, C, H, W, edges, tile_order, rank_map, fwd_plan, n_edges_dev, n_rows, ks, kw,
+                          sigma, eps, generalization, ssg, ssg2, row_scale, false, stream);
 }
 
 size_t ssg_backward_scratch_bytes(int n_rows, int ks) { return split_scratch_bytes(n_rows, ks); }
@@ -487,7 +523,7 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
                          const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
                          float sigma, int generalization, float *ssg_sr, float *ssg_gt, float w_l1, float w_kl,
                          const float *upstream, float *loss_out, float *grad_sr, void *scratch, void *grad_fix,
-                         const double *row_scale, bool rows_scratch, ssg_stream_t stream) {
+                         const double *row_scale, bool rows_scratch, bool fix_zeroed, ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
@@ -520,19 +556,21 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   p.row_scale = row_scale;
   p.rows_scratch = rows_scratch ? 1 : 0;
   if (row_scale && !split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) return SSG_E_BADARG;  // only ssg_grad_rows rescales
-  int rc = det_begin(p, grad_fix, st);
+  int rc = det_begin(p, grad_fix, st, fix_zeroed);
   if (rc) return rc;
   int nparts;
+  bool fin_done = false;
   if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
-    rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st);
     nparts = (int)grow_grid(n_rows);
+    const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out};
+    rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done);
   } else {
     if (p.gfix) rc = launch_grad_fix_bound(p, st);
     if (!rc) rc = launch_bwd(p, st);
     nparts = (int)bwd_grid(p);
   }
   if (!rc) rc = det_end(p, st);
-  if (rc) return rc;
+  if (rc || fin_done) return rc;
   return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
 }
 
@@ -544,7 +582,7 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
                       int rows_are_scratch, ssg_stream_t stream) {
   return loss_backward(sr, B, C, H, W, edges, tile_order, rank_map, fwd_plan, n_edges_dev, n_rows, ks, kw, sigma,
                        generalization, ssg_sr, ssg_gt, w_l1, w_kl, upstream, loss_out, grad_sr, scratch, grad_fix,
-                       row_scale, rows_are_scratch != 0, stream);
+                       row_scale, rows_are_scratch != 0, false, stream);
 }
 
 size_t ssg_loss_rows_bytes(int capacity, int ks) {
@@ -593,15 +631,20 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   const bool defer = split_ok(ks, kw, C, rank, plan, lscratch) && dense_supported(ks, kw, C);
   // with the plan in use every kernel takes its job order from it: the full tile-major order is not built (3 launches)
   if (defer) order = nullptr;
-  int rc = ssg_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
-                         W, mask_stride, lap_threshold, ks, edges, capacity, counts, rank, order, plan, escratch, stream);
+  // the row scales and the fixed-point gradient sums start at zero: cleared by the edge-list builder's first kernel
+  // (16-byte granules: both sizes are multiples of 16)
+  const bool zero_fix = grad_fix && grad_sr;
+  const size_t fix_bytes = sizeof(long long) * ((size_t)B * C * H * W + 8), rs_bytes = 2 * sizeof(double) * (size_t)capacity;
+  int rc = edge_list_impl(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
+                          W, mask_stride, lap_threshold, ks, edges, capacity, counts, rank, order, plan, escratch,
+                          defer ? (void *)row_scale : nullptr, rs_bytes, zero_fix ? grad_fix : nullptr, fix_bytes, stream);
   if (rc) return rc;
-  rc = ssg_map_forward(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
-                       generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, stream);
+  rc = map_forward_impl(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
+                        generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, defer, stream);
   if (rc) return rc;
   return loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
                        ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix,
-                       defer ? row_scale : nullptr, fused, stream);
+                       defer ? row_scale : nullptr, fused, zero_fix, stream);
 }
 
 int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,
