@@ -257,6 +257,19 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask,
                      void *workspace, size_t workspace_bytes,
                      void *grad_fix /* nullable: deterministic mode */, ssg_stream_t stream);
 
+/* ssg_loss_fwd_bwd with the gradient as an OUTPUT: grad_sr (B,C,H,W) is overwritten with d(l1+kl)/d sr instead of
+ * accumulated into, so the caller does not clear it first (one fill kernel per step less: the deterministic mode's
+ * final fold assigns it, the fp32-atomics mode has it cleared by the edge-list builder's first kernel).  Everything
+ * else as ssg_loss_fwd_bwd.  N == 0 (every mask empty): grad_sr = 0. */
+int ssg_loss_step(const float *sr, const float *gt, const void *mask,
+                  int mask_kind, int mask_channels, int B, int C, int H,
+                  int W, int ks, int kw, float sigma, float eps,
+                  int generalization, float w_l1, float w_kl, int mask_stride,
+                  float lap_threshold, int capacity, float *ssg_sr /* nullable with ssg_gt: fused step */,
+                  float *ssg_gt, int *counts, float *loss_out, float *grad_sr,
+                  void *workspace, size_t workspace_bytes,
+                  void *grad_fix /* nullable: deterministic mode */, ssg_stream_t stream);
+
 /* ---------------------------------------------------------------- (E) ----
  * The step before the loss, on the GPU (minimal slice): joint augmentation + crop of image and mask, and the
  * training pair pool.  Byte moves only, bit exact.

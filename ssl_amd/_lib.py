@@ -47,6 +47,8 @@ PROTOTYPES = {
     "ssg_usm_sharp": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _sz, _vp]),
     "ssg_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,
                               _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "ssg_loss_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _vp, _vp,
+                           _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ssg_augment_crop": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssg_pool_swap": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
     "ssg_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),

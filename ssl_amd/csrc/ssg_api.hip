@@ -21,7 +21,7 @@ size_t edge_scratch_bytes(int B, int H, int W);
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
                      int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
                      int plan_tile_rows, void *scratch, void *zero_a, size_t zero_a_bytes, void *zero_b,
-                     size_t zero_b_bytes, hipStream_t st);
+                     size_t zero_b_bytes, void *zero_c, size_t zero_c_bytes, hipStream_t st);
 size_t fwd_plan_bytes(int B, int H, int W, int capacity);
 int fwd_plan_order_offset(int B, int H, int W);
 struct DenseParams {
@@ -60,7 +60,7 @@ int launch_filter2d(const float *img, const float *kernels, float *out, int B, i
                     hipStream_t st);
 int launch_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int ksize, float sigma, float weight,
                      float threshold, void *scratch, hipStream_t st);
-int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st);
+int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, int assign, hipStream_t st);
 int launch_grad_fix_bound(const BwdParams &p, hipStream_t st);
 int launch_grad_fix_reduce(const float *part, int n, long long *gfix, size_t n_fix, hipStream_t st);
 }  // namespace ssg
@@ -282,9 +282,9 @@ static int det_begin(BwdParams &p, void *grad_fix, hipStream_t st, bool prezeroe
   if (prezeroed) return 0;   // (the fused step: cleared by the edge-list builder's first kernel)
   return (int)hipMemsetAsync(grad_fix, 0, sizeof(long long) * ((size_t)p.B * p.C * p.H * p.W + 8), st);
 }
-static int det_end(const BwdParams &p, hipStream_t st) {
+static int det_end(const BwdParams &p, hipStream_t st, bool assign = false) {
   if (!p.gfix) return 0;
-  return launch_grad_fix_flush(p.gfix, p.grad, (size_t)p.B * p.C * p.H * p.W, st);
+  return launch_grad_fix_flush(p.gfix, p.grad, (size_t)p.B * p.C * p.H * p.W, assign ? 1 : 0, st);
 }
 
 static bool split_ok(int ks, int kw, int C, const int *rank, const int *plan, const void *scratch) {
@@ -367,7 +367,7 @@ size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity) { return fwd_pl
 static int edge_list_impl(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
                           float lap_threshold, int plan_ks, int *edges, int capacity, int *counts, int *rank_map,
                           int *tile_order, int *fwd_plan, void *scratch, void *zero_a, size_t zero_a_bytes, void *zero_b,
-                          size_t zero_b_bytes, ssg_stream_t stream) {
+                          size_t zero_b_bytes, void *zero_c, size_t zero_c_bytes, ssg_stream_t stream) {
   if (!mask || !edges || !counts || !scratch || B <= 0 || H <= 0 || W <= 0 || capacity < 0 || mask_kind < 0 ||
       mask_kind > 2 || mask_channels <= 0 || ((tile_order || fwd_plan) && !rank_map))
     return SSG_E_BADARG;
@@ -375,14 +375,14 @@ static int edge_list_impl(const void *mask, int mask_kind, int mask_channels, in
   // direct order -- so that the kernels consuming it never depend on the process-wide threshold)
   return launch_edge_list(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, edges, capacity,
                           counts, rank_map, tile_order, fwd_plan, dense_threshold(), dense_tile_rows(plan_ks), scratch,
-                          zero_a, zero_a_bytes, zero_b, zero_b_bytes, (hipStream_t)stream);
+                          zero_a, zero_a_bytes, zero_b, zero_b_bytes, zero_c, zero_c_bytes, (hipStream_t)stream);
 }
 
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B, int H, int W, int mask_stride,
                   float lap_threshold, int plan_ks, int *edges, int capacity, int *counts, int *rank_map,
                   int *tile_order, int *fwd_plan, void *scratch, ssg_stream_t stream) {
   return edge_list_impl(mask, mask_kind, mask_channels, B, H, W, mask_stride, lap_threshold, plan_ks, edges, capacity,
-                        counts, rank_map, tile_order, fwd_plan, scratch, nullptr, 0, nullptr, 0, stream);
+                        counts, rank_map, tile_order, fwd_plan, scratch, nullptr, 0, nullptr, 0, nullptr, 0, stream);
 }
 
 int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_threshold, int mask_stride,
@@ -523,7 +523,8 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
                          const int *rank_map, const int *fwd_plan, const int *n_edges_dev, int n_rows, int ks, int kw,
                          float sigma, int generalization, float *ssg_sr, float *ssg_gt, float w_l1, float w_kl,
                          const float *upstream, float *loss_out, float *grad_sr, void *scratch, void *grad_fix,
-                         const double *row_scale, bool rows_scratch, bool fix_zeroed, ssg_stream_t stream) {
+                         const double *row_scale, bool rows_scratch, bool fix_zeroed, bool grad_is_output,
+                         ssg_stream_t stream) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
@@ -569,7 +570,7 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
     if (!rc) rc = launch_bwd(p, st);
     nparts = (int)bwd_grid(p);
   }
-  if (!rc) rc = det_end(p, st);
+  if (!rc) rc = det_end(p, st, grad_is_output);
   if (rc || fin_done) return rc;
   return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
 }
@@ -582,7 +583,7 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
                       int rows_are_scratch, ssg_stream_t stream) {
   return loss_backward(sr, B, C, H, W, edges, tile_order, rank_map, fwd_plan, n_edges_dev, n_rows, ks, kw, sigma,
                        generalization, ssg_sr, ssg_gt, w_l1, w_kl, upstream, loss_out, grad_sr, scratch, grad_fix,
-                       row_scale, rows_are_scratch != 0, false, stream);
+                       row_scale, rows_are_scratch != 0, false, false, stream);
 }
 
 size_t ssg_loss_rows_bytes(int capacity, int ks) {
@@ -597,11 +598,11 @@ size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
          align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
 }
 
-int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,
-                     int C, int H, int W, int ks, int kw, float sigma, float eps, int generalization, float w_l1,
-                     float w_kl, int mask_stride, float lap_threshold, int capacity, float *ssg_sr, float *ssg_gt,
-                     int *counts, float *loss_out, float *grad_sr, void *workspace, size_t workspace_bytes,
-                     void *grad_fix, ssg_stream_t stream) {
+static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,
+                             int C, int H, int W, int ks, int kw, float sigma, float eps, int generalization, float w_l1,
+                             float w_kl, int mask_stride, float lap_threshold, int capacity, float *ssg_sr,
+                             float *ssg_gt, int *counts, float *loss_out, float *grad_sr, void *workspace,
+                             size_t workspace_bytes, void *grad_fix, bool grad_is_output, ssg_stream_t stream) {
   if (!sr || !gt || !counts || !loss_out || !workspace || capacity <= 0) return SSG_E_BADARG;
   if ((ssg_sr == nullptr) != (ssg_gt == nullptr)) return SSG_E_BADARG;
   if (mask_kind != 2 && !mask) return SSG_E_BADARG;
@@ -637,14 +638,41 @@ int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mas
   const size_t fix_bytes = sizeof(long long) * ((size_t)B * C * H * W + 8), rs_bytes = 2 * sizeof(double) * (size_t)capacity;
   int rc = edge_list_impl(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
                           W, mask_stride, lap_threshold, ks, edges, capacity, counts, rank, order, plan, escratch,
-                          defer ? (void *)row_scale : nullptr, rs_bytes, zero_fix ? grad_fix : nullptr, fix_bytes, stream);
+                          defer ? (void *)row_scale : nullptr, rs_bytes, zero_fix ? grad_fix : nullptr, fix_bytes,
+                          // a gradient that is an OUTPUT: the deterministic flush assigns it; with fp32 atomics it is
+                          // cleared here (whole 16-byte granules; a tail of < 16 bytes by the memset below)
+                          (grad_is_output && grad_sr && !zero_fix) ? (void *)grad_sr : nullptr,
+                          sizeof(float) * (size_t)B * C * H * W, stream);
+  if (!rc && grad_is_output && grad_sr && !zero_fix && ((sizeof(float) * (size_t)B * C * H * W) & 15))
+    rc = (int)hipMemsetAsync((char *)grad_sr + ((sizeof(float) * (size_t)B * C * H * W) & ~(size_t)15), 0,
+                             (sizeof(float) * (size_t)B * C * H * W) & 15, (hipStream_t)stream);
   if (rc) return rc;
   rc = map_forward_impl(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
                         generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, defer, stream);
   if (rc) return rc;
   return loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
                        ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix,
-                       defer ? row_scale : nullptr, fused, zero_fix, stream);
+                       defer ? row_scale : nullptr, fused, zero_fix, grad_is_output && zero_fix, stream);
+}
+
+int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,
+                     int C, int H, int W, int ks, int kw, float sigma, float eps, int generalization, float w_l1,
+                     float w_kl, int mask_stride, float lap_threshold, int capacity, float *ssg_sr, float *ssg_gt,
+                     int *counts, float *loss_out, float *grad_sr, void *workspace, size_t workspace_bytes,
+                     void *grad_fix, ssg_stream_t stream) {
+  return loss_fwd_bwd_impl(sr, gt, mask, mask_kind, mask_channels, B, C, H, W, ks, kw, sigma, eps, generalization, w_l1,
+                           w_kl, mask_stride, lap_threshold, capacity, ssg_sr, ssg_gt, counts, loss_out, grad_sr,
+                           workspace, workspace_bytes, grad_fix, false, stream);
+}
+
+int ssg_loss_step(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B, int C,
+                  int H, int W, int ks, int kw, float sigma, float eps, int generalization, float w_l1, float w_kl,
+                  int mask_stride, float lap_threshold, int capacity, float *ssg_sr, float *ssg_gt, int *counts,
+                  float *loss_out, float *grad_sr, void *workspace, size_t workspace_bytes, void *grad_fix,
+                  ssg_stream_t stream) {
+  return loss_fwd_bwd_impl(sr, gt, mask, mask_kind, mask_channels, B, C, H, W, ks, kw, sigma, eps, generalization, w_l1,
+                           w_kl, mask_stride, lap_threshold, capacity, ssg_sr, ssg_gt, counts, loss_out, grad_sr,
+                           workspace, workspace_bytes, grad_fix, true, stream);
 }
 
 int ssg_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,

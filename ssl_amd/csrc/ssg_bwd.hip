@@ -682,12 +682,14 @@ __global__ __launch_bounds__(1024) void ssg_loss_finalize(const float *partials,
   }
 }
 
-// deterministic mode: grad += fixed-point sums (one rounding per pixel)
-__global__ __launch_bounds__(256) void grad_fix_flush(const long long *gfix, float *grad, size_t n) {
+// deterministic mode: grad += fixed-point sums (one rounding per pixel); assign != 0: grad = the sums (ssg_loss_step:
+// the gradient is an output, nobody has to clear it first)
+__global__ __launch_bounds__(256) void grad_fix_flush(const long long *gfix, float *grad, size_t n, int assign) {
   const double inv = 1.0 / (double)grad_fix_scale(gfix, n);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const long long v = gfix[i];
-    if (v) grad[i] += (float)((double)v * inv);
+    if (assign) grad[i] = (float)((double)v * inv);
+    else if (v) grad[i] += (float)((double)v * inv);
   }
 }
 
@@ -748,10 +750,10 @@ int launch_grad_fix_bound(const BwdParams &p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, hipStream_t st) {
+int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, int assign, hipStream_t st) {
   if (!n) return 0;
   const unsigned grid = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-  hipLaunchKernelGGL(grad_fix_flush, dim3(grid), dim3(256), 0, st, gfix, grad, n);
+  hipLaunchKernelGGL(grad_fix_flush, dim3(grid), dim3(256), 0, st, gfix, grad, n, assign);
   return (int)hipGetLastError();
 }
 

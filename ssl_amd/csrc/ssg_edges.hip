@@ -75,8 +75,8 @@ constexpr int OT = 8;  // order tile side (pixels)
 // edge-list kernel's threads instead of by hipMemsetAsync launches of their own (the fused step's row scales and
 // fixed-point gradient sums: two launches, 12 us at C2).
 struct ZeroRanges {
-  void *ptr[2];
-  size_t bytes[2];
+  void *ptr[3];
+  size_t bytes[3];
 };
 
 // (also zeroes the order tiles' counters that edge_scatter fills, and the caller's ZeroRanges)
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void edge_count(EdgeParams p, int *blockcnt, i
   if (tcnt)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gridDim.x * 256) tcnt[i] = 0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     uint4 *q = (uint4 *)z.ptr[k];
     const size_t n = z.bytes[k] / 16;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) q[i] = make_uint4(0, 0, 0, 0);
@@ -431,14 +431,14 @@ static void build_order(const int *rank, int B, int H, int W, int *order, int ca
 int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
                      int *edges, int capacity, int *counts, int *rank, int *order, int *plan, int dense_thr,
                      int plan_tile_rows, void *scratch, void *zero_a, size_t zero_a_bytes, void *zero_b,
-                     size_t zero_b_bytes, hipStream_t st) {
+                     size_t zero_b_bytes, void *zero_c, size_t zero_c_bytes, hipStream_t st) {
   EdgeParams p{mask, kind, mask_channels, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
   const int nblk = B * p.nblk_img;
   const int nt = (int)n_order_tiles(B, H, W);
   int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;
   int *tcnt = blockoff + nblk, *toff = tcnt + nt;
   const bool need_tiles = order || plan;  // rows per 8x8 order tile, counted while the edges are scattered
-  const ZeroRanges z{{zero_a, zero_b}, {zero_a ? zero_a_bytes : 0, zero_b ? zero_b_bytes : 0}};
+  const ZeroRanges z{{zero_a, zero_b, zero_c}, {zero_a ? zero_a_bytes : 0, zero_b ? zero_b_bytes : 0, zero_c ? zero_c_bytes : 0}};
   hipLaunchKernelGGL(edge_count, dim3(nblk), dim3(256), 0, st, p, blockcnt, need_tiles ? tcnt : nullptr, nt, z);
   hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts, plan);
   hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank,

@@ -299,16 +299,16 @@ class _SSGFusedFn(torch.autograd.Function):
             kind, mc = 0, mp.shape[1]
         want_grad = bool(ctx.needs_input_grad[0])
         dev = x.device
-        loss = torch.zeros(2, dtype=torch.float32, device=dev)
-        grad = torch.zeros_like(x) if want_grad else None
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(x) if want_grad else None      # (an OUTPUT of ssg_loss_step: no fill kernel)
         nb = L.ssg_loss_workspace_bytes(B, H, W, cap, ks) + L.ssg_loss_rows_bytes(cap, ks)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         fix = _grad_fix(det, x) if want_grad else None
         with torch.cuda.device(dev):
-            _lib.check(L.ssg_loss_fwd_bwd(_ptr(x), _ptr(y), _ptr(mp), kind, mc, B, C, H, W, ks, kw, float(sigma),
-                                          float(eps), int(bool(generalization)), float(w_l1), float(w_kl),
-                                          int(mask_stride or 0), float(lap_threshold), cap, None, None, _ptr(counts),
-                                          _ptr(loss), _ptr(grad), _ptr(ws), nb, _ptr(fix), _stream()))
+            _lib.check(L.ssg_loss_step(_ptr(x), _ptr(y), _ptr(mp), kind, mc, B, C, H, W, ks, kw, float(sigma),
+                                       float(eps), int(bool(generalization)), float(w_l1), float(w_kl),
+                                       int(mask_stride or 0), float(lap_threshold), cap, None, None, _ptr(counts),
+                                       _ptr(loss), _ptr(grad), _ptr(ws), nb, _ptr(fix), _stream()))
         ctx.cfg = (cap, ks, kw, sigma, eps, generalization, w_l1, w_kl, mask_stride, lap_threshold, det)
         ctx.in_dtype = sr.dtype
         ctx.has_mask = mask is not None
@@ -344,7 +344,7 @@ def ssg_loss_from_mask(sr, gt, mask, counts, capacity, ks=25, kw=9, sigma=0.004,
 
 
 class LossStep:
-    """The whole loss step in ONE C call (ssg_loss_fwd_bwd): edge list, SSG(sr), SSG(gt),
+    """The whole loss step in ONE C call (ssg_loss_step = ssg_loss_fwd_bwd with the gradient as an output): edge list, SSG(sr), SSG(gt),
     L1 + KL and d(l1+kl)/d sr, with persistent buffers sized for `capacity` edge pixels.
 
     This is the path bench.py times.  No host synchronisation happens inside; `counts[0]`
@@ -402,9 +402,9 @@ class LossStep:
             assert mp.is_contiguous()
 
         def launch():
-            self.grad.zero_()
+            # (ssg_loss_step: the gradient is an output of the call -- no fill kernel in front of it)
             with torch.cuda.device(self.grad.device):
-                _lib.check(_lib.lib().ssg_loss_fwd_bwd(_ptr(sr), _ptr(gt), _ptr(mp), kind, mc, B, C, H, W, ks, kw,
+                _lib.check(_lib.lib().ssg_loss_step(_ptr(sr), _ptr(gt), _ptr(mp), kind, mc, B, C, H, W, ks, kw,
                                                        sigma, eps, gen, w_l1, w_kl, stride, thr, self.capacity,
                                                        _ptr(self.ssg_sr), _ptr(self.ssg_gt), _ptr(self.counts),
                                                        _ptr(self.loss), _ptr(self.grad), _ptr(self.ws), self.ws_bytes,

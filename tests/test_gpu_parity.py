@@ -1637,3 +1637,41 @@ def test_degradation_production_draws_shapes_and_ranges(dev):
             assert out["gt_mask"].shape == (B, 1, 64, 64) and out["gt_mask"].dtype == torch.uint8
             assert float(lq.min()) >= 0 and float(lq.max()) <= 1 and bool(torch.isfinite(lq).all())
             assert float((lq * 255 - (lq * 255).round()).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("det", [True, False])
+def test_loss_step_gradient_is_an_output(dev, det):
+    """ssg_loss_step = ssg_loss_fwd_bwd with grad_sr overwritten instead of accumulated into: a gradient buffer full
+    of garbage gives the same result as ssg_loss_fwd_bwd on a cleared one, in the deterministic mode (the final fold
+    assigns) and with fp32 atomics (cleared by the edge-list builder's first kernel), for a size whose byte count is
+    not a multiple of 16, and all-empty masks give an all-zero gradient."""
+    from ssl_amd import _lib, engine
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    B, C, H, W, ks, kw = 1, 3, 37, 41, 25, 9            # 4 * B*C*H*W = 18204 bytes: not a multiple of 16
+    sr, gt = rng.random((B, C, H, W), dtype=np.float32), rng.random((B, C, H, W), dtype=np.float32)
+    for dens in (0.2, 0.0):
+        mask = (rng.random((B, 1, H, W)) < dens).astype(np.float32)
+        cap = B * H * W
+        nb = L.ssg_loss_workspace_bytes(B, H, W, cap, ks) + L.ssg_loss_rows_bytes(cap, ks)
+        out = {}
+        for name, fn, fill in (("acc", L.ssg_loss_fwd_bwd, 0.0), ("out", L.ssg_loss_step, 123.0)):
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            counts = torch.zeros(B + 2, dtype=torch.int32, device=dev)
+            loss = torch.full((2,), -1.0, device=dev)
+            grad = torch.full((B, C, H, W), fill, device=dev)
+            fix = torch.empty(L.ssg_grad_fix_bytes(B, C, H, W), dtype=torch.uint8, device=dev) if det else None
+            p = engine._ptr
+            _lib.check(fn(p(T(sr, dev)), p(T(gt, dev)), p(T(mask, dev)), 0, 1, B, C, H, W, ks, kw, 0.05, 1e-10, 1, 1e3,
+                          1e3, 0, 20.0, cap, None, None, p(counts), p(loss), p(grad), p(ws), nb, p(fix),
+                          torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            out[name] = (loss.cpu().numpy(), grad.cpu().numpy(), int(counts[0]))
+        assert out["acc"][2] == out["out"][2] == int(mask.sum())
+        assert np.array_equal(out["acc"][0], out["out"][0])
+        if det:
+            assert np.array_equal(out["acc"][1], out["out"][1])
+        else:
+            assert np.abs(out["acc"][1] - out["out"][1]).max() <= 1e-6 * max(np.abs(out["acc"][1]).max(), 1e-30)
+        if dens == 0.0:
+            assert not out["out"][1].any() and not out["out"][0].any()
