@@ -44,7 +44,7 @@ __device__ __forceinline__ void load_row(const float *tc, int rs, const float *z
 //                 SIMD).  Both variants are launched over the same job groups; a group runs in the
 //                 variant its geometry selects and exits at once in the other.
 template <class G, bool MERGED>
-__global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void ssg_fwd_tiled(FwdParams p) {
+__device__ __forceinline__ bool fwd_tiled_group(const FwdParams &p, int grp) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
   constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
   constexpr int JOBS = G::JOBS, PW = G::PW, S = G::S, CH = G::CH;
@@ -60,24 +60,28 @@ __global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void
   double *red = (double *)(zero + ((G::ZROW + 3) & ~3));           // [WG] row-sum scratch (8-byte aligned)
   int *sh_edge = (int *)(red + WG);                                // [JOBS][6]: b, y, x, row, which, pad
 
-  const int tid = threadIdx.x;
+  int tid_ = threadIdx.x;
+  // (inside the k_s = 49 group loop: opaque to the optimiser, which would otherwise hoist the lane constants derived
+  // from it out of the loop and hold them across the whole body -- spills)
+  if constexpr (G::KS >= 49) asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
   // job numbering: row order -> q = row * nimg + image; tile order -> image-major, every image's
   // jobs padded to a multiple of JOBS so that groups coincide with the ORDER_GROUP groups
   const int npad = p.order ? (nrows + JOBS - 1) / JOBS * JOBS : nrows;
   const int njobs = npad * p.nimg;
-  const int job0 = blockIdx.x * JOBS;
-  if (job0 >= njobs) return;
+  const int job0 = grp * JOBS;
+  if (job0 >= njobs) return false;
   int which0 = 0, k0 = 0;
   bool mergeable = false;
   if (p.order) {
     static_assert(!MERGED || JOBS == ORDER_GROUP, "order flags are computed for groups of ORDER_GROUP jobs");
     which0 = job0 / npad;
     k0 = job0 - which0 * npad;
-    if (k0 >= nrows) return;                             // padding-only group
+    if (k0 >= nrows) return false;                       // padding-only group
     mergeable = (p.order[k0] & ORDER_FLAG) != 0;         // one wave-uniform load decides the variant
   }
-  if (mergeable != MERGED) return;
+  if (mergeable != MERGED) return false;
 
   if (tid < JOBS) {
     int row = -1, which = 0;
@@ -297,12 +301,12 @@ __global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void
           if (py < KS && px < KS) o[py * KS + px] += acc[i][j];
         }
     }
-    return;
+    return true;
   }
 
   if (SSG_DBG(p, 4)) {
     if (acc[0][0] == 123.456f) p.out[0][0] = acc[1][1];
-    return;
+    return true;
   }
   // ---- epilogue: e = exp(-(D/den)/sigma), row sum, normalise ----
   // -(D/(C k_w^2))/sigma as one multiply by a host-rounded constant (|x| differs from the reference's two
@@ -356,6 +360,28 @@ __global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void
     float *o = p.out[sh_edge[j * 6 + 4]] + (size_t)row * P;
     const float *sj = tiles + (MERGED ? j * P : j * CH);
     for (int e = tid; e < P; e += WG) o[e] = sj[e];
+  }
+  return true;   // (LDS was used: the caller's loop needs a barrier before the next group)
+}
+
+// Job groups per workgroup.  k_s = 49 is the stress configuration, whose masks are dense: nearly every row belongs
+// to the dense kernels and the host's bound (capacity) sizes a grid of 1e5 workgroups that start only to leave (4.2e5
+// waves per launch, 40-70 us each at C5); there a workgroup walks 16 consecutive groups, so the empty grid is 16 times
+// smaller.  k_s <= 25 keeps one group per workgroup (the loop and its register cost fold away).
+template <class G>
+constexpr int fwd_groups_per_wg() { return G::KS >= 49 ? 16 : 1; }
+
+template <class G, bool MERGED>
+__global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void ssg_fwd_tiled(FwdParams p) {
+  constexpr int GPW = fwd_groups_per_wg<G>();
+  if constexpr (GPW == 1) {
+    fwd_tiled_group<G, MERGED>(p, (int)blockIdx.x);
+  } else {
+#pragma unroll 1
+    for (int g = 0; g < GPW; ++g) {
+      if (fwd_tiled_group<G, MERGED>(p, (int)blockIdx.x * GPW + g))
+        __syncthreads();   // the group's LDS (job table, staging) is rewritten by the next one
+    }
   }
 }
 
@@ -431,7 +457,8 @@ static int launch_fwd_tiled(const FwdParams &p, hipStream_t st) {
   const long per_img = p.order ? ((long)p.n_host + G::JOBS - 1) / G::JOBS * G::JOBS : (long)p.n_host;
   const long njobs = per_img * p.nimg;
   if (njobs == 0) return 0;
-  const unsigned grid = (unsigned)((njobs + G::JOBS - 1) / G::JOBS);
+  const long ngroups = (njobs + G::JOBS - 1) / G::JOBS;
+  const unsigned grid = (unsigned)((ngroups + fwd_groups_per_wg<G>() - 1) / fwd_groups_per_wg<G>());
   hipLaunchKernelGGL((ssg_fwd_tiled<G, MERGED>), dim3(grid), dim3(G::WG), lds, st, p);
   return (int)hipGetLastError();
 }
