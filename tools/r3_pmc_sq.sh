@@ -6,7 +6,8 @@ cd /tmp
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM" \
-           "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+           "GRBM_GUI_ACTIVE GRBM_COUNT" \
+           "SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_LEVEL_WAVES SQ_INSTS_VALU"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/p$i" -o pmc -- python "$R/bench.py" --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-module --no-extra > "$O/p$i.log" 2>&1
   echo "pmc pass $i rc=$?"
