@@ -108,6 +108,7 @@ class SSGLoss(nn.Module):
         self.deterministic = deterministic   # None: SSG_DETERMINISTIC env; True: bit-reproducible gradients
         self._sync_left = int(sync_checks)   # calls still to be checked in the same step
         self._pending = []         # (event, pinned count, capacity used) of earlier calls, oldest first
+        self._free = {}            # device index -> (pinned count, event) pairs whose count has been read
 
     def _capacity_for(self, B, H, W):
         cap = self.capacity if self.capacity is not None else max(1024, (B * H * W) // 4)
@@ -131,13 +132,15 @@ class SSGLoss(nn.Module):
         overflowed call is reported."""
         first_error = None
         while self._pending:
-            ev, host, cap = self._pending[0]
+            ev, host, cap = self._pending[0][:3]
             if not (wait or ev.query()):
                 break
             if wait:
                 ev.synchronize()
-            self._pending.pop(0)
+            done = self._pending.pop(0)
             n = int(host[0])
+            if len(done) > 3:
+                self._free.setdefault(done[3], []).append((host, ev))
             if n > cap:
                 self._grow(n, cap)
                 try:
@@ -176,10 +179,11 @@ class SSGLoss(nn.Module):
                 self._report(n, cap, recomputed=True)
         else:
             with torch.cuda.device(sr.device):   # the copy and the event go to the stream of sr's device
-                host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                # (pinned words and events are recycled once their count has been read: no page-locking per call)
+                pool = self._free.setdefault(sr.device.index, [])
+                host, ev = pool.pop() if pool else (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
                 host.copy_(counts[:1], non_blocking=True)
-                ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(sr.device))
-            self._pending.append((ev, host, cap))
+            self._pending.append((ev, host, cap, sr.device.index))
         self.last_counts = counts
         return out
