@@ -528,6 +528,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           }
           const float ev = __builtin_amdgcn_exp2f(d * nk);
           rs[ck] += (double)ev;
+          asm volatile("" : "+v"(rs[ck]));   // (pinned: the sink pass otherwise moves these additions to the end of the row and keeps every e for them)
           // every lane writes its own SSG row: single dwords are one L2 request per lane and step (request-
           // rate bound at high density), so SB consecutive offsets leave together as 16-byte stores
           evb[ck][qxi % SB] = ev;
