@@ -39,6 +39,9 @@ struct DenseParams {
   int generalization;
   int dbg;
   double *row_scale;
+  float *tm[2];
+  int tm_slots;
+  int grid_tiles;
 };
 bool dense_supported(int ks, int kw, int C);
 int dense_max_tiles(int B, int H, int W, int ks);
@@ -48,6 +51,7 @@ int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride
 bool grow_supported(int ks, int kw);
 unsigned grow_grid(int n_host);
 int launch_grad_rows(const GrowParams &p, int ks, int kw, hipStream_t st);
+int launch_rows_tm(const TmRowsParams &p, int ks, int kw, hipStream_t st);
 bool dense_bwd_supported(int ks, int kw, int C);
 int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st);
 int launch_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,
@@ -188,7 +192,23 @@ static int bwd_qsplit() {
 // Scratch of the split backward (ssg_grad_rows -> dense-tile kernel + direct kernel): G (n, k_s^2), sum_b (n).
 static size_t split_scratch_bytes(int n_rows, int ks) {
   const size_t n = (size_t)(n_rows > 0 ? n_rows : 1);
-  return align_up(sizeof(float) * n * ks * ks, 256) + 2 * align_up(sizeof(float) * n, 256);   // G, sum_b, max|G| parts
+  return align_up(sizeof(float) * n * ks * ks, 256) + 3 * align_up(sizeof(float) * n, 256);   // G, sum_b, max|G| parts, dot
+}
+
+// Tile-major scratch rows of the fused step at k_s = 49 (TmRowsParams, ssg_common.hpp): the dense tiles in the first
+// `slots` places of the plan keep their e rows in a second rows region, tile by tile, and the three kernels that touch
+// them move whole 256-byte runs.  SSG_TILE_MAJOR=0 keeps every row row-major (A/B measurements).
+struct TileMajor {
+  float *rows[2] = {nullptr, nullptr};
+  int slots = 0;
+};
+static bool tile_major_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SSG_TILE_MAJOR");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
 }
 
 // Backward over a forward plan: G rows (+ criteria sums) by ssg_grad_rows, the dense tiles by the shared-term
@@ -204,11 +224,21 @@ struct FinalizeArgs {
   float *loss_out;
 };
 
+// nparts of a split backward's criteria sums: ssg_grad_rows' workgroups, then ssg_rows_tm's
+static int split_tm_tiles(const BwdParams &p, const TileMajor *tm) {
+  if (!tm || tm->slots <= 0) return 0;
+  const int mt = dense_max_tiles(p.B, p.H, p.W, p.ks);
+  return tm->slots < mt ? tm->slots : mt;
+}
+
 static int split_backward(BwdParams p, const int *rank, const int *plan, void *scratch, hipStream_t st,
-                          const FinalizeArgs *fin = nullptr, bool *fin_done = nullptr) {
+                          const FinalizeArgs *fin = nullptr, bool *fin_done = nullptr, const TileMajor *tm = nullptr) {
   float *G = (float *)scratch;
+  const size_t nfl = align_up(sizeof(float) * (size_t)(p.n_host > 0 ? p.n_host : 1), 256);
   float *sum_b = (float *)((char *)scratch + align_up(sizeof(float) * (size_t)p.n_host * p.ks * p.ks, 256));
-  float *gmax_part = (float *)((char *)sum_b + align_up(sizeof(float) * (size_t)(p.n_host > 0 ? p.n_host : 1), 256));
+  float *gmax_part = (float *)((char *)sum_b + nfl);
+  float *dot = (float *)((char *)gmax_part + nfl);
+  const int n_tm = split_tm_tiles(p, tm);
   GrowParams g{};
   g.mode = p.mode;
   g.gin = p.gin;
@@ -229,9 +259,35 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   g.partials = p.partials;
   g.gmax_part = p.gfix ? gmax_part : nullptr;
   int rc = (dbg_mask() & (1 << 29)) ? 0 : launch_grad_rows(g, p.ks, p.kw, st);
+  if (!rc && n_tm > 0) {   // the rows of the tile-major tiles (ssg_grad_rows skipped them: negative row scale)
+    TmRowsParams t{};
+    t.tm[0] = tm->rows[0];
+    t.tm[1] = tm->rows[1];
+    t.row_scale = p.row_scale;
+    t.rank = rank;
+    t.n_dense = plan + 1;
+    t.tiles = plan + 4;
+    t.n_tiles = n_tm;
+    t.tm_slots = tm->slots;
+    t.n_dev = p.n_dev;
+    t.n_host = p.n_host;
+    t.B = p.B;
+    t.H = p.H;
+    t.W = p.W;
+    t.C = p.C;
+    t.sigma = p.sigma;
+    t.w_l1 = p.w_l1;
+    t.w_kl = p.w_kl;
+    t.upstream = p.upstream;
+    t.dot = dot;
+    t.sum_b = sum_b;
+    t.partials = p.partials + 2 * (size_t)grow_grid(p.n_host);
+    t.gmax_part = p.gfix ? gmax_part + grow_grid(p.n_host) : nullptr;
+    rc = (dbg_mask() & (1 << 29)) ? 0 : launch_rows_tm(t, p.ks, p.kw, st);
+  }
   if (rc || !p.grad) return rc;
   if (p.gfix) {
-    rc = launch_grad_fix_reduce(gmax_part, (int)grow_grid(p.n_host), p.gfix, (size_t)p.B * p.C * p.H * p.W, st);
+    rc = launch_grad_fix_reduce(gmax_part, (int)grow_grid(p.n_host) + n_tm, p.gfix, (size_t)p.B * p.C * p.H * p.W, st);
     if (rc) return rc;
   }
   const float *grows = p.mode == GRAD_D ? p.gin : G;
@@ -252,6 +308,17 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   d.W = p.W;
   d.qsplit = bwd_qsplit();
   d.dbg = p.dbg;
+  if (n_tm > 0) {
+    d.tm[0] = tm->rows[0];
+    d.tm[1] = tm->rows[1];
+    d.row_scale = p.row_scale;
+    d.dot = dot;
+    d.tm_slots = tm->slots;
+    d.sigma = p.sigma;
+    d.w_l1 = p.w_l1;
+    d.w_kl = p.w_kl;
+    d.upstream = p.upstream;
+  }
   SideStream *fk = nullptr;
   hipStream_t st2 = (dbg_mask() & ((1 << 27) | (1 << 28))) ? st : fork_from(st, p.ks, fk);
   if (fin && fk && st2 != st) {   // (only when there IS a side stream: on one stream it would only delay the backward)
@@ -394,7 +461,8 @@ int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W, float lap_thre
 static int map_forward_impl(const float *img, const float *img2, int B, int C, int H, int W, const int *edges,
                             const int *tile_order, const int *rank_map, const int *fwd_plan, const int *n_edges_dev,
                             int n_rows, int ks, int kw, float sigma, float eps, int generalization, float *ssg,
-                            float *ssg2, double *row_scale, bool row_scale_zeroed, ssg_stream_t stream) {
+                            float *ssg2, double *row_scale, bool row_scale_zeroed, ssg_stream_t stream,
+                            const TileMajor *tm = nullptr) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -443,6 +511,11 @@ static int map_forward_impl(const float *img, const float *img2, int B, int C, i
     d.generalization = generalization;
     d.dbg = (dbg_mask() >> 16) & 0xff;
     d.row_scale = row_scale;
+    if (tm && tm->slots > 0 && row_scale && img2) {
+      d.tm[0] = tm->rows[0];
+      d.tm[1] = tm->rows[1];
+      d.tm_slots = tm->slots;
+    }
     if (row_scale && !row_scale_zeroed) {   // 0 = "this row is already normalised" (the rows of the direct kernels)
       const int rc0 = (int)hipMemsetAsync(row_scale, 0, sizeof(double) * 2 * (size_t)n_rows, (hipStream_t)stream);
       if (rc0) return rc0;
@@ -524,7 +597,7 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
                          float sigma, int generalization, float *ssg_sr, float *ssg_gt, float w_l1, float w_kl,
                          const float *upstream, float *loss_out, float *grad_sr, void *scratch, void *grad_fix,
                          const double *row_scale, bool rows_scratch, bool fix_zeroed, bool grad_is_output,
-                         ssg_stream_t stream) {
+                         ssg_stream_t stream, const TileMajor *tm = nullptr) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
@@ -562,9 +635,9 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   int nparts;
   bool fin_done = false;
   if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
-    nparts = (int)grow_grid(n_rows);
+    nparts = (int)grow_grid(n_rows) + split_tm_tiles(p, tm);
     const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out};
-    rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done);
+    rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done, tm);
   } else {
     if (p.gfix) rc = launch_grad_fix_bound(p, st);
     if (!rc) rc = launch_bwd(p, st);
@@ -586,9 +659,11 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
                        row_scale, rows_are_scratch != 0, false, false, stream);
 }
 
-size_t ssg_loss_rows_bytes(int capacity, int ks) {
-  return 2 * align_up(sizeof(float) * (size_t)(capacity > 0 ? capacity : 1) * ks * ks, 256);
+// two row-major regions (sr, gt); at k_s = 49 two tile-major regions of the same size behind them
+static size_t rows_region_bytes(int capacity, int ks) {
+  return align_up(sizeof(float) * (size_t)(capacity > 0 ? capacity : 1) * ks * ks, 256);
 }
+size_t ssg_loss_rows_bytes(int capacity, int ks) { return (ks == 49 ? 4 : 2) * rows_region_bytes(capacity, ks); }
 
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
   return align_up(sizeof(int) * 3 * (size_t)(capacity > 0 ? capacity : 1), 256) +
@@ -610,9 +685,16 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   const bool fused = ssg_sr == nullptr;
   const size_t base_bytes = ssg_loss_workspace_bytes(B, H, W, capacity, ks);
   if (workspace_bytes < base_bytes + (fused ? ssg_loss_rows_bytes(capacity, ks) : 0)) return SSG_E_WORKSPACE;
+  TileMajor tm;
   if (fused) {
+    const size_t region = rows_region_bytes(capacity, ks);
     ssg_sr = (float *)((char *)workspace + base_bytes);
-    ssg_gt = (float *)((char *)ssg_sr + ssg_loss_rows_bytes(capacity, ks) / 2);
+    ssg_gt = (float *)((char *)ssg_sr + region);
+    if (ks == 49 && kw == 13 && C == 3 && generalization && tile_major_enabled()) {
+      tm.rows[0] = (float *)((char *)ssg_gt + region);
+      tm.rows[1] = (float *)((char *)tm.rows[0] + region);
+      tm.slots = capacity / TM_PX;   // tm.slots * P * TM_PX floats <= one region
+    }
   }
   char *ws = (char *)workspace;
   int *edges = (int *)ws;
@@ -630,6 +712,7 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   double *row_scale = (double *)ws;
   // (deferred normalisation wherever the split backward -- whose ssg_grad_rows pass rescales -- follows)
   const bool defer = split_ok(ks, kw, C, rank, plan, lscratch) && dense_supported(ks, kw, C);
+  if (!defer) tm.slots = 0;
   // with the plan in use every kernel takes its job order from it: the full tile-major order is not built (3 launches)
   if (defer) order = nullptr;
   // the row scales and the fixed-point gradient sums start at zero: cleared by the edge-list builder's first kernel
@@ -648,11 +731,11 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
                              (sizeof(float) * (size_t)B * C * H * W) & 15, (hipStream_t)stream);
   if (rc) return rc;
   rc = map_forward_impl(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
-                        generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, defer, stream);
+                        generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, defer, stream, &tm);
   if (rc) return rc;
   return loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
                        ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix,
-                       defer ? row_scale : nullptr, fused, zero_fix, grad_is_output && zero_fix, stream);
+                       defer ? row_scale : nullptr, fused, zero_fix, grad_is_output && zero_fix, stream, &tm);
 }
 
 int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,

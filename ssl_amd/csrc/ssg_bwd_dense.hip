@@ -147,7 +147,11 @@ struct DenseBwdGeo {
 // NCH = 64-pixel chunks of the tile's edge-pixel list this instantiation carries per offset step; a wave
 // whose tile needs another count leaves at once (every instantiation is launched over the same tile list), so
 // the offset loop is free of control flow.
-template <int KS, int KW, int C, int TY, int NCH, int RG>
+// TM (k_s 49 only): the tile's rows are tile-major scratch rows of the fused step (TmRowsParams, ssg_common.hpp) -- the
+// lanes keep the dense forward's fixed pixel map, read e_sr / e_gt of one offset as aligned 256-byte runs seven
+// steps ahead, and form G = -(s k)(g - dot) themselves (criteria_elem's g, bit for bit what ssg_rows_tm summed into
+// dot) instead of reading G rows that ssg_grad_rows would have had to write.
+template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 : 1, RG == 8 ? 2 : 1))) void ssg_bwd_dense(DenseBwdParams p) {
   using G = DenseBwdGeo<KS, KW, C, TY, RG>;
   constexpr int RR = G::RR, RMASK = RR - 1, BRS = G::BRS;
@@ -159,6 +163,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   constexpr int DUMMY = FSZ - 1;  // last word of a copy (offsets are relative to the copy's base)
   constexpr int NCH_LO = NCH <= 2 ? 0 : NCH / 2;  // instantiations: 2 and 4 chunks
   static_assert(NG % 2 == 0 && NCH <= NCHUNK, "two G slots alternate over an even number of groups");
+  constexpr int TMD = 7;   // tile-major rows: offsets in flight (ring slots; k_s % TMD == 0 keeps slot = q_x % TMD)
+  static_assert(!TM || (RG == 4 && TY == 4 && NCH == NCHUNK && NCH * 64 == TM_PX && KS % TMD == 0), "tile-major rows: 4 x 32 tiles, one wave");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *imgb = smem;                       // [16][C][RWS] image band: region rows q_y .. q_y+15
@@ -172,6 +178,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   const int lane = threadIdx.x;
   const int tslot = blockIdx.x;
   if (tslot >= dense_tile_count(p.n_dense)) return;
+  if (p.tm_slots > 0 && tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host)) != TM) return;
+  if (TM && p.tm_slots <= 0) return;
   if (p.n_dense[1] != TY) __builtin_trap();   // plan cut for another tile height (see ssg_fwd_dense)
   const int H = p.H, W = p.W;
   const int tx_n = (W + TX - 1) / TX, ty_n = (H + TY - 1) / TY;
@@ -184,14 +192,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
 
   // ---- census of the tile's edge pixels (row-major inside the tile) ----
   int n_e = 0;
+  int tm_pos[NCH], tm_row[NCH];   // tile-major rows: the lane's pixels by the fixed map, no list
 #pragma unroll
   for (int k = 0; k < NCHUNK; ++k) {
-    const int pos = lane + 64 * k, ey = pos / TX, ex = pos - ey * TX;
+    const int pos = lane + 64 * k;
+    const int ey = TM ? tm_pixel_row(k, lane) : pos / TX, ex = TM ? tm_pixel_col(lane) : pos - (pos / TX) * TX;
     const int y = ty0 + ey, x = tx0 + ex;
     int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
     if (r >= nrows) r = -1;
     const unsigned long long bal = __ballot(r >= 0);
-    if (r >= 0) {
+    if constexpr (TM) {
+      tm_pos[k < NCH ? k : 0] = r >= 0 ? ey * GQS + 2 * HK + ex : DUMMY;
+      tm_row[k < NCH ? k : 0] = r;
+    } else if (r >= 0) {
       const int at = n_e + __popcll(bal & ((1ull << lane) - 1ull));
       elist[2 * at] = ey * GQS + 2 * HK + ex;
       elist[2 * at + 1] = r;
@@ -206,13 +219,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   int epos[NCH];
   const float *gp[NCH];
   int erow[NCH];
+  // tile-major rows: the two row scales (as the floats ssg_rows_tm used) and dot of the lane's pixels; 0 for a hole
+  // (s = t = 0 -> G = 0, dropped into the dummy word)
+  TmScale tsa[NCH], tsb[NCH];
+  float tdot[NCH];
 #pragma unroll
   for (int ck = 0; ck < NCH; ++ck) {
-    const int e = ck * 64 + lane;
-    const bool on = e < n_e;
-    epos[ck] = on ? elist[2 * e] : DUMMY;
-    erow[ck] = on ? elist[2 * e + 1] : elist[1];
-    gp[ck] = p.G + (SSG_DBG(p, 16) ? (size_t)0 : (size_t)erow[ck] * P);   // (profiling: bit 4 = every lane streams row 0)
+    if constexpr (TM) {
+      const int r = tm_row[ck];
+      epos[ck] = tm_pos[ck];
+      erow[ck] = r >= 0 ? r : 0;
+      gp[ck] = nullptr;
+      tsa[ck] = tm_scale(r >= 0 ? p.row_scale[r] : 0.0);
+      tsb[ck] = tm_scale(r >= 0 ? p.row_scale[(size_t)p.n_host + r] : 0.0);
+      tdot[ck] = r >= 0 ? p.dot[r] : 0.f;   // (times k: below)
+    } else {
+      const int e = ck * 64 + lane;
+      const bool on = e < n_e;
+      epos[ck] = on ? elist[2 * e] : DUMMY;
+      erow[ck] = on ? elist[2 * e + 1] : elist[1];
+      gp[ck] = p.G + (SSG_DBG(p, 16) ? (size_t)0 : (size_t)erow[ck] * P);   // (profiling: bit 4 = every lane streams row 0)
+      tsa[ck] = tsb[ck] = TmScale{0.f, 0.f};
+      tdot[ck] = 0.f;
+    }
   }
 
   // lane roles: main (U-row r, column group g); prefix (tile row hty, column group hg)
@@ -407,28 +436,74 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
 
   // G values of the lane's edge pixels, 4 offsets per load, one group ahead (two register slots) + the row's
   // last offset on its own
-  float4u gbuf[2][NCH];
+  float4u gbuf[2][TM ? 1 : NCH];
   float gl[NCH];
-  auto load_group = [&](int qyi, int k, float4u (&dst)[NCH]) {
+  auto load_group = [&](int qyi, int k, float4u (&dst)[TM ? 1 : NCH]) {
+    if constexpr (!TM) {
 #pragma unroll
-    for (int ck = 0; ck < NCH; ++ck) dst[ck] = *(const float4u *)(gp[ck] + qyi * KS + 4 * k);
+      for (int ck = 0; ck < NCH; ++ck) dst[ck] = *(const float4u *)(gp[ck] + qyi * KS + 4 * k);
+    }
   };
   auto load_last = [&](int qyi) {
+    if constexpr (!TM) {
 #pragma unroll
-    for (int ck = 0; ck < NCH; ++ck) gl[ck] = gp[ck][qyi * KS + KS - 1];
+      for (int ck = 0; ck < NCH; ++ck) gl[ck] = gp[ck][qyi * KS + KS - 1];
+    }
   };
-  load_group(qy0, 0, gbuf[0]);
-  load_group(qy0, 1, gbuf[1]);
-  load_last(qy0);
-  // G[.,q] of one offset into field copy f; x_put(.., qyi, qxi) reads the registers the schedule below filled
-  auto x_put = [&](auto qx_c, int qyi, float *f) {
+  // tile-major rows: ring of TMD offsets (slot = q_x % TMD), e_sr / e_gt of the lane's NCH pixels each
+  float tea[TM ? TMD : 1][NCH], teb[TM ? TMD : 1][NCH];
+  const float *tma = nullptr, *tmb = nullptr;
+  float tw1 = 0.f, tw2 = 0.f, tkf = 0.f;
+  if constexpr (TM) {
+    tma = p.tm[0] + (size_t)tslot * P * TM_PX;   // (wave-uniform: scalar base + lane offset addressing)
+    tmb = p.tm[1] + (size_t)tslot * P * TM_PX;
+    const float invM = 1.f / ((float)nrows * (float)P);
+    tkf = 1.f / (p.sigma * (float)(C * KW * KW));
+    tw1 = -tkf * (p.w_l1 * invM * (p.upstream ? p.upstream[0] : 1.f));
+    tw2 = tkf * (p.w_kl * invM * (p.upstream ? p.upstream[1] : 1.f));
+#pragma unroll
+    for (int ck = 0; ck < NCH; ++ck) tdot[ck] *= tkf;
+  }
+  auto tm_load = [&](auto slot_c, int q) {   // offset q (linear) -> ring slot
+    constexpr int sl = decltype(slot_c)::value;
+    if constexpr (TM) {
+#pragma unroll
+      for (int ck = 0; ck < NCH; ++ck) {
+        tea[sl][ck] = __builtin_nontemporal_load(tma + (size_t)q * TM_PX + ck * 64 + lane);
+        teb[sl][ck] = __builtin_nontemporal_load(tmb + (size_t)q * TM_PX + ck * 64 + lane);
+      }
+    }
+  };
+  if constexpr (TM) {
+    static_for(std::make_integer_sequence<int, TMD>{}, [&](auto sc) { tm_load(sc, qy0 * KS + decltype(sc)::value); });
+  } else {
+    load_group(qy0, 0, gbuf[0]);
+    load_group(qy0, 1, gbuf[1]);
+    load_last(qy0);
+  }
+  // G[.,q] of one offset into field copy f; x_put(.., qyi, qxi) reads the registers the schedule below filled.
+  // (tile-major rows: G is formed here; `q_refill` = the linear offset TMD steps ahead that refills the ring slot)
+  auto x_put = [&](auto qx_c, int qyi, float *f, int q_refill = 0) {
     constexpr int qxi = decltype(qx_c)::value, grp = qxi / 4, gj = qxi % 4;
 #pragma unroll
     for (int ck = 0; ck < NCH; ++ck) {
-      float gv = grp < NG ? gbuf[grp & 1][ck][gj] : gl[ck];
+      float gv;
+      if constexpr (TM) {
+        // G = -k s (g - dot) with s g = w1 s sgn(s - t) - w2 t' (t' = max(t, 1e-10) where s >= 1e-10, else 0: the
+        // product s * t'/s of KLDistanceLoss' gradient without the division), the constants folded:
+        // tw1 = -k w1, tw2 = k w2, tdot = k dot.  sgn by scaling and clamping: exact for |s - t| >= 2^-126.
+        const float cl = 1e-10f;
+        const float a = tm_apply(tea[qxi % TMD][ck], tsa[ck]), t = tm_apply(teb[qxi % TMD][ck], tsb[ck]);
+        const float sg = __builtin_amdgcn_fmed3f((a - t) * 0x1p126f, -1.f, 1.f);
+        const float bz = a >= cl ? fmaxf(t, cl) : 0.f;
+        gv = __builtin_fmaf(a, __builtin_fmaf(sg, tw1, tdot[ck]), tw2 * bz);
+      } else {
+        gv = grp < NG ? gbuf[grp & 1][ck][gj] : gl[ck];
+      }
       if constexpr (qxi == HP) gv = (qyi == HP) ? 0.f : gv;  // centre offset: A - B == 0 exactly
       f[epos[ck]] = gv;
     }
+    if constexpr (TM) tm_load(std::integral_constant<int, qxi % TMD>{}, q_refill);
   };
   // The work of one offset t is spread over three steps so that a step waits for LDS ONCE:
   //   end of step t-2 : G[., t] into field copy t&1                       (x_put)
@@ -438,8 +513,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   // Every LDS read of a step is issued at its top and touches only what earlier steps wrote.
   {  // first two offsets of the sweep (copy = parity of the offset's linear index; k_s is odd)
     float *f0 = fld + ((qy0 * KS) & 1) * FSZ, *f1 = fld + (((qy0 * KS) & 1) ^ 1) * FSZ;
-    x_put(std::integral_constant<int, 0>{}, qy0, f0);
-    x_put(std::integral_constant<int, 1>{}, qy0, f1);
+    x_put(std::integral_constant<int, 0>{}, qy0, f0, qy0 * KS + TMD);
+    x_put(std::integral_constant<int, 1>{}, qy0, f1, qy0 * KS + TMD + 1);
     __builtin_amdgcn_wave_barrier();
     x_stage(std::integral_constant<int, (-HK > 0 ? -HK : 0)>{}, std::integral_constant<int, HK>{}, f0);
     step_fence();
@@ -449,6 +524,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   for (int qyi = qy0; qyi < qy1; ++qyi) {
     // (next row's prefetches run unconditionally on clamped rows: the offset loop stays branch-free)
     const int qyn = qyi + 1 < KS ? qyi + 1 : KS - 1;
+    // (first offsets of this and the next offset row for the tile-major loads, opaque to the optimiser: loop strength
+    // reduction otherwise keeps one running pointer per unrolled load -- 196 of them -- across the offset rows)
+    int rq0 = qyi * KS, rq1 = qyn * KS;
+    if constexpr (TM) asm volatile("" : "+s"(rq0), "+s"(rq1));
     float nrow[C][CPL];
     load_img_row(r0 + qyi + RR < RH ? r0 + qyi + RR : RH - 1, nrow);
     const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
@@ -559,7 +638,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
           wB[s0] = wn[2];
         }
       }
-      x_put(std::integral_constant<int, qx2>{}, qxi + 2 < KS ? qyi : qyn, fc);
+      x_put(std::integral_constant<int, qx2>{}, qxi + 2 < KS ? qyi : qyn, fc,
+            (qxi + 2 < KS && qx2 + TMD < KS) ? rq0 + qx2 + TMD : (qxi + 2 < KS ? rq1 + qx2 + TMD - KS : rq1 + qx2 + TMD));
       // (the accumulators of the lane's own pixels pass through an empty asm: they are not read again before
       // the end of the sweep, and hipcc otherwise sinks their FMAs below all k_s steps, keeping every step's
       // W and differences alive: 1,000 spilled registers)
@@ -626,25 +706,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
 // ------------------------------------------------------------------ host ----
 bool dense_bwd_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }
 
-template <int KS, int KW, int C, int TY, int NCH, int RG>
-static int launch_one(const DenseBwdParams &p, hipStream_t st) {
+template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM = false>
+static int launch_one(const DenseBwdParams &p, int n_tiles, hipStream_t st) {
   using G = DenseBwdGeo<KS, KW, C, TY, RG>;
+  if (n_tiles <= 0) return 0;
   static std::atomic<unsigned long long> lds_set{0};
-  if (const int rc = ensure_dynamic_lds(ssg_bwd_dense<KS, KW, C, TY, NCH, RG>, (int)G::lds_bytes(), lds_set)) return rc;
-  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH, RG>), dim3((unsigned)p.max_tiles, (unsigned)p.qsplit, G::NHALF),
+  if (const int rc = ensure_dynamic_lds(ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM>, (int)G::lds_bytes(), lds_set)) return rc;
+  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM>), dim3((unsigned)n_tiles, (unsigned)p.qsplit, G::NHALF),
                      dim3(64), G::lds_bytes(), st, p);
   return (int)hipGetLastError();
 }
 
-int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st) {
+int launch_bwd_dense(const DenseBwdParams &p0, int ks, int kw, int C, hipStream_t st) {
   if (!dense_bwd_supported(ks, kw, C)) return -1;
-  if (p.max_tiles == 0) return 0;
+  if (p0.max_tiles == 0) return 0;
+  DenseBwdParams p = p0;
   // 4 x 32 tiles: at most 128 edge pixels.  One wave per tile: the two-waves-per-tile layout (RG = 8, 48 padded
   // columns, prefix rows through LDS) was measured slower here, 3.16 vs 2.27 ms at C5 -- with 4 tile rows each half
-  // repeats a W stage that is most of its work
-  if (ks == 49) return launch_one<49, 13, 3, 4, 2, 4>(p, st);
-  int rc = launch_one<25, 9, 3, 8, 2, 8>(p, st);
-  if (!rc) rc = launch_one<25, 9, 3, 8, 4, 8>(p, st);
+  // repeats a W stage that is most of its work.  With a tile-major region (fused step) both variants are launched
+  // and tm_active() lets one of them run.
+  const bool tm = ks == 49 && p.tm[0] && p.tm[1] && p.row_scale && p.dot && p.tm_slots > 0;
+  if (!tm) p.tm_slots = 0;
+  if (ks == 49) {
+    int rc = tm ? launch_one<49, 13, 3, 4, 2, 4, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st) : 0;
+    if (!rc) rc = launch_one<49, 13, 3, 4, 2, 4, false>(p, p.max_tiles, st);
+    return rc;
+  }
+  int rc = launch_one<25, 9, 3, 8, 2, 8>(p, p.max_tiles, st);
+  if (!rc) rc = launch_one<25, 9, 3, 8, 4, 8>(p, p.max_tiles, st);
   return rc;
 }
 

@@ -298,6 +298,61 @@ struct GrowParams {
                           // behind the fixed-point sums by grad_fix_reduce: no atomics on one address)
 };
 
+// Tile-major scratch rows (fused step at k_s = 49): the tile in slot t of the plan's dense list keeps
+// e[n,q] = exp(-d/sigma) of its TM_PX = 4 x 32 pixels at  base + (t * P + q) * TM_PX + idx,  idx = 64 ck + lane with
+// pixel (row 2 (lane / 32) + ck, column lane % 32) of the tile -- the dense forward's fixed pixel map -- so that every
+// wave access of the three kernels that touch the rows is one aligned 256-byte run.
+constexpr int TM_PX = 128;
+// s = e * (1/(sum e + eps)) with the fp64 row scale as a float pair (hi, lo): e * lo brings
+// back what the rounding of the scale to ONE float would lose for the whole row at once (a relative 6e-8 common to
+// the 2,401 entries of a row shifts t/s - 1, i.e. the KL part of the gradient, by 1e-4 of itself at sigma = 1).
+// ssg_rows_tm and the dense backward both use exactly this, so they see the same bits.
+struct TmScale {
+  float hi, lo;
+};
+__device__ __forceinline__ TmScale tm_scale(double neg_scale) {   // tile-major rows carry -1/(sum e + eps)
+  const double sc = -neg_scale;
+  TmScale r;
+  r.hi = (float)sc;
+  r.lo = (float)(sc - (double)r.hi);
+  return r;
+}
+// (e * hi is formed exactly inside the fma, the small product joins it, ONE rounding: the correctly rounded e * scale)
+__device__ __forceinline__ float tm_apply(float e, TmScale s) { return __builtin_fmaf(e, s.hi, e * s.lo); }
+__device__ __forceinline__ int tm_pixel_row(int ck, int lane) { return 2 * (lane >> 5) + ck; }
+__device__ __forceinline__ int tm_pixel_col(int lane) { return lane & 31; }
+
+// A call keeps ALL its dense tiles tile-major or none (the same test in every kernel that touches the rows; the
+// order of the plan's tile list varies from run to run -- atomic appends -- so a per-slot split would not be
+// reproducible): when the tiles fit the region's slots and are at least 60 % full on average -- a tile-major row
+// costs 128 pixels' worth of traffic whatever the number of edge pixels in the tile.
+// hdr = plan + 1 (hdr[-1] = rows NOT in a dense tile), nrows = rows of the call.
+__device__ __forceinline__ bool tm_active(const int *hdr, int tm_slots, int nrows) {
+  const int nd = hdr[0] + hdr[2];
+  return tm_slots > 0 && nd <= tm_slots && 5 * (nrows - hdr[-1]) >= 3 * TM_PX * nd;
+}
+
+// ssg_rows_tm (ssg_grow.hip): the row pass over tile-major rows -- criteria sums, sum_q g s, border sums, |G| bound
+struct TmRowsParams {
+  const float *tm[2];        // e rows of sr / gt
+  const double *row_scale;   // [2][n_host]; tile-major rows carry -1/(sum e + eps)
+  const int *rank;           // (B,H,W)
+  const int *n_dense;        // plan + 1
+  const int *tiles;          // plan + 4
+  int n_tiles;               // launch bound = min(dense_max_tiles, tm_slots)
+  int tm_slots;              // slots of the tile-major region (tm_active)
+  const int *n_dev;
+  int n_host;
+  int B, H, W, C;
+  float sigma;
+  float w_l1, w_kl;
+  const float *upstream;     // nullable device {dL/dl1, dL/dkl}
+  float *dot;                // (n) out: sum_q g s of every tile-major row
+  float *sum_b;              // (n) out: sum of G over the border offsets
+  float *partials;           // (n_tiles, 2) out: criteria sums per workgroup
+  float *gmax_part;          // nullable (n_tiles) out: upper bound of |G| per workgroup
+};
+
 // ssg_bwd_dense (ssg_bwd_dense.hip)
 struct DenseBwdParams {
   const float *img;    // (B,C,H,W)
@@ -314,6 +369,14 @@ struct DenseBwdParams {
   int B, H, W;
   int qsplit;          // waves per tile, each taking a contiguous range of offset rows
   int dbg;
+  // tile-major rows (TmRowsParams), when tm_active(): the TM variant forms G = -(s k)(g - dot) itself from the two e
+  // rows, the row scales and ssg_rows_tm's dot; otherwise the other variant reads the row-major G rows
+  const float *tm[2];
+  const double *row_scale;
+  const float *dot;
+  int tm_slots;
+  float sigma, w_l1, w_kl;
+  const float *upstream;
 };
 
 __device__ __forceinline__ int rows_to_do(const int *n_dev, int n_host) {

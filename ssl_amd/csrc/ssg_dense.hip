@@ -105,6 +105,12 @@ struct DenseParams {
   int generalization;
   int dbg;  // profiling ablations: bit0 no stores, bit1 no edge stage, bit3 no rescale, bit6 no main loop
   double *row_scale;  // nullable [nimg][n_host]: deferred normalisation -- the rows stay e, 1/(sum e + eps) goes here
+  // tile-major scratch rows (fused step at k_s = 49, ssg_api.hip; tm_active() in ssg_common.hpp decides per call):
+  // the tile in plan slot t leaves its e values at tm[img] + t * P * 128 + q * 128 + (64 ck + lane) -- every wave
+  // store is one aligned 256-byte run -- and marks its rows with a NEGATIVE row scale; nullptr / 0 = row-major rows only
+  float *tm[2];
+  int tm_slots;
+  int grid_tiles;  // plan slots this launch covers (per image)
 };
 
 constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1) (8 for k_w = 9, 4 for k_w = 13)
@@ -136,7 +142,8 @@ __device__ __forceinline__ int dense_h_col(int ex, int L, int G, bool paired) {
 // only one workgroup fits and the kernel takes 0.63 instead of 0.45 ms); (49,13): its 71 KB region allows one
 // workgroup per CU, and a lone wave per SIMD issues a VALU instruction only every ~4 cycles, so 7 waves -- 49 rows
 // are 7 each, with 8 the workgroup waits for the one wave that has a 7th row.
-template <int KS, int KW, int C, int NW>
+// TM: the launch writes tile-major scratch rows (k_w 13 only: the fixed pixel map below is the layout's pixel index)
+template <int KS, int KW, int C, int NW, bool TM = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_fwd_dense(DenseParams p) {
   constexpr int NT = 64 * NW;
   constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK, DT_Y = 16 - 2 * HK;
@@ -148,6 +155,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr bool HPAIR = dense_h_paired(KW);
   constexpr int HG = dense_h_group(KW);
   constexpr int NE_MAX = DT_Y * DT_X, NCHUNK = NE_MAX / 64;
+  static_assert(!TM || !HPAIR, "tile-major rows use the k_w 13 pixel map");
   static_assert(UH == 16 && DT_X == 32 && 4 * L >= UW && 3 * HG + L <= DT_HS && HG >= L && (HPAIR || HG == L) && L % 2 == 0 && KW - 1 <= L,
                 "lane map: 16 U-rows x 4 column groups (one quad) of L pixels; a window spans two lanes");
 
@@ -165,8 +173,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   int *misc = elist + NE_MAX * 3;          // [16 + 64 NW]: wave counts, n_e (misc[NW]); then the census' (wave, bank) counts and starts
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int which = blockIdx.x / p.max_tiles, tslot = blockIdx.x - which * p.max_tiles;
+  const int which = blockIdx.x / p.grid_tiles, tslot = blockIdx.x - which * p.grid_tiles;
   if (tslot >= dense_tile_count(p.n_dense)) return;
+  // (both variants are launched over the whole tile list when the call has a tile-major region; one of them leaves)
+  if (p.tm_slots > 0 && tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host)) != TM) return;
+  if (TM && p.tm_slots <= 0) return;
   // the plan records the tile height it was cut for (ssg_edge_list's plan_ks): walking an 8-row plan with 4-row
   // tiles (or the reverse) would decode garbage tile ids -- stop loudly instead (the Python host raises before
   // it gets here, engine.check_plan)
@@ -389,7 +400,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int t = 0; t < HL; ++t) w[c][t] = f2{rq[c * RH * RS + t], rq[c * RH * RS + t + HL]};
     constexpr int SB = 13;  // consecutive offsets per edge pixel buffered in registers and stored together
-    float evb[NCHUNK][SB];
+    float evb[TM ? 1 : NCHUNK][TM ? 1 : SB];   // (tile-major rows: nothing is buffered)
+    float *tmq = nullptr;                      // tile-major: this wave's offset row, + 64 ck + lane
+    if constexpr (TM) tmq = p.tm[which] + ((size_t)tslot * P + (size_t)qyi * KS) * (size_t)NE_MAX + lane;
     static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
@@ -529,6 +542,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           const float ev = __builtin_amdgcn_exp2f(d * nk);
           rs[ck] += (double)ev;
           asm volatile("" : "+v"(rs[ck]));   // (pinned: the sink pass otherwise moves these additions to the end of the row and keeps every e for them)
+          if constexpr (TM) {
+            // tile-major scratch rows: the 64 lanes' values of one offset are one aligned 256-byte run (holes
+            // included: the consumers skip them by the rank map)
+            if (do_store) tmq[qxi * NE_MAX + ck * 64] = ev;
+          } else {
           // every lane writes its own SSG row: single dwords are one L2 request per lane and step (request-
           // rate bound at high density), so SB consecutive offsets leave together as 16-byte stores
           evb[ck][qxi % SB] = ev;
@@ -544,6 +562,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
               for (int t = cnt & ~3; t < cnt; ++t) o[q0 + t] = evb[ck][t];
             }
+          }
           }
         }
       }
@@ -566,10 +585,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       double tot = 0.0;
 #pragma unroll
       for (int k = 0; k < NW; ++k) tot += rsum[k * RSTR + e];
-      rsc[elist[3 * e + 2]] = 1.0 / (tot + (double)p.eps);
+      const double sc = 1.0 / (tot + (double)p.eps);
+      rsc[elist[3 * e + 2]] = TM ? -sc : sc;   // (negative: "this row lives in the tile-major region")
     }
     return;
   }
+  if constexpr (TM) return;   // (tile-major rows exist in the deferred form only)
   // global stores of this workgroup must be visible to its own later loads: same CU, L1 is
   // write-through, the loads below are issued after the barrier + vmcnt drain
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -629,19 +650,29 @@ int dense_max_tiles(int B, int H, int W, int ks) {
   return B * ((H + ty - 1) / ty) * ((W + DT_X - 1) / DT_X);
 }
 
-template <int KS, int KW, int C, int NW>
-static int launch_fwd_dense_t(const DenseParams &p, hipStream_t st) {
+template <int KS, int KW, int C, int NW, bool TM>
+static int launch_fwd_dense_t(DenseParams p, int n_tiles, hipStream_t st) {
+  if (n_tiles <= 0) return 0;
   const size_t lds = dense_lds_bytes<KS, KW, C, NW>();
   static std::atomic<unsigned long long> lds_set{0};
-  if (const int rc = ensure_dynamic_lds(ssg_fwd_dense<KS, KW, C, NW>, (int)lds, lds_set)) return rc;
-  hipLaunchKernelGGL((ssg_fwd_dense<KS, KW, C, NW>), dim3((unsigned)p.max_tiles * p.nimg), dim3(64 * NW), lds, st, p);
+  if (const int rc = ensure_dynamic_lds(ssg_fwd_dense<KS, KW, C, NW, TM>, (int)lds, lds_set)) return rc;
+  p.grid_tiles = n_tiles;
+  hipLaunchKernelGGL((ssg_fwd_dense<KS, KW, C, NW, TM>), dim3((unsigned)n_tiles * p.nimg), dim3(64 * NW), lds, st, p);
   return (int)hipGetLastError();
 }
 
-int launch_fwd_dense(const DenseParams &p, int ks, int kw, int C, hipStream_t st) {
+// a call with a tile-major region (k_s 49, fused step with a row-scale array) launches both variants over the tile
+// list; tm_active() -- device-side, from the plan's counts -- lets one of them run
+int launch_fwd_dense(const DenseParams &p0, int ks, int kw, int C, hipStream_t st) {
   if (!dense_supported(ks, kw, C)) return -1;
-  if (p.max_tiles == 0) return 0;
-  return ks == 25 ? launch_fwd_dense_t<25, 9, 3, 4>(p, st) : launch_fwd_dense_t<49, 13, 3, 7>(p, st);
+  if (p0.max_tiles == 0) return 0;
+  DenseParams p = p0;
+  const bool tm = ks == 49 && p.tm[0] && p.tm_slots > 0 && p.row_scale && p.generalization && (p.nimg == 1 || p.tm[1]);
+  if (!tm) p.tm_slots = 0;
+  if (ks == 25) return launch_fwd_dense_t<25, 9, 3, 4, false>(p, p.max_tiles, st);
+  int rc = tm ? launch_fwd_dense_t<49, 13, 3, 7, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st) : 0;
+  if (!rc) rc = launch_fwd_dense_t<49, 13, 3, 7, false>(p, p.max_tiles, st);
+  return rc;
 }
 
 }  // namespace ssg

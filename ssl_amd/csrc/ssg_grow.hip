@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
   const int nrows = rows_to_do(p.n_dev, p.n_host);
   const int n = blockIdx.x * 4 + wv;
   float l1p = 0.f, klp = 0.f, gmax = 0.f;
-  if (n < nrows) {
+  // a NEGATIVE row scale: the row lives in the tile-major region (fused step at k_s = 49); ssg_rows_tm and the dense
+  // backward own it, nothing of it is read or written here
+  const bool tm_row = n < nrows && p.row_scale && p.mode == GRAD_LOSS && p.row_scale[n] < 0.0;
+  if (n < nrows && !tm_row) {
     const size_t base = (size_t)n * P;
     float va[EPL], vg[EPL];
     const float *src_a = p.mode == GRAD_D ? p.gin : p.ssg;
@@ -119,6 +122,153 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
       p.partials[2 * blockIdx.x + 1] = (sred[4] + sred[5]) + (sred[6] + sred[7]);
     }
   }
+}
+
+// The row pass over TILE-MAJOR rows (TmRowsParams, ssg_common.hpp): one workgroup of 16 waves per tile; wave (ck, part)
+// walks the offset rows of its eighth of the search area for the 64 pixels of chunk ck -- lane = pixel, so that every
+// load is one aligned 256-byte run and nothing is exchanged between lanes until the end.  s = tm_apply(e, row scale)
+// (the same operations the dense backward uses: both see the same bits), then per pixel
+//   criteria sums (L1Loss basic_loss.py:66, KLDistanceLoss basic_loss.py:281; same operations as criteria_elem),
+//   dot = sum_q g s (loss_util.py:224-227 differentiated: G = -(s k)(g - dot)),
+//   sum_b = sum of G over the offsets with a truncated window = -k (sum_b g s - dot sum_b s),
+//   an upper bound of |G| for the fixed-point scale of the deterministic accumulation.  The exact maximum would need
+//   dot before the pass; the bound splits g = g_l1 + g_kl: |s (g_l1 - dot_l1)| <= s (|w1| + |dot_l1|), and with
+//   s g_kl = -w2 t' (t' = the clamped s_gt, 0 where s < 1e-10), s (g_kl - dot_kl) = w2 (s - t') - s (dot_kl + w2): the
+//   first term is tracked per element, the second vanishes as sum t -> 1.  At most ~2x above the true maximum whether
+//   the L1 or the KL part dominates (a bit of the 11 spare bits of the fixed-point format).
+template <int KS, int KW>
+__global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
+  constexpr int P = KS * KS, HP = KS / 2, HK = KW / 2, NQ = 8, TY = 4, TX = 32, UNR = 7;
+  static_assert(KS % UNR == 0 && TY * TX == TM_PX, "offset rows in groups of 7; 4 x 32 tiles");
+  __shared__ float red[8][NQ][TM_PX];
+  __shared__ float wred[3][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ck = wv & 1, part = wv >> 1;
+  const int tslot = blockIdx.x;
+  if (tslot >= dense_tile_count(p.n_dense) || p.n_dense[1] != TY ||
+      !tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host))) {
+    if (threadIdx.x == 0) {
+      p.partials[2 * tslot] = 0.f;
+      p.partials[2 * tslot + 1] = 0.f;
+      if (p.gmax_part) p.gmax_part[tslot] = 0.f;
+    }
+    return;
+  }
+  const int H = p.H, W = p.W;
+  const int tx_n = (W + TX - 1) / TX, ty_n = (H + TY - 1) / TY;
+  const int tile = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
+  const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
+  const int ty0 = (tr / tx_n) * TY, tx0 = (tr % tx_n) * TX;
+  const int nrows = rows_to_do(p.n_dev, p.n_host);
+  const int y = ty0 + tm_pixel_row(ck, lane), x = tx0 + tm_pixel_col(lane);
+  int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+  if (r >= nrows) r = -1;
+  // (holes of the tile: scale 0 -> s = t = 0 -> every sum below gets an exact 0 from them)
+  const TmScale sa = tm_scale(r >= 0 ? p.row_scale[r] : 0.0), sb = tm_scale(r >= 0 ? p.row_scale[(size_t)p.n_host + r] : 0.0);
+  const float invM = 1.f / ((float)nrows * (float)P);
+  const float u1 = p.upstream ? p.upstream[0] : 1.f, u2 = p.upstream ? p.upstream[1] : 1.f;
+  const float w1m = p.w_l1 * invM * u1, w2m = p.w_kl * invM * u2;
+  const float cl = 1e-10f;
+  const float *pa = p.tm[0] + (size_t)tslot * P * TM_PX + ck * 64 + lane;
+  const float *pb = p.tm[1] + (size_t)tslot * P * TM_PX + ck * 64 + lane;
+  float l1 = 0.f, kl = 0.f, d1 = 0.f, d2 = 0.f, bs = 0.f, bg = 0.f, m1 = 0.f, m2 = 0.f;
+  const int qy0 = (KS * part) / NQ, qy1 = (KS * (part + 1)) / NQ;
+  for (int qy = qy0; qy < qy1; ++qy) {
+    const bool yb = qy < HK || qy > KS - 1 - HK, yc = qy == HP;
+#pragma unroll 1
+    for (int g0 = 0; g0 < KS; g0 += UNR) {   // (rolled: unrolled, hipcc lifts all 98 loads of the offset row to its top and spills)
+      float ea[UNR], eb[UNR];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) {
+        ea[j] = __builtin_nontemporal_load(pa + (size_t)(qy * KS + g0 + j) * TM_PX);
+        eb[j] = __builtin_nontemporal_load(pb + (size_t)(qy * KS + g0 + j) * TM_PX);
+      }
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) {
+        const int qx = g0 + j;
+        const float a = tm_apply(ea[j], sa), t = tm_apply(eb[j], sb);
+        // criteria_elem's operations (ssg_common.hpp), with the two parts of g kept apart
+        const float ac = fmaxf(a, cl), bc = fmaxf(t, cl);
+        l1 += fabsf(a - t);
+        const float rc = __builtin_amdgcn_rcpf(ac);
+        const float r0 = bc * rc;
+        const float ratio = __builtin_fmaf(__builtin_fmaf(-r0, ac, bc), rc, r0);
+        kl += bc * (0.69314718056f * __builtin_amdgcn_logf(ratio));
+        // s g in the form the dense backward uses (s * t'/s = t' without the division; sgn by scaling and clamping):
+        // d1 = sum s sgn(s - t), d2 = sum t' -- the weights come in at the end
+        const float sg = __builtin_amdgcn_fmed3f((a - t) * 0x1p126f, -1.f, 1.f);
+        const float bz = a >= cl ? bc : 0.f;
+        d1 = __builtin_fmaf(sg, a, d1);
+        d2 += bz;
+        const float gs = __builtin_fmaf(w1m * sg, a, -w2m * bz);
+        // wave-uniform 0/1 factors instead of branches: border offset; not the centre offset (G there multiplies
+        // A - B == 0 and is dropped: not part of the bound)
+        const float bm = (yb || qx < HK || qx > KS - 1 - HK) ? 1.f : 0.f, cm = (qx == HP && yc) ? 0.f : 1.f;
+        bs = __builtin_fmaf(a, bm, bs);
+        bg = __builtin_fmaf(gs, bm, bg);
+        m1 = fmaxf(m1, a * cm);
+        m2 = fmaxf(m2, fabsf(a - bz) * cm);
+      }
+    }
+  }
+  red[0][part][ck * 64 + lane] = l1;
+  red[1][part][ck * 64 + lane] = kl;
+  red[2][part][ck * 64 + lane] = d1;
+  red[3][part][ck * 64 + lane] = d2;
+  red[4][part][ck * 64 + lane] = bs;
+  red[5][part][ck * 64 + lane] = bg;
+  red[6][part][ck * 64 + lane] = m1;
+  red[7][part][ck * 64 + lane] = m2;
+  __syncthreads();
+  float l1w = 0.f, klw = 0.f, gb = 0.f;
+  if (part == 0) {   // waves 0 and 1: one lane per pixel, the eight parts in a fixed order
+    const int px = ck * 64 + lane;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float t = red[k][0][px];
+#pragma unroll
+      for (int j = 1; j < NQ; ++j) t += red[k][j][px];
+      v[k] = t;
+    }
+#pragma unroll
+    for (int k = 6; k < 8; ++k) {
+      float t = red[k][0][px];
+#pragma unroll
+      for (int j = 1; j < NQ; ++j) t = fmaxf(t, red[k][j][px]);
+      v[k] = t;
+    }
+    const float kfac = 1.f / (p.sigma * (float)(p.C * KW * KW));
+    v[2] *= w1m;    // dot_l1 = w1 sum s sgn(s - t)
+    v[3] *= -w2m;   // dot_kl = -w2 sum t'
+    const float dot = v[2] + v[3];
+    if (r >= 0) {
+      p.dot[r] = dot;
+      p.sum_b[r] = -kfac * (v[5] - dot * v[4]);
+    }
+    gb = kfac * (v[6] * (fabsf(w1m) + fabsf(v[2]) + fabsf(v[3] + w2m)) + fabsf(w2m) * v[7]) * 1.0001f;
+    l1w = wave_sum(v[0]);
+    klw = wave_sum(v[1]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gb = fmaxf(gb, __shfl_xor(gb, o, 64));
+    if (lane == 0) {
+      wred[0][ck] = l1w;
+      wred[1][ck] = klw;
+      wred[2][ck] = gb;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    p.partials[2 * tslot] = wred[0][0] + wred[0][1];
+    p.partials[2 * tslot + 1] = wred[1][0] + wred[1][1];
+    if (p.gmax_part) p.gmax_part[tslot] = fmaxf(wred[2][0], wred[2][1]);
+  }
+}
+
+int launch_rows_tm(const TmRowsParams &p, int ks, int kw, hipStream_t st) {
+  if (p.n_tiles <= 0) return 0;
+  if (ks != 49 || kw != 13) return -1;
+  hipLaunchKernelGGL((ssg_rows_tm<49, 13>), dim3((unsigned)p.n_tiles), dim3(1024), 0, st, p);
+  return (int)hipGetLastError();
 }
 
 bool grow_supported(int ks, int kw) { return (ks == 25 && kw == 9) || (ks == 49 && kw == 13); }
