@@ -243,11 +243,25 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
  * workspace, which must hold ssg_loss_workspace_bytes(...) + ssg_loss_rows_bytes(capacity, ks); the dense-tile
  * forward leaves them un-normalised, ssg_grad_rows reads them once (rescaling in registers) and nothing normalised is
  * ever written -- one write and one read of every row instead of two writes and two reads (C5: 26 -> 21 GB per step).
- * Loss and gradient are bit-identical to the materialising call.  A kernel that kept a tile's rows on chip through
- * criteria and backward would need 64 edge pixels x k_s^2 x 2 images x 4 B = 320 KB at (25,9) -- twice the LDS of a
- * CU -- or a second forward sweep; DESIGN.md section 8 has the measured costing. */
+ * Loss and gradient are bit-identical to the materialising call (row-major rows).  A kernel that kept a tile's rows
+ * on chip through criteria and backward would need 64 edge pixels x k_s^2 x 2 images x 4 B = 320 KB at (25,9) --
+ * twice the LDS of a CU -- or a second forward sweep; DESIGN.md section 8 has the measured costing.
+ *
+ * k_s = 49 (k_w 13, C 3, generalization): ssg_loss_rows_bytes() holds a second pair of regions for TILE-MAJOR rows,
+ * [slot of the plan's dense-tile list][offset q][128 pixels of the 4 x 32 tile].  A call whose dense tiles fit the
+ * region (count <= capacity / 128) and are >= 60 % full on average -- decided on the device from the plan's counts,
+ * for all tiles of the call or none -- keeps the dense tiles' rows there: the forward stores whole 256-byte runs,
+ * ssg_rows_tm reads them once (criteria, sum_q g s, border sums), and the dense backward forms G = dL/dD itself
+ * from the two rows instead of reading G rows (C5: 21 -> 15 GB per step).  Same loss and gradient as the row-major
+ * step up to fp32 rounding (measured: l1 <= 2e-7, kl <= 3e-6 relative, gradient <= 2e-7 of its maximum);
+ * bit-reproducible run to run in deterministic mode.  SSG_TILE_MAJOR=0 (environment) keeps every row row-major.
+ * ssg_loss_workspace_layout() reports where the pieces of the workspace live (byte offsets; tests and tools read
+ * the scratch rows of a finished call through it): out[0] edge list, [1] rank map, [2] plan, [3] row scales
+ * (2 x capacity doubles, negative = tile-major row), [4] / [5] row-major rows of sr / gt, [6] / [7] tile-major
+ * regions of sr / gt (0 when the size has none), out[8] = slots of a tile-major region. */
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks);
 size_t ssg_loss_rows_bytes(int capacity, int ks);
+int ssg_loss_workspace_layout(int B, int H, int W, int capacity, int ks, size_t out[9]);
 int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask,
                      int mask_kind, int mask_channels, int B, int C, int H,
                      int W, int ks, int kw, float sigma, float eps,

@@ -258,6 +258,12 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   g.sum_b = p.grad ? sum_b : nullptr;
   g.partials = p.partials;
   g.gmax_part = p.gfix ? gmax_part : nullptr;
+  if (n_tm > 0) {   // (tile-major call: ssg_grad_rows walks the plan's list of sparse rows with a capped grid)
+    g.grid_cap = 4096;
+    g.tm_hdr = plan + 1;
+    g.tm_slots = tm->slots;
+    g.sparse_order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
+  }
   int rc = (dbg_mask() & (1 << 29)) ? 0 : launch_grad_rows(g, p.ks, p.kw, st);
   if (!rc && n_tm > 0) {   // the rows of the tile-major tiles (ssg_grad_rows skipped them: negative row scale)
     TmRowsParams t{};
@@ -673,6 +679,54 @@ size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
          align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
 }
 
+// carving of the fused call's workspace (one place: loss_fwd_bwd_impl and ssg_loss_workspace_layout use it)
+struct LossWorkspace {
+  size_t edges, rank, order, plan, escratch, lscratch, row_scale, base_bytes, rows[2], tm[2];
+  int tm_slots;
+};
+static LossWorkspace carve_workspace(int B, int H, int W, int capacity, int ks) {
+  LossWorkspace w{};
+  size_t o = 0;
+  w.edges = o;
+  o += align_up(sizeof(int) * 3 * (size_t)capacity, 256);
+  w.rank = o;
+  o += align_up(sizeof(int) * (size_t)B * H * W, 256);
+  w.order = o;
+  o += align_up(sizeof(int) * (size_t)capacity, 256);
+  w.plan = o;
+  o += align_up(fwd_plan_bytes(B, H, W, capacity), 256);
+  w.escratch = o;
+  o += align_up(edge_scratch_bytes(B, H, W), 256);
+  w.lscratch = o;
+  o += align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
+  w.row_scale = o;
+  w.base_bytes = ssg_loss_workspace_bytes(B, H, W, capacity, ks);
+  const size_t region = rows_region_bytes(capacity, ks);
+  w.rows[0] = w.base_bytes;
+  w.rows[1] = w.rows[0] + region;
+  if (ks == 49) {
+    w.tm[0] = w.rows[1] + region;
+    w.tm[1] = w.tm[0] + region;
+    w.tm_slots = capacity / TM_PX;   // tm_slots * P * TM_PX floats <= one region
+  }
+  return w;
+}
+
+int ssg_loss_workspace_layout(int B, int H, int W, int capacity, int ks, size_t out[9]) {
+  if (!out || B <= 0 || H <= 0 || W <= 0 || capacity <= 0 || ks <= 0) return SSG_E_BADARG;
+  const LossWorkspace w = carve_workspace(B, H, W, capacity, ks);
+  out[0] = w.edges;
+  out[1] = w.rank;
+  out[2] = w.plan;
+  out[3] = w.row_scale;
+  out[4] = w.rows[0];
+  out[5] = w.rows[1];
+  out[6] = w.tm[0];
+  out[7] = w.tm[1];
+  out[8] = (size_t)w.tm_slots;
+  return 0;
+}
+
 static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,
                              int C, int H, int W, int ks, int kw, float sigma, float eps, int generalization, float w_l1,
                              float w_kl, int mask_stride, float lap_threshold, int capacity, float *ssg_sr,
@@ -685,31 +739,25 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   const bool fused = ssg_sr == nullptr;
   const size_t base_bytes = ssg_loss_workspace_bytes(B, H, W, capacity, ks);
   if (workspace_bytes < base_bytes + (fused ? ssg_loss_rows_bytes(capacity, ks) : 0)) return SSG_E_WORKSPACE;
+  const LossWorkspace lw = carve_workspace(B, H, W, capacity, ks);
+  char *ws = (char *)workspace;
   TileMajor tm;
   if (fused) {
-    const size_t region = rows_region_bytes(capacity, ks);
-    ssg_sr = (float *)((char *)workspace + base_bytes);
-    ssg_gt = (float *)((char *)ssg_sr + region);
+    ssg_sr = (float *)(ws + lw.rows[0]);
+    ssg_gt = (float *)(ws + lw.rows[1]);
     if (ks == 49 && kw == 13 && C == 3 && generalization && tile_major_enabled()) {
-      tm.rows[0] = (float *)((char *)ssg_gt + region);
-      tm.rows[1] = (float *)((char *)tm.rows[0] + region);
-      tm.slots = capacity / TM_PX;   // tm.slots * P * TM_PX floats <= one region
+      tm.rows[0] = (float *)(ws + lw.tm[0]);
+      tm.rows[1] = (float *)(ws + lw.tm[1]);
+      tm.slots = lw.tm_slots;
     }
   }
-  char *ws = (char *)workspace;
-  int *edges = (int *)ws;
-  ws += align_up(sizeof(int) * 3 * (size_t)capacity, 256);
-  int *rank = (int *)ws;
-  ws += align_up(sizeof(int) * (size_t)B * H * W, 256);
-  int *order = (int *)ws;
-  ws += align_up(sizeof(int) * (size_t)capacity, 256);
-  int *plan = (int *)ws;
-  ws += align_up(fwd_plan_bytes(B, H, W, capacity), 256);
-  void *escratch = ws;
-  ws += align_up(edge_scratch_bytes(B, H, W), 256);
-  void *lscratch = ws;
-  ws += align_up(ssg_loss_scratch_bytes(B, H, W, capacity, ks), 256);
-  double *row_scale = (double *)ws;
+  int *edges = (int *)(ws + lw.edges);
+  int *rank = (int *)(ws + lw.rank);
+  int *order = (int *)(ws + lw.order);
+  int *plan = (int *)(ws + lw.plan);
+  void *escratch = ws + lw.escratch;
+  void *lscratch = ws + lw.lscratch;
+  double *row_scale = (double *)(ws + lw.row_scale);
   // (deferred normalisation wherever the split backward -- whose ssg_grad_rows pass rescales -- follows)
   const bool defer = split_ok(ks, kw, C, rank, plan, lscratch) && dense_supported(ks, kw, C);
   if (!defer) tm.slots = 0;

@@ -296,6 +296,13 @@ struct GrowParams {
   float *partials;        // (grid, 2), GRAD_LOSS
   float *gmax_part;       // nullable (grid): deterministic mode, every workgroup's max|G| (reduced into the word
                           // behind the fixed-point sums by grad_fix_reduce: no atomics on one address)
+  int ngroups;            // groups of 4 rows (set by launch_grad_rows)
+  int grid_cap;           // > 0: at most this many workgroups, each walking several groups
+  // a call with a tile-major region: plan + 1 (tm_active's header), the region's slots, and the plan's list of the
+  // rows that are not in a dense tile (plan[0] of them)
+  const int *tm_hdr;
+  int tm_slots;
+  const int *sparse_order;
 };
 
 // Tile-major scratch rows (fused step at k_s = 49): the tile in slot t of the plan's dense list keeps

@@ -23,7 +23,25 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
   __shared__ float sred[12];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
-  const int n = blockIdx.x * 4 + wv;
+  // one group of 4 rows per workgroup (grid == p.ngroups), or -- a call with a tile-major region, where most groups
+  // only find out that their rows live there -- a capped grid that walks the groups; either way group g's sums go to
+  // slot g of the partial arrays (same values, same order in the finalize)
+  // (a call whose dense tiles are tile-major: only the rows NOT in a dense tile are left, taken from the plan's own
+  // list of them; the groups behind the list write their zero sums without reading anything)
+  const bool via_list = p.tm_hdr && tm_active(p.tm_hdr, p.tm_slots, nrows);
+  const int n_list = via_list ? (p.tm_hdr[-1] < nrows ? p.tm_hdr[-1] : nrows) : 0;
+  const int live_groups = via_list ? (n_list + 3) / 4 : p.ngroups;
+  // the groups behind the list: zero sums, one thread per group (no barrier, nothing read)
+  for (int g = live_groups + blockIdx.x * 256 + threadIdx.x; g < p.ngroups; g += gridDim.x * 256) {
+    if (p.gmax_part) p.gmax_part[g] = 0.f;
+    if (p.mode == GRAD_LOSS) {
+      p.partials[2 * g] = 0.f;
+      p.partials[2 * g + 1] = 0.f;
+    }
+  }
+  for (int grp = blockIdx.x; grp < live_groups; grp += gridDim.x) {
+  const int k4 = grp * 4 + wv;
+  const int n = via_list ? (k4 < n_list ? (p.sparse_order[k4] & ORDER_MASK) : nrows) : k4;
   float l1p = 0.f, klp = 0.f, gmax = 0.f;
   // a NEGATIVE row scale: the row lives in the tile-major region (fused step at k_s = 49); ssg_rows_tm and the dense
   // backward own it, nothing of it is read or written here
@@ -107,7 +125,7 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
     for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
     if (lane == 0) sred[8 + wv] = gmax;
     __syncthreads();
-    if (threadIdx.x == 0) p.gmax_part[blockIdx.x] = fmaxf(fmaxf(sred[8], sred[9]), fmaxf(sred[10], sred[11]));
+    if (threadIdx.x == 0) p.gmax_part[grp] = fmaxf(fmaxf(sred[8], sred[9]), fmaxf(sred[10], sred[11]));
   }
   if (p.mode == GRAD_LOSS) {
     l1p = wave_sum(l1p);
@@ -118,9 +136,11 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      p.partials[2 * blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
-      p.partials[2 * blockIdx.x + 1] = (sred[4] + sred[5]) + (sred[6] + sred[7]);
+      p.partials[2 * grp] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+      p.partials[2 * grp + 1] = (sred[4] + sred[5]) + (sred[6] + sred[7]);
     }
+  }
+  if (gridDim.x < (unsigned)live_groups) __syncthreads();   // (sred is reused by the next group)
   }
 }
 
@@ -141,6 +161,7 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
   constexpr int P = KS * KS, HP = KS / 2, HK = KW / 2, NQ = 8, TY = 4, TX = 32, UNR = 7;
   static_assert(KS % UNR == 0 && TY * TX == TM_PX, "offset rows in groups of 7; 4 x 32 tiles");
   __shared__ float red[8][NQ][TM_PX];
+  __shared__ double redk[NQ][TM_PX];
   __shared__ float wred[3][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ck = wv & 1, part = wv >> 1;
   const int tslot = blockIdx.x;
@@ -170,10 +191,15 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
   const float cl = 1e-10f;
   const float *pa = p.tm[0] + (size_t)tslot * P * TM_PX + ck * 64 + lane;
   const float *pb = p.tm[1] + (size_t)tslot * P * TM_PX + ck * 64 + lane;
-  float l1 = 0.f, kl = 0.f, d1 = 0.f, d2 = 0.f, bs = 0.f, bg = 0.f, m1 = 0.f, m2 = 0.f;
+  float l1 = 0.f, d1 = 0.f, d2 = 0.f, bs = 0.f, bg = 0.f, m1 = 0.f, m2 = 0.f;
+  // KL: first-order terms t log(t/s) of either sign that cancel to second order over a row (sigma = 1: to 1e-3 of
+  // their size) -- fp32 inside an offset row (49 terms), fp64 across the rows; a 300-term fp32 chain costs the
+  // cancelled total 2e-5 (measured against the fp64 KL of the same SSGs)
+  double kld = 0.0;
   const int qy0 = (KS * part) / NQ, qy1 = (KS * (part + 1)) / NQ;
   for (int qy = qy0; qy < qy1; ++qy) {
     const bool yb = qy < HK || qy > KS - 1 - HK, yc = qy == HP;
+    float kl = 0.f;
 #pragma unroll 1
     for (int g0 = 0; g0 < KS; g0 += UNR) {   // (rolled: unrolled, hipcc lifts all 98 loads of the offset row to its top and spills)
       float ea[UNR], eb[UNR];
@@ -209,9 +235,10 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
         m2 = fmaxf(m2, fabsf(a - bz) * cm);
       }
     }
+    kld += (double)kl;
   }
   red[0][part][ck * 64 + lane] = l1;
-  red[1][part][ck * 64 + lane] = kl;
+  redk[part][ck * 64 + lane] = kld;
   red[2][part][ck * 64 + lane] = d1;
   red[3][part][ck * 64 + lane] = d2;
   red[4][part][ck * 64 + lane] = bs;
@@ -225,10 +252,17 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
     float v[8];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
+      if (k == 1) continue;
       float t = red[k][0][px];
 #pragma unroll
       for (int j = 1; j < NQ; ++j) t += red[k][j][px];
       v[k] = t;
+    }
+    {
+      double t = redk[0][px];
+#pragma unroll
+      for (int j = 1; j < NQ; ++j) t += redk[j][px];
+      v[1] = (float)t;   // (the pixel's KL: non-negative up to rounding, no cancellation left)
     }
 #pragma unroll
     for (int k = 6; k < 8; ++k) {
@@ -275,9 +309,11 @@ bool grow_supported(int ks, int kw) { return (ks == 25 && kw == 9) || (ks == 49 
 
 unsigned grow_grid(int n_host) { return (unsigned)((n_host + 3) / 4); }
 
-int launch_grad_rows(const GrowParams &p, int ks, int kw, hipStream_t st) {
-  if (p.n_host <= 0) return 0;
-  const unsigned grid = grow_grid(p.n_host);
+int launch_grad_rows(const GrowParams &p0, int ks, int kw, hipStream_t st) {
+  if (p0.n_host <= 0) return 0;
+  GrowParams p = p0;
+  p.ngroups = (int)grow_grid(p.n_host);
+  const unsigned grid = p.grid_cap > 0 && p.grid_cap < p.ngroups ? (unsigned)p.grid_cap : (unsigned)p.ngroups;
   if (ks == 25 && kw == 9)
     hipLaunchKernelGGL((ssg_grad_rows<25, 9>), dim3(grid), dim3(256), 0, st, p);
   else if (ks == 49 && kw == 13)
