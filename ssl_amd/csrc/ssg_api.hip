@@ -42,7 +42,11 @@ struct DenseParams {
   float *tm[2];
   int tm_slots;
   int grid_tiles;
+  const int *strips;
+  int max_strips;
 };
+int fwd_plan_strip_offset(int B, int H, int W);
+int dense_max_strips(int B, int H, int W, int ks);
 bool dense_supported(int ks, int kw, int C);
 int dense_max_tiles(int B, int H, int W, int ks);
 int dense_tile_rows(int ks);
@@ -202,6 +206,14 @@ struct TileMajor {
   float *rows[2] = {nullptr, nullptr};
   int slots = 0;
 };
+static bool strips_enabled() {   // SSG_STRIPS=0: the tile kernel computes every tile-major tile (A/B measurements)
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SSG_STRIPS");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
+}
 static bool tile_major_enabled() {
   static int v = -1;
   if (v < 0) {
@@ -521,6 +533,8 @@ static int map_forward_impl(const float *img, const float *img2, int B, int C, i
       d.tm[0] = tm->rows[0];
       d.tm[1] = tm->rows[1];
       d.tm_slots = tm->slots;
+      d.max_strips = strips_enabled() ? dense_max_strips(B, H, W, ks) : 0;   // (k_s 49: whole strips of heavy tiles)
+      d.strips = d.max_strips ? fwd_plan + fwd_plan_strip_offset(B, H, W) : nullptr;
     }
     if (row_scale && !row_scale_zeroed) {   // 0 = "this row is already normalised" (the rows of the direct kernels)
       const int rc0 = (int)hipMemsetAsync(row_scale, 0, sizeof(double) * 2 * (size_t)n_rows, (hipStream_t)stream);
@@ -669,7 +683,13 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *ed
 static size_t rows_region_bytes(int capacity, int ks) {
   return align_up(sizeof(float) * (size_t)(capacity > 0 ? capacity : 1) * ks * ks, 256);
 }
-size_t ssg_loss_rows_bytes(int capacity, int ks) { return (ks == 49 ? 4 : 2) * rows_region_bytes(capacity, ks); }
+// (a tile-major region: capacity / 128 slots and a spare one for the short strips of ssg_fwd_strip)
+static size_t tm_region_bytes(int capacity, int ks) {
+  return align_up(sizeof(float) * ((size_t)(capacity > 0 ? capacity : 1) / TM_PX + 1) * ks * ks * TM_PX, 256);
+}
+size_t ssg_loss_rows_bytes(int capacity, int ks) {
+  return 2 * rows_region_bytes(capacity, ks) + (ks == 49 ? 2 * tm_region_bytes(capacity, ks) : 0);
+}
 
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
   return align_up(sizeof(int) * 3 * (size_t)(capacity > 0 ? capacity : 1), 256) +
@@ -706,8 +726,8 @@ static LossWorkspace carve_workspace(int B, int H, int W, int capacity, int ks) 
   w.rows[1] = w.rows[0] + region;
   if (ks == 49) {
     w.tm[0] = w.rows[1] + region;
-    w.tm[1] = w.tm[0] + region;
-    w.tm_slots = capacity / TM_PX;   // tm_slots * P * TM_PX floats <= one region
+    w.tm[1] = w.tm[0] + tm_region_bytes(capacity, ks);
+    w.tm_slots = capacity / TM_PX;
   }
   return w;
 }

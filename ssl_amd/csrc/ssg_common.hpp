@@ -113,6 +113,14 @@ __device__ __forceinline__ void pin_block(float (&v)[R][N]) {
 // 64 edge pixels (two or more 64-lane chunks in the forward's edge stage, i.e. the longest workgroups) are appended
 // from the front of the `n_super` slots, the others from the back, and slot t walks the heavy ones first: longest jobs
 // first shortens the kernel's tail (list scheduling of ~2,000 workgroups on 512 slots: -12 % makespan in a model).
+// k_s 49: a STRIP of STRIP_ROWS x 32 centres = nine 4-row tiles (fewer at the bottom of the image), all of them heavy,
+// is listed in the plan's strip list with the position of its first tile in the dense list -- the strip's tiles occupy
+// consecutive positions there, i.e. consecutive slots of the tile-major region -- and its tiles' ids carry
+// TILE_IN_STRIP: in a tile-major call ssg_fwd_strip computes their forward rows (E/H shared by 36 centre rows instead
+// of 4) and the tile kernel skips them; every other consumer masks the bit off (dense_tile_id).
+constexpr int STRIP_ROWS = 36;
+constexpr int TILE_IN_STRIP = 1 << 30;
+__device__ __forceinline__ int dense_tile_id(int listed) { return listed & ~TILE_IN_STRIP; }
 __device__ __forceinline__ int dense_tile_count(const int *hdr) { return hdr[0] + hdr[2]; }
 __device__ __forceinline__ int dense_tile_at(const int *hdr, const int *tiles, int n_super, int tslot) {
   const int nh = hdr[0];

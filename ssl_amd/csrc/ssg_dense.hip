@@ -111,6 +111,8 @@ struct DenseParams {
   float *tm[2];
   int tm_slots;
   int grid_tiles;  // plan slots this launch covers (per image)
+  const int *strips;  // k_s 49 tile-major calls: [0] number of strips, then (strip id, first slot) pairs; nullable
+  int max_strips;     // launch bound per image
 };
 
 constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1) (8 for k_w = 9, 4 for k_w = 13)
@@ -184,7 +186,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if (p.n_dense[1] != DT_Y) __builtin_trap();
   const int H = p.H, W = p.W;
   const int tx_n = (W + DT_X - 1) / DT_X, ty_n = (H + DT_Y - 1) / DT_Y;
-  const int tile = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
+  const int listed = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
+  if (TM && p.strips && (listed & TILE_IN_STRIP)) return;   // a strip (ssg_fwd_strip) computes this tile's rows
+  const int tile = dense_tile_id(listed);
   const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
   const int ty0 = (tr / tx_n) * DT_Y, tx0 = (tr % tx_n) * DT_X;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
@@ -631,6 +635,322 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 }
 
+
+// ------------------------------------------------------------------ strips (k_s 49, tile-major rows) ----
+// The tile kernel above computes E_q and its horizontal sums on 16 U-rows to serve DT_Y = 16 - (k_w - 1) centre rows:
+// at k_w 13 that is 4 rows of 16, a four-fold overhead on the part of the kernel that does not depend on the number of
+// edge pixels -- and C5 is a 100 % mask.  A strip is SY = 16 NW - (k_w - 1) centre rows x 32 columns (36 rows for NW =
+// 3): NW waves own 16 U-rows each (the lane map, the window and the horizontal sums are the tile kernel's), walk ALL
+// k_s^2 offsets in lockstep and exchange the horizontal sums through a double-buffered H array (one s_barrier per
+// offset): the overhead falls to 48 / 36.  Every lane owns PX = 6 centres of one column (rows 6 seg .. 6 seg + 5) for
+// the whole kernel: their 13-tap vertical windows share 18 H values (a tree of 48 additions for the six sums) and the
+// row sums stay in the lane's registers (no reduction over waves).
+// The rows go to the TILE-MAJOR region only (round 3 measured the same kernel on row-major rows: compute 2.0 ms against
+// the tile kernel's 2.9 at C5, but 5.2 ms with 1,152 row-major rows open per workgroup): the strip's tiles hold
+// consecutive slots of the region (strip_select, ssg_edges.hip), a half-wave's 32 centres of one tile row are one
+// aligned 128-byte run of slot (first + row / 4) at every offset, holes included.
+// The image region does not fit LDS for 36 + 2 HALO rows and is not needed at once: offset row q_y touches region
+// rows q_y .. q_y + 47 only, a BAND of 48 rows kept as a ring (region row rho at slot rho % 48); one new row per q_y
+// is fetched at the top of the q_y loop and stored after its last step.
+template <int KS, int KW, int C, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_fwd_strip(DenseParams p) {
+  constexpr int NT = 64 * NW;
+  constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK;
+  constexpr int UH = 16 * NW, SY = UH - 2 * HK;                  // U-rows and centre rows of a strip
+  constexpr int RWD = DT_X + 2 * HALO, RS = RWD + 1;             // band row
+  constexpr int UW = DT_X + 2 * HK;
+  constexpr int L = dense_lane_px(KW), HL = L / 2, NV = HL + KW - 1;
+  constexpr int HS = DT_X + 1;                                   // H row stride: gathers AND the dword stores conflict-free
+  constexpr int PX = SY * DT_X / NT, NHV = PX + KW - 1;          // centres per lane (one column), H values they share
+  static_assert(SY == STRIP_ROWS && SY * DT_X == PX * NT && NT % DT_X == 0 && (NT / DT_X) * PX == SY && 4 * L >= UW && L % 2 == 0 &&
+                KW - 1 <= L && KW == 13 && PX == 6, "lane maps: 16 U-rows per wave, 6 centres of a column per lane");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *band = smem;                 // [C][UH][RS]  region rows q_y .. q_y + UH - 1, row rho at slot rho % UH
+  float *HF = band + C * UH * RS;     // [UH][HS]     full-window horizontal sums of |I|^2
+  float *Hb = HF + UH * HS;           // [2][UH][HS]  horizontal sums of E_q, double-buffered over the steps
+  float *F = Hb + 2 * UH * HS;        // [UH][UW]     |I|^2 on U (the columns a truncated window leaves behind)
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int which = blockIdx.x / p.max_strips, slot = blockIdx.x - which * p.max_strips;
+  if (slot >= p.strips[0]) return;
+  const int nrows = rows_to_do(p.n_dev, p.n_host);
+  if (!tm_active(p.n_dense, p.tm_slots, nrows)) return;   // (row-major call: the tile kernel computes these tiles)
+  const int H = p.H, W = p.W;
+  const int tx_n = (W + DT_X - 1) / DT_X, sy_n = (H + SY - 1) / SY;
+  const int strip = p.strips[1 + 2 * slot], first = p.strips[2 + 2 * slot];
+  const int b = strip / (tx_n * sy_n), tr = strip - b * tx_n * sy_n;
+  const int ty0 = (tr / tx_n) * SY, tx0 = (tr % tx_n) * DT_X;
+  const float *src = p.img[which] + (size_t)b * C * H * W;
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // region rows rho0 .. rho0 + UH - 1 into the band (reflect by index mirroring, clamped like the tile kernel's)
+  auto fill_band = [&](int rho0) {
+    constexpr int CPLF = (RWD + 15) / 16, RPP = NT / 16;
+    const int lx = tid % 16, lr = tid / 16;
+    for (int R0 = 0; R0 < C * UH; R0 += RPP) {
+      const int R = R0 + lr;
+      const int c = R / UH, i = R - c * UH, rho = rho0 + i;
+      int gy = reflect_idx(ty0 - HALO + rho, H);
+      gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+      const float *srow = src + ((size_t)c * H + gy) * W;
+      float v[CPLF];
+#pragma unroll
+      for (int k = 0; k < CPLF; ++k) {
+        int gx = reflect_idx(tx0 - HALO + lx + 16 * k, W);
+        gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+        v[k] = srow[gx];
+      }
+      float *drow = band + (c * UH + rho % UH) * RS;
+#pragma unroll
+      for (int k = 0; k < CPLF; ++k)
+        if (lx + 16 * k < RWD) drow[lx + 16 * k] = v[k];
+    }
+  };
+  static_assert((C * UH) % (NT / 16) == 0, "whole row passes");
+
+  // ---- set-up on the U rows themselves (region rows HP .. HP + UH - 1): own pixels, |I|^2 and its sums ----
+  fill_band(HP);
+  __syncthreads();
+  const int r = lane >> 2, g = lane & 3, R = 16 * wv + r;   // U-row of the lane
+  f2 iu[C][HL];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const float *q = band + (c * UH + (R + HP) % UH) * RS + L * g + HP + j;
+      iu[c][j] = f2{q[0], q[HL]};
+    }
+  for (int i = tid; i < UH * UW; i += NT) {
+    const int ur = i / UW, uc = i - ur * UW;
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float v = band[(c * UH + (ur + HP) % UH) * RS + uc + HP];
+      t = __builtin_fmaf(v, v, t);
+    }
+    F[i] = t;
+  }
+  __syncthreads();
+  for (int i = tid; i < UH * DT_X; i += NT) {
+    const int ur = i / DT_X, tc = i - ur * DT_X;
+    float t = 0.f;
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) t += F[ur * UW + tc + kx];
+    HF[ur * HS + tc] = t;
+  }
+  // |I|^2 on the pixels the lane's windows reach, Fv(m) = (F[m], F[m + L/2]) counted from the lane's first pixel
+  // (the tile kernel keeps these 18 pairs in registers; here they are read when a truncated step needs them: 12 of
+  // 49 steps).  The last group's columns past UW belong to centres outside the strip: clamped to the row.
+  const int frow_off = R * UW + (g < 3 ? L * g : UW - NV - HL);
+  __syncthreads();
+  fill_band(0);
+
+  // ---- the lane's PX centres: rows e0 .. e0 + PX - 1 of column ecol ----
+  // Centre j lives in the strip's tile (e0 + j) / 4 = slot first + (e0 + j) / 4 of the tile-major region, at pixel
+  // index 64 (ey & 1) + 32 (ey >> 1) + column, ey = (e0 + j) % 4 (tm_pixel_row / tm_pixel_col inverted): a uniform
+  // base per offset + one 32-bit element offset per centre.
+  // A strip at the bottom of the image has fewer than nine tiles: the centres below them go to the region's spare
+  // slot (index tm_slots, behind the last real one: written by every short strip, read by nobody).
+  const int ecol = tid % DT_X, e0 = (tid / DT_X) * PX;
+  const int ty_n = (H + 3) / 4, n_tq = ty_n - ty0 / 4 < SY / 4 ? ty_n - ty0 / 4 : SY / 4;
+  int orow[PX];
+  float *cptr[PX];
+#pragma unroll
+  for (int j = 0; j < PX; ++j) {
+    const int y = ty0 + e0 + j, x = tx0 + ecol;
+    const int rk = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+    orow[j] = rk >= nrows ? -1 : rk;
+    const int tq = (e0 + j) >> 2, ey = (e0 + j) & 3;
+    cptr[j] = p.tm[which] + (size_t)(tq < n_tq ? first + tq : p.tm_slots) * (P * TM_PX) + (64 * (ey & 1) + 32 * (ey >> 1) + ecol);
+  }
+  int pf_gx = reflect_idx(tx0 - HALO + (tid < RWD ? tid : 0), W);   // column of the band row this thread fetches
+  pf_gx = pf_gx < 0 ? 0 : (pf_gx >= W ? W - 1 : pf_gx);
+  const float nk = (float)(-1.4426950408889634 / ((double)(C * KW * KW) * (double)p.sigma));
+  double rs[PX];
+#pragma unroll
+  for (int j = 0; j < PX; ++j) rs[j] = 0.0;
+  float *hwrite = Hb + R * HS + L * g;          // the lane's centres L g .. L g + L - 1 (those < DT_X are stored)
+  const float *hread = Hb + e0 * HS + ecol;     // window row k of centre j is U-row e0 + j + k
+  const float *hfread = HF + e0 * HS + ecol;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int qyi = 0; qyi < KS; ++qyi) {
+    // the band row the NEXT q_y needs (region row qyi + UH), fetched now, stored after this row's last step
+    float pf[C];
+    if (qyi + 1 < KS && tid < RWD) {   // one column per thread, C uniform row pointers
+      int gy = reflect_idx(ty0 - HALO + qyi + UH, H);
+      gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+#pragma unroll
+      for (int c = 0; c < C; ++c) pf[c] = src[((size_t)c * H + gy) * W + pf_gx];
+    }
+    const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
+    float wgt[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+      wgt[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((k - HK >= ylo && k - HK <= yhi) ? 0x3f800000 : 0));
+    const bool interior = ylo == -HK && yhi == HK;
+    float av[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) av[j] = 0.f;
+    if (!interior) {
+      float hf[NHV], cw[KW];
+#pragma unroll
+      for (int t = 0; t < NHV; ++t) hf[t] = hfread[t * HS];
+#pragma unroll
+      for (int k = 0; k < KW; ++k) cw[k] = 1.f - wgt[k];
+#pragma unroll
+      for (int j = 0; j < PX; ++j) {
+        float fv[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) fv[k] = hf[j + k];
+        av[j] = tap_sum<KW>(fv, cw, 0.f);
+      }
+    }
+    const float *rq = band + ((R + qyi) % UH) * RS + L * g;  // + c*UH*RS + column
+    f2 w[C][HL];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int t = 0; t < HL; ++t) w[c][t] = f2{rq[c * UH * RS + t], rq[c * UH * RS + t + HL]};
+    // step (qyi, qxi) writes H buffer (qyi + qxi) % 2 (k_s is odd: the parity alternates across rows too)
+    float *hw_even = hwrite + (qyi & 1) * UH * HS, *hw_odd = hwrite + ((qyi & 1) ^ 1) * UH * HS;
+    const float *hr_even = hread + (qyi & 1) * UH * HS, *hr_odd = hread + ((qyi & 1) ^ 1) * UH * HS;
+    static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
+      constexpr int qxi = decltype(qc)::value;
+      constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
+      f2 E[HL];
+#pragma unroll
+      for (int j = 0; j < HL; ++j) {
+        const int a = (j + qxi) % L;
+        f2 t = f2{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const f2 wv2 = a < HL ? w[c][a] : w[c][a - HL].yx;
+          const f2 d = iu[c][j] - wv2;
+          t = __builtin_elementwise_fma(d, d, t);
+        }
+        E[j] = t;
+      }
+      float hs[L];
+      if constexpr (xlo == -HK && xhi == HK) {
+        float Pf[L], Sf[L];
+        static_for(std::make_integer_sequence<int, HL>{}, [&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const f2 pl = sum_from<0, m + 1>(E);
+          const f2 su = sum_upto<HL, HL - m>(E);
+          const f2 tot = sum_from<0, HL>(E);
+          Pf[m] = pl.x;
+          Pf[m + HL] = tot.x + pl.y;
+          Sf[m + HL] = su.y;
+          Sf[m] = su.x + tot.y;
+        });
+        static_for(std::make_integer_sequence<int, L>{}, [&](auto kc) {
+          constexpr int k = decltype(kc)::value, last = k + KW - 1;
+          if constexpr (last < L) hs[k] = k == 0 ? Pf[last] : Sf[k];
+          else hs[k] = Sf[k] + quad_next<1>(Pf[last - L]);
+        });
+      } else {
+        // (|I|^2 does not depend on q_y: left alone, the compiler hoists the sums of the taps left behind out of the
+        // q_y loop -- 144 registers)
+        int fo = frow_off;
+        asm volatile("" : "+v"(fo));
+        const float *frow = F + fo;
+        f2 V[NV];
+#pragma unroll
+        for (int m = 0; m < NV; ++m) {
+          if (m < HL) V[m] = E[m];
+          else if (m < L) V[m] = f2{E[m - HL].y, quad_next<1>(E[m - HL].x)};
+          else V[m] = f2{quad_next<1>(E[m - L].x), quad_next<1>(E[m - L].y)};
+        }
+#pragma unroll
+        for (int k = 0; k < HL; ++k) {
+          f2 t = f2{0.f, 0.f};
+          bool first_tap = true;
+#pragma unroll
+          for (int tp = 0; tp < KW; ++tp) {
+            const bool kept = tp - HK >= xlo && tp - HK <= xhi;
+            const f2 v = kept ? V[k + tp] : f2{frow[k + tp], frow[k + tp + HL]};
+            t = first_tap ? v : t + v;
+            first_tap = false;
+          }
+          hs[k] = t.x;
+          hs[k + HL] = t.y;
+        }
+      }
+      float *hw = qxi % 2 == 0 ? hw_even : hw_odd;
+#pragma unroll
+      for (int k = 0; k < L; ++k)
+        if (L * g + k < DT_X) hw[k] = hs[k];
+      if (qxi + 1 < KS) {
+        constexpr int sl = qxi % L;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float v = rq[c * UH * RS + L + qxi];
+          if constexpr (sl < HL) w[c][sl].x = v;
+          else w[c][sl - HL].y = v;
+        }
+      }
+      // every wave's H rows of this step are in LDS; the next step writes the OTHER buffer, and the one after it
+      // comes behind the next barrier, which no wave passes before all have finished the reads below
+      lds_barrier();
+      const float *hc = qxi % 2 == 0 ? hr_even : hr_odd;
+      float hv[NHV];
+#pragma unroll
+      for (int t = 0; t < NHV; ++t) hv[t] = hc[t * HS];
+      float d[PX];
+      if (interior) {
+        // all 13 taps kept: blocks of 2, 4 and 8 consecutive H values shared between the six windows
+        float s2[NHV - 2], s4[NHV - 4], s8[PX];
+#pragma unroll
+        for (int i = 0; i < NHV - 2; ++i) s2[i] = hv[i] + hv[i + 1];
+#pragma unroll
+        for (int i = 0; i < NHV - 4; ++i) s4[i] = s2[i] + s2[i + 2];
+#pragma unroll
+        for (int i = 0; i < PX; ++i) s8[i] = s4[i] + s4[i + 4];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) d[j] = (s8[j] + s4[j + 8]) + hv[j + 12];
+      } else {
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+          // (weights are wave-uniform: scalar operands of plain FMAs, four accumulators)
+          float a0 = av[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+          for (int k = 0; k < KW; ++k) {
+            float &acc = k % 4 == 0 ? a0 : (k % 4 == 1 ? a1 : (k % 4 == 2 ? a2 : a3));
+            acc = __builtin_fmaf(wgt[k], hv[j + k], acc);
+          }
+          d[j] = (a0 + a1) + (a2 + a3);
+        }
+      }
+      // e, row sums, stores: every half-wave's 32 values of a centre row are one aligned 128-byte run
+#pragma unroll
+      for (int j = 0; j < PX; ++j) {
+        const float ev = __builtin_amdgcn_exp2f(d[j] * nk);
+        // (row sums in fp64 from the first addition: an fp32 chain over one offset row leaves the sum -- hence the
+        // whole row's scale -- a relative 1e-7 off, which the KL part of the gradient sees as 1e-4 of itself)
+        rs[j] += (double)ev;
+        asm volatile("" : "+v"(rs[j]));   // (or the additions sink to the end of the row, with every e kept for them)
+        cptr[j][qyi * (KS * TM_PX) + qxi * TM_PX] = ev;
+      }
+    });
+    if (qyi + 1 < KS) {
+      // (the last step's barrier is behind every wave's last read of region row qyi, whose slot this is)
+      if (tid < RWD) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) band[(c * UH + qyi % UH) * RS + tid] = pf[c];
+      }
+      lds_barrier();
+    }
+  }
+  // deferred normalisation, the tile-major mark (see the tile kernel)
+  double *rsc = p.row_scale + (size_t)which * p.n_host;
+#pragma unroll
+  for (int j = 0; j < PX; ++j)
+    if (orow[j] >= 0) rsc[orow[j]] = -1.0 / (rs[j] + (double)p.eps);
+}
+
 // ------------------------------------------------------------------ host ----
 template <int KS, int KW, int C, int NW>
 static size_t dense_lds_bytes() {
@@ -661,6 +981,21 @@ static int launch_fwd_dense_t(DenseParams p, int n_tiles, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// strips of ssg_fwd_strip: STRIP_ROWS x 32 centres (k_s 49 only)
+int dense_max_strips(int B, int H, int W, int ks) {
+  return ks == 49 ? B * ((H + STRIP_ROWS - 1) / STRIP_ROWS) * ((W + DT_X - 1) / DT_X) : 0;
+}
+
+template <int KS, int KW, int C, int NW>
+static int launch_fwd_strip_t(const DenseParams &p, hipStream_t st) {
+  constexpr int UH = 16 * NW, HALO = KS / 2 + KW / 2, RS = DT_X + 2 * HALO + 1, HS = DT_X + 1;
+  const size_t lds = sizeof(float) * (size_t)(C * UH * RS + 3 * UH * HS + UH * (DT_X + KW - 1) + 8);
+  static std::atomic<unsigned long long> lds_set{0};
+  if (const int rc = ensure_dynamic_lds(ssg_fwd_strip<KS, KW, C, NW>, (int)lds, lds_set)) return rc;
+  hipLaunchKernelGGL((ssg_fwd_strip<KS, KW, C, NW>), dim3((unsigned)p.max_strips * p.nimg), dim3(64 * NW), lds, st, p);
+  return (int)hipGetLastError();
+}
+
 // a call with a tile-major region (k_s 49, fused step with a row-scale array) launches both variants over the tile
 // list; tm_active() -- device-side, from the plan's counts -- lets one of them run
 int launch_fwd_dense(const DenseParams &p0, int ks, int kw, int C, hipStream_t st) {
@@ -670,7 +1005,9 @@ int launch_fwd_dense(const DenseParams &p0, int ks, int kw, int C, hipStream_t s
   const bool tm = ks == 49 && p.tm[0] && p.tm_slots > 0 && p.row_scale && p.generalization && (p.nimg == 1 || p.tm[1]);
   if (!tm) p.tm_slots = 0;
   if (ks == 25) return launch_fwd_dense_t<25, 9, 3, 4, false>(p, p.max_tiles, st);
-  int rc = tm ? launch_fwd_dense_t<49, 13, 3, 7, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st) : 0;
+  if (!tm) p.strips = nullptr;
+  int rc = (tm && p.strips && p.max_strips > 0) ? launch_fwd_strip_t<49, 13, 3, 3>(p, st) : 0;
+  if (!rc && tm) rc = launch_fwd_dense_t<49, 13, 3, 7, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st);
   if (!rc) rc = launch_fwd_dense_t<49, 13, 3, 7, false>(p, p.max_tiles, st);
   return rc;
 }

@@ -204,8 +204,10 @@ __device__ __forceinline__ int super_tile_of(int b, int y, int x, int H, int W, 
 
 // one wave per super-tile: count its edge pixels (rank map), flag it dense at >= thr and append it to the dense
 // list (plan[1] / plan[3] = counts of heavy / light tiles, zeroed by edge_scan)
+// `strips` (k_s 49, 4-row tiles): the lists are built later (strip_select, plan_append) -- only the count is left in
+// dflag (0 = not dense) and the strip list's counter is cleared
 __global__ __launch_bounds__(256) void plan_count(const int *rank, int B, int H, int W, int sty, int thr, int *dflag,
-                                                  int *plan, int *dense_ids, int *tcnt) {
+                                                  int *plan, int *dense_ids, int *tcnt, int *strips) {
   const int sx_n = (W + 31) / 32, sy_n = (H + sty - 1) / sty;
   const int st = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (st >= B * sy_n * sx_n) return;
@@ -241,13 +243,54 @@ __global__ __launch_bounds__(256) void plan_count(const int *rank, int B, int H,
   }
   if (lane == 0) {
     const int dense = thr > 0 && n >= thr;
+    if (st == 0) plan[2] = sty;
+    if (strips) {
+      dflag[st] = dense ? n : 0;
+      if (st == 0) strips[0] = 0;
+      return;
+    }
     dflag[st] = dense;
     if (dense) {   // heavy tiles from the front, light ones from the back (dense_tile_at, ssg_common.hpp)
       if (n > 64) dense_ids[atomicAdd(&plan[1], 1)] = st;
       else dense_ids[B * sy_n * sx_n - 1 - atomicAdd(&plan[3], 1)] = st;
     }
-    if (st == 0) plan[2] = sty;
   }
+}
+
+// k_s 49: a strip of STRIP_ROWS x 32 centres (nine 4-row tiles, fewer at the bottom of the image) is listed for
+// ssg_fwd_strip when every tile it covers is heavy (> 64 edge pixels).  Its tiles take CONSECUTIVE places at the front
+// of the dense list (one atomic for the whole strip: place = slot of the tile-major region) with TILE_IN_STRIP set, and
+// their counts are negated so that plan_append leaves them alone.  One thread per strip; strips[0] = number of
+// strips, then (strip id, first place) pairs.
+__global__ __launch_bounds__(256) void strip_select(int B, int H, int W, int *dflag, int *plan, int *dense_ids, int *strips) {
+  constexpr int TPS = STRIP_ROWS / 4;
+  const int sx_n = (W + 31) / 32, sy_n = (H + 3) / 4, ss_n = (H + STRIP_ROWS - 1) / STRIP_ROWS;
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= B * ss_n * sx_n) return;
+  const int b = s / (ss_n * sx_n), t = s - b * ss_n * sx_n, ssy = t / sx_n, sx = t - ssy * sx_n;
+  const int r0 = ssy * TPS, r1 = r0 + TPS < sy_n ? r0 + TPS : sy_n;
+  int *f = dflag + ((size_t)b * sy_n) * sx_n + sx;
+  bool all = true;
+  for (int rr = r0; rr < r1; ++rr) all = all && f[rr * sx_n] > 64;
+  if (!all) return;
+  const int first = atomicAdd(&plan[1], r1 - r0);
+  for (int rr = r0; rr < r1; ++rr) {
+    f[rr * sx_n] = -f[rr * sx_n];
+    dense_ids[first + rr - r0] = ((b * sy_n + rr) * sx_n + sx) | TILE_IN_STRIP;
+  }
+  const int k = atomicAdd(&strips[0], 1);
+  strips[1 + 2 * k] = s;
+  strips[2 + 2 * k] = first;
+}
+
+// the rest of the dense tile list from the counts plan_count left (negative: listed by strip_select)
+__global__ __launch_bounds__(256) void plan_append(int ns, const int *dflag, int *plan, int *dense_ids) {
+  const int st = blockIdx.x * 256 + threadIdx.x;
+  if (st >= ns) return;
+  const int n = dflag[st];
+  if (n <= 0) return;
+  if (n > 64) dense_ids[atomicAdd(&plan[1], 1)] = st;
+  else dense_ids[ns - 1 - atomicAdd(&plan[3], 1)] = st;
 }
 
 // plan_count for 8-row super-tiles without touching the rank map: a super-tile's edge-pixel count is the sum of the four
@@ -409,12 +452,16 @@ size_t edge_scratch_bytes(int B, int H, int W) {
   return (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64;
 }
 
+static size_t n_strips(int B, int H, int W) { return (size_t)B * ((H + STRIP_ROWS - 1) / STRIP_ROWS) * ((W + 31) / 32); }
+
 // forward plan: [0] n_sparse, [1] n_heavy, [2] tile rows, [3] n_light, [4, 4+ns) the dense kernels' super-tile ids (heavy from the front, light from the back; ns =
-// n_super_tiles), then (capacity) the tile-major order of the rows left to the direct kernels
-int fwd_plan_order_offset(int B, int H, int W) { return 4 + (int)n_super_tiles(B, H, W); }
+// n_super_tiles), then the k_s 49 forward's strip list (count, then n_strips (strip id, first place) pairs), then
+// (capacity) the tile-major order of the rows left to the direct kernels
+int fwd_plan_strip_offset(int B, int H, int W) { return 4 + (int)n_super_tiles(B, H, W); }
+int fwd_plan_order_offset(int B, int H, int W) { return fwd_plan_strip_offset(B, H, W) + 1 + 2 * (int)n_strips(B, H, W); }
 
 size_t fwd_plan_bytes(int B, int H, int W, int capacity) {
-  return sizeof(int) * (4 + (size_t)(capacity > 0 ? capacity : 1) + n_super_tiles(B, H, W));
+  return sizeof(int) * ((size_t)fwd_plan_order_offset(B, H, W) + (size_t)(capacity > 0 ? capacity : 1));
 }
 
 static void build_order(const int *rank, int B, int H, int W, int *order, int capacity, const int *edges,
@@ -447,14 +494,21 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   if (order) build_order(rank, B, H, W, order, capacity, edges, counts, !plan, tcnt, toff, st);
   if (plan) {
     const int sty = plan_tile_rows;
-    const int ns_max = (int)n_super_tiles(B, H, W), ns = B * ((H + sty - 1) / sty) * ((W + 31) / 32);
-    int *dflag = toff + nt, *order2 = plan + 4 + ns_max;
+    const int ns = B * ((H + sty - 1) / sty) * ((W + 31) / 32);
+    int *dflag = toff + nt, *order2 = plan + fwd_plan_order_offset(B, H, W);
+    int *strips = plan + fwd_plan_strip_offset(B, H, W);
     if (sty == OT) {   // 8-row super-tiles = four order tiles each: counts are already there
       hipLaunchKernelGGL(plan_from_tile_counts, dim3((ns + 255) / 256), dim3(256), 0, st, B, H, W, dense_thr, dflag, plan,
                          plan + 4, tcnt);
     } else {
+      const bool with_strips = sty == 4;
       hipLaunchKernelGGL(plan_count, dim3((ns + 3) / 4), dim3(256), 0, st, rank, B, H, W, sty, dense_thr, dflag, plan,
-                         plan + 4, nullptr);
+                         plan + 4, nullptr, with_strips ? strips : nullptr);
+      if (with_strips) {
+        const int nstr = (int)n_strips(B, H, W);
+        hipLaunchKernelGGL(strip_select, dim3((nstr + 255) / 256), dim3(256), 0, st, B, H, W, dflag, plan, plan + 4, strips);
+        hipLaunchKernelGGL(plan_append, dim3((ns + 255) / 256), dim3(256), 0, st, ns, dflag, plan, plan + 4);
+      }
       hipLaunchKernelGGL(tile_count_sparse, dim3((nt + 3) / 4), dim3(256), 0, st, rank, B, H, W, nt, sty, dflag, tcnt);
     }
     hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, tcnt, toff, nt, plan);

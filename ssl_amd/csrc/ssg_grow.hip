@@ -176,7 +176,7 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
   }
   const int H = p.H, W = p.W;
   const int tx_n = (W + TX - 1) / TX, ty_n = (H + TY - 1) / TY;
-  const int tile = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
+  const int tile = dense_tile_id(dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot));
   const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
   const int ty0 = (tr / tx_n) * TY, tx0 = (tr % tx_n) * TX;
   const int nrows = rows_to_do(p.n_dev, p.n_host);

@@ -1252,8 +1252,8 @@ def test_fused_step_without_ssg_output(dev, ks, kw, shape, density, tile_major):
     never written back.  Row-major scratch rows (dense-tile sizes, a size that only the direct kernels serve, and a
     k_s = 49 mask whose 4 x 32 tiles are under 60 % full): loss and gradient are the BITS of the materialising call.
     Tile-major scratch rows (k_s = 49, full tiles): the same numbers up to fp32 rounding -- the rows are scaled by a
-    float pair instead of a double, G is formed inside the dense backward (measured: l1 2e-7, kl 3e-6 relative,
-    gradient 2e-7 of its maximum).  A too-small workspace must be refused."""
+    float pair instead of a double, G is formed inside the dense backward, whole strips of tiles come from
+    ssg_fwd_strip (measured: l1 2e-7, kl 3e-6 relative; gradient: see below).  A too-small workspace must be refused."""
     import ctypes
     from ssl_amd import _lib, engine, synth
     B, C, H, W = shape
@@ -1278,7 +1278,11 @@ def test_fused_step_without_ssg_output(dev, ks, kw, shape, density, tile_major):
         assert bool((scales < 0).all()) == tile_major and (tile_major or bool((scales >= 0).all()))
     if tile_major:
         assert abs(float(la[0] - lb[0])) <= 1e-6 * float(la[0]) and abs(float(la[1] - lb[1])) <= 1e-5 * float(la[1])
-        assert float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max())
+        # (the strip forward sums the same terms in another order: e differs in its last bit, and a few of the L1 entries
+        # whose sign(s_sr - s_gt) fp32 does not decide -- 50 to 500 per case -- flip; each moves the gradient by ~1e-5 of
+        # its maximum.  With the GPU's own signs both steps are within 5e-7 of the fp64 oracle: tools/tm_oracle.py and
+        # test_tile_major_fused_step_k49_vs_oracle.  Measured here: 1.9e-5.)
+        assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
         lb1, gb1 = lb.clone(), gb.clone()
         lb2, gb2 = b(T(sr, dev), T(gt, dev), T(mask, dev))
         assert torch.equal(lb1, lb2) and torch.equal(gb1, gb2)       # deterministic mode: run-to-run bits
@@ -1319,6 +1323,7 @@ def tile_major_ssg(step):
     seen = np.zeros(n, bool)
     for slot in range(nh + nl):
         tile = int(plan[4 + slot]) if slot < nh else int(plan[4 + ns - 1 - (slot - nh)])
+        tile &= ~(1 << 30)      # TILE_IN_STRIP: the tile's forward rows came from ssg_fwd_strip
         b, tr = divmod(tile, ty_n * tx_n)
         y, x = (tr // tx_n) * 4 + ey, (tr % tx_n) * 32 + ex
         ok = (y < H) & (x < W)
