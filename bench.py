@@ -362,6 +362,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-module", action="store_true", help="skip the SSGLoss (nn.Module) timing")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` block (C5 and the fused steps)")
+    ap.add_argument("--no-kernel-table", action="store_true",
+                    help="skip the per-kernel table (it launches the kernels one at a time through the separate entry "
+                         "points): a rocprofv3 run of the fused step then shows that step's own kernels only")
     ap.add_argument("--no-ssg-output", action="store_true",
                     help="the fused step of the C ABI (ssg_sr = ssg_gt = NULL): a SEPARATE metric with SURVEY 8d's "
                          "B_alg' = (12C+4)HW/N -- not comparable with the default line")
@@ -471,6 +474,16 @@ def main():
             res["config"]["l1"], res["config"]["kl"] = float(loss[0]), float(loss[1])
             b_alg = alg_bytes_per_edge_px(cfg, n_edges, B) - (8.0 * cfg["ks"] ** 2 if args.no_ssg_output else 0.0)
             it = max(3, min(args.steps, 10))
+            if args.no_kernel_table:
+                step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), it)
+                ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
+                res["roofline"] = {"alg_bytes_per_edge_px": b_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS}}
+                print(json.dumps(res))
+                if use_dist:
+                    dist.barrier()
+                    dist.destroy_process_group()
+                return
             # (per-kernel times: through the separate entry points, which need SSG tensors of their own)
             step_k = step if not args.no_ssg_output else engine.LossStep(
                 B, C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1, W_KL, device=dev,

@@ -18,7 +18,7 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (se
        "kernels": {}}
 cfg, vals = None, collections.defaultdict(dict)
 for line in open(src):
-    m = re.match(r"===== (c\d)", line)
+    m = re.match(r"===== (c\d\w*)", line)
     if m:
         cfg = m.group(1)
         continue
@@ -28,7 +28,7 @@ for line in open(src):
     vals[(cfg, name)].update((k, float(v)) for k, v in re.findall(r"([A-Z_]+)=([0-9.e+-]+)", line))
 for (cfg, name), d in vals.items():
     fetch, write = d.get("FETCH_SIZE", 0) * 1024, d.get("WRITE_SIZE", 0) * 1024
-    out["kernels"][name] = {"config": cfg, "fetch_bytes_raw": fetch, "write_bytes_raw": write,
+    out["kernels"][name if cfg != "c5f" or name not in out["kernels"] else name + "@c5f"] = {"config": cfg, "fetch_bytes_raw": fetch, "write_bytes_raw": write,
                             "hbm_bytes_per_launch": write + 2 * fetch,
                             "valu_insts_per_launch": d.get("SQ_INSTS_VALU", 0.0),            # wave-instructions
                             "lds_active_cycles_per_launch": d.get("SQ_LDS_IDX_ACTIVE", 0.0),   # summed over the CUs

@@ -12,8 +12,11 @@ python tools/degrade_time.py > "$O/r3_degrade_time.txt" 2>&1; echo "degrade rc=$
 cd /tmp
 # kernel durations with SSG_OVERLAP=0 (every launch alone on the caller's stream = what bench's masked runs measure);
 # the default build's trace (direct kernels beside the dense ones) as *_overlap.csv
-for cfg in c2 c5; do
-  SSG_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$cfg" -o bench -- python "$R/bench.py" --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-module --no-extra > "$O/prof_$cfg.log" 2>&1
+# (c5f = the fused C5 step, no SSG output: tile-major scratch rows, ssg_fwd_strip / ssg_rows_tm / ssg_bwd_dense<..., TM>;
+#  its stats come from a run WITHOUT bench's per-kernel table, which launches the row-major kernels on their own)
+flags() { case $1 in c2) echo "--config c2";; c5) echo "--config c5";; c5f) echo "--config c5 --no-ssg-output --no-kernel-table";; esac; }
+for cfg in c2 c5 c5f; do
+  SSG_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$cfg" -o bench -- python "$R/bench.py" $(flags $cfg) --steps 10 --warmup 3 --no-cpu-baseline --no-module --no-extra > "$O/prof_$cfg.log" 2>&1
   f=$(find "$O/prof_$cfg" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/r3_bench_${cfg}_kernel_stats.csv"
   find "$O/prof_$cfg" -name "*kernel_trace.csv" -delete
 done
@@ -26,8 +29,8 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  for cfg in c2 c5; do
-    timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/pmc_$cfg/p$i" -o pmc -- python "$R/bench.py" --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-module --no-extra > "$O/pmc_$cfg.p$i.log" 2>&1
+  for cfg in c2 c5 c5f; do
+    timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/pmc_$cfg/p$i" -o pmc -- python "$R/bench.py" $(flags $cfg) --steps 3 --warmup 1 --no-cpu-baseline --no-module --no-extra > "$O/pmc_$cfg.p$i.log" 2>&1
     echo "pmc pass $i $cfg rc=$?"
     find "$O/pmc_$cfg/p$i" -name "*kernel_trace.csv" -delete
   done
@@ -35,12 +38,12 @@ done
 cd "$R"
 python - <<'PY' > gpurun_out/r3/r3_pmc_summary.txt
 import csv, glob, collections
-for cfg in ("c2", "c5"):
-    print("=====", cfg, "(bench.py --config %s --steps 3; per-dispatch means; rocprofv3 --pmc, one pass per counter set)" % cfg)
+for cfg in ("c2", "c5", "c5f"):
+    print("=====", cfg, "(bench.py %s --steps 3; per-dispatch means; rocprofv3 --pmc, one pass per counter set)" % {"c2": "--config c2", "c5": "--config c5", "c5f": "--config c5 --no-ssg-output (fused step, tile-major rows)"}[cfg])
     for f in sorted(glob.glob('gpurun_out/r3/pmc_%s/p*/pmc_counter_collection.csv' % cfg)):
         agg = collections.defaultdict(lambda: collections.defaultdict(float)); seen = collections.defaultdict(set)
         for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'][:72]
+            k = r['Kernel_Name'][:80]
             agg[k][r['Counter_Name']] += float(r['Counter_Value']); seen[k].add(r['Dispatch_Id'])
         for k, d in agg.items():
             if 'ssg_' not in k: continue
