@@ -817,7 +817,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // step (qyi, qxi) writes H buffer (qyi + qxi) % 2 (k_s is odd: the parity alternates across rows too)
     float *hw_even = hwrite + (qyi & 1) * UH * HS, *hw_odd = hwrite + ((qyi & 1) ^ 1) * UH * HS;
     const float *hr_even = hread + (qyi & 1) * UH * HS, *hr_odd = hread + ((qyi & 1) ^ 1) * UH * HS;
-    static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
+    // One offset = an E/H stage (E_q on the lane's pixels, horizontal sums, H rows to this step's buffer, window moved
+    // on) and an edge stage (the 18 H values of the lane's six centres, vertical sums, exp, row sums, stores).  They
+    // are software-pipelined: a step runs the E/H stage of the NEXT offset, then the edge stage of its own -- whose H
+    // values were requested right behind the previous barrier and arrive under the E/H arithmetic -- then the barrier
+    // (everybody's H rows of the next offset are in LDS, everybody's reads of this offset's buffer are done) and the
+    // requests for the next offset.  One s_barrier per offset as before; the LDS round trips leave the critical path.
+    auto eh_stage = [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
       f2 E[HL];
@@ -892,13 +898,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           else w[c][sl - HL].y = v;
         }
       }
-      // every wave's H rows of this step are in LDS; the next step writes the OTHER buffer, and the one after it
-      // comes behind the next barrier, which no wave passes before all have finished the reads below
-      lds_barrier();
+    };
+    float hv[NHV];
+    auto h_requests = [&](auto qc) {
+      constexpr int qxi = decltype(qc)::value;
       const float *hc = qxi % 2 == 0 ? hr_even : hr_odd;
-      float hv[NHV];
 #pragma unroll
       for (int t = 0; t < NHV; ++t) hv[t] = hc[t * HS];
+    };
+    auto edge_stage = [&](auto qc) {
+      constexpr int qxi = decltype(qc)::value;
       float d[PX];
       if (interior) {
         // all 13 taps kept: blocks of 2, 4 and 8 consecutive H values shared between the six windows
@@ -933,6 +942,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         rs[j] += (double)ev;
         asm volatile("" : "+v"(rs[j]));   // (or the additions sink to the end of the row, with every e kept for them)
         cptr[j][qyi * (KS * TM_PX) + qxi * TM_PX] = ev;
+      }
+    };
+    eh_stage(std::integral_constant<int, 0>{});
+    lds_barrier();
+    h_requests(std::integral_constant<int, 0>{});
+    static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
+      constexpr int qxi = decltype(qc)::value;
+      if constexpr (qxi + 1 < KS) eh_stage(std::integral_constant<int, qxi + 1>{});
+      edge_stage(qc);
+      if constexpr (qxi + 1 < KS) {
+        lds_barrier();
+        h_requests(std::integral_constant<int, qxi + 1>{});
       }
     });
     if (qyi + 1 < KS) {
