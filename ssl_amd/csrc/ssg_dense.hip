@@ -899,38 +899,63 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
     };
-    float hv[NHV];
+    // the 18 H values of the lane's six centres as nine register pairs P[m] = (H[2m], H[2m+1]): the vertical sums
+    // below are packed operations on them -- these waves are issue-limited (one VALU slot per 4 cycles, DESIGN
+    // section 4), so two additions per slot count
+    static_assert(NHV == 18, "nine pairs");
+    f2 P[NHV / 2];
     auto h_requests = [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       const float *hc = qxi % 2 == 0 ? hr_even : hr_odd;
 #pragma unroll
-      for (int t = 0; t < NHV; ++t) hv[t] = hc[t * HS];
+      for (int m = 0; m < NHV / 2; ++m) P[m] = f2{hc[2 * m * HS], hc[(2 * m + 1) * HS]};
     };
     auto edge_stage = [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       float d[PX];
       if (interior) {
-        // all 13 taps kept: blocks of 2, 4 and 8 consecutive H values shared between the six windows
-        float s2[NHV - 2], s4[NHV - 4], s8[PX];
+        // all 13 taps kept.  Window j = H[j] + ... + H[j+12]; with T[m] = P[m] + P[m+1] and Q[a] = T[a] + T[a+2] + T[a+4]
+        // (= P[a] + ... + P[a+5], packed), S[a] = Q[a].x + Q[a].y is H[2a] + ... + H[2a+11]:
+        //   window 2a = S[a] + H[2a+12],  window 2a+1 = H[2a+1] + S[a+1]          (16 packed + 10 scalar additions)
+        f2 T[8], Q[4];
 #pragma unroll
-        for (int i = 0; i < NHV - 2; ++i) s2[i] = hv[i] + hv[i + 1];
+        for (int m = 0; m < 8; ++m) T[m] = P[m] + P[m + 1];
 #pragma unroll
-        for (int i = 0; i < NHV - 4; ++i) s4[i] = s2[i] + s2[i + 2];
+        for (int a = 0; a < 4; ++a) Q[a] = (T[a] + T[a + 2]) + T[a + 4];
+        float S[4];
 #pragma unroll
-        for (int i = 0; i < PX; ++i) s8[i] = s4[i] + s4[i + 4];
+        for (int a = 0; a < 4; ++a) S[a] = Q[a].x + Q[a].y;
 #pragma unroll
-        for (int j = 0; j < PX; ++j) d[j] = (s8[j] + s4[j + 8]) + hv[j + 12];
+        for (int a = 0; a < 3; ++a) {
+          d[2 * a] = S[a] + P[a + 6].x;
+          d[2 * a + 1] = P[a].y + S[a + 1];
+        }
       } else {
+        // truncated rows: 0/1 weights (wave-uniform) as pairs; window 2a takes (w[2m], w[2m+1]) on P[a+m], m = 0..5,
+        // and w[12] on H[2a+12]; window 2a+1 takes w[0] on H[2a+1] and (w[2m-1], w[2m]) on P[a+m], m = 1..6
+        f2 we[6], wo[6];
 #pragma unroll
-        for (int j = 0; j < PX; ++j) {
-          // (weights are wave-uniform: scalar operands of plain FMAs, four accumulators)
-          float a0 = av[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int m = 0; m < 6; ++m) {
+          we[m] = f2{wgt[2 * m], wgt[2 * m + 1]};
+          wo[m] = f2{wgt[2 * m + 1], wgt[2 * m + 2]};
+        }
 #pragma unroll
-          for (int k = 0; k < KW; ++k) {
-            float &acc = k % 4 == 0 ? a0 : (k % 4 == 1 ? a1 : (k % 4 == 2 ? a2 : a3));
-            acc = __builtin_fmaf(wgt[k], hv[j + k], acc);
+        for (int a = 0; a < 3; ++a) {
+          f2 e0 = P[a] * we[0], e1 = P[a + 1] * we[1];
+          f2 o0 = P[a + 1] * wo[0], o1 = P[a + 2] * wo[1];
+#pragma unroll
+          for (int m = 2; m < 6; ++m) {
+            if (m % 2 == 0) {
+              e0 = __builtin_elementwise_fma(P[a + m], we[m], e0);
+              o0 = __builtin_elementwise_fma(P[a + 1 + m], wo[m], o0);
+            } else {
+              e1 = __builtin_elementwise_fma(P[a + m], we[m], e1);
+              o1 = __builtin_elementwise_fma(P[a + 1 + m], wo[m], o1);
+            }
           }
-          d[j] = (a0 + a1) + (a2 + a3);
+          const f2 e = e0 + e1, o = o0 + o1;
+          d[2 * a] = (e.x + e.y) + __builtin_fmaf(wgt[12], P[a + 6].x, av[2 * a]);
+          d[2 * a + 1] = (o.x + o.y) + __builtin_fmaf(wgt[0], P[a].y, av[2 * a + 1]);
         }
       }
       // e, row sums, stores: every half-wave's 32 values of a centre row are one aligned 128-byte run
