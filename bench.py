@@ -239,6 +239,20 @@ def pmc_traffic(kernel_name):
     return e.get("hbm_bytes_per_launch") if e else None
 
 
+def pmc_step_bytes(config_key):
+    """HBM bytes one step of a configuration moves: the per-launch figures of its kernels in profiles/pmc_traffic.json
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the guide's corrections) summed; None without a record."""
+    if not config_key:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ks = [k for k in json.load(f).get("kernels", {}).values() if k.get("config") == config_key]
+        tot = sum(k.get("hbm_bytes_per_launch", 0.0) for k in ks)
+        return tot or None
+    except (OSError, ValueError):
+        return None
+
+
 VALU_CYCLES_PER_INST = 2.0   # MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues over 2 cycles (v_pk_*: 4)
 N_SIMD, N_CU, CLOCK_HZ = 1024, 256, 2.4e9
 
@@ -328,11 +342,15 @@ def extra_line(cfg_key, fused, dev, steps, warmup):
     ach = b_alg * n / (ms * 1e-3) / 1e9
     del step, sr, gt, mask
     torch.cuda.empty_cache()
+    # what the step really moves (scratch rows included): the committed PMC passes of this configuration
+    moved = pmc_step_bytes({"c2": "c2", "c5": "c5f" if fused else "c5"}.get(cfg_key) if not (fused and cfg_key == "c2") else None)
     return {"workload": cfg["name"].replace("SSGs materialised", "fused step: no SSG output") if fused else cfg["name"],
             "ms_per_step": ms, "value": n / (ms * 1e-3), "unit": "edge-px/s", "steps": steps, "warmup": warmup,
             "edge_px": n, "l1": float(loss[0]), "kl": float(loss[1]),
             "roofline": {"step": {"alg_bytes_per_edge_px": b_alg, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": ach / HBM_PEAK_GBS}}}
+                                  "frac": ach / HBM_PEAK_GBS, "traffic": moved,
+                                  "traffic_GBps": None if not moved else moved / (ms * 1e-3) / 1e9,
+                                  "traffic_frac": None if not moved else moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}}
 
 
 def make_inputs(cfg, rank, world, scaling):
@@ -507,7 +525,11 @@ def main():
                 "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "alg_bytes_per_edge_px": b_alg,
                 "kernel_ms": stages,
-                "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS},
+                "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS,
+                         "traffic": pmc_step_bytes(None if args.no_ssg_output and args.config == "c2" else
+                                                   ("c5f" if args.no_ssg_output else args.config)),
+                         "traffic_note": "HBM bytes the whole step moves by the committed PMC passes (scratch rows, "
+                                         "G rows, atomics included); / gpu_ms = the step's real HBM rate"},
                 "valu": {"reference_equivalent_tflops": tflops, "fp32_vector_peak_tflops": FP32_PEAK_TFLOPS,
                          "alg_flops_per_edge_px": alg_flops_per_edge_px(cfg),
                          "note": "SURVEY's DIRECT flop count over the step's GPU time; the dense-tile kernels do "
