@@ -274,6 +274,29 @@ def test_argument_checks_need_no_gpu():
     assert L.ssg_backward_scratch_bytes(100, 25) >= 100 * 625 * 4
 
 
+def test_workspace_layout_of_the_fused_call():
+    """ssg_loss_workspace_layout (host arithmetic only): the pieces lie in order inside ssg_loss_workspace_bytes(), the
+    row-major scratch rows of the fused step behind them, and -- k_s = 49 only -- two tile-major regions of capacity / 128
+    slots plus a spare one each; ssg_loss_rows_bytes() covers exactly that."""
+    from ssl_amd import _lib
+    L = _lib.lib()
+    lay = (ctypes.c_size_t * 9)()
+    for ks, cap in ((25, 5000), (49, 5000), (49, 100), (11, 333)):
+        B, H, W = 2, 70, 100
+        assert L.ssg_loss_workspace_layout(B, H, W, cap, ks, lay) == 0
+        base, rows = L.ssg_loss_workspace_bytes(B, H, W, cap, ks), L.ssg_loss_rows_bytes(cap, ks)
+        edges, rank, plan, rsc, r0, r1, t0, t1, slots = list(lay)
+        assert 0 == edges < rank < plan < rsc < base == r0 < r1 and all(o % 256 == 0 for o in (rank, plan, rsc, r0, r1))
+        assert base - rsc >= 16 * cap and rank - edges >= 12 * cap and r1 - r0 >= 4 * cap * ks * ks
+        if ks == 49:
+            slot_bytes = 49 * 49 * 128 * 4
+            assert slots == cap // 128 and r1 < t0 < t1 and t0 - r1 == r1 - r0
+            assert t1 - t0 >= (slots + 1) * slot_bytes and base + rows - t1 >= (slots + 1) * slot_bytes
+        else:
+            assert (t0, t1, slots) == (0, 0, 0) and base + rows - r1 == r1 - r0
+    assert L.ssg_loss_workspace_layout(1, 64, 64, 0, 25, lay) == -1 and L.ssg_loss_workspace_layout(1, 64, 64, 10, 25, None) == -1
+
+
 def test_plan_built_for_another_tile_height_is_refused():
     """A dense/direct plan is cut for one tile height (8 rows for k_s <= 25, 4 for k_s = 49) and records the k_s it
     was built for; handing it to a call with the other geometry raises before anything is launched (the dense
