@@ -771,6 +771,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
   for (int j = 0; j < PX; ++j) rs[j] = 0.0;
   float *hwrite = Hb + R * HS + L * g;          // the lane's centres L g .. L g + L - 1 (those < DT_X are stored)
+  // centres k < HSPLIT of a lane are inside the strip for column groups g <= GA, the others for g <= GB
+  constexpr int HSPLIT = DT_X - 2 * L, GA = 2, GB = 1;
+  static_assert(L == 12 && DT_X == 32 && HSPLIT == 8, "groups 0, 1 whole, group 2 its first eight centres, group 3 none");
+  float *hdummy = F + UH * UW;                  // [L] dummy words behind F
   const float *hread = Hb + e0 * HS + ecol;     // window row k of centre j is U-row e0 + j + k
   const float *hfread = HF + e0 * HS + ecol;
   __syncthreads();
@@ -816,6 +820,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int t = 0; t < HL; ++t) w[c][t] = f2{rq[c * UH * RS + t], rq[c * UH * RS + t + HL]};
     // step (qyi, qxi) writes H buffer (qyi + qxi) % 2 (k_s is odd: the parity alternates across rows too)
     float *hw_even = hwrite + (qyi & 1) * UH * HS, *hw_odd = hwrite + ((qyi & 1) ^ 1) * UH * HS;
+    float *hwa_even = g <= GA ? hw_even : hdummy, *hwa_odd = g <= GA ? hw_odd : hdummy;
+    float *hwb_even = g <= GB ? hw_even : hdummy, *hwb_odd = g <= GB ? hw_odd : hdummy;
     const float *hr_even = hread + (qyi & 1) * UH * HS, *hr_odd = hread + ((qyi & 1) ^ 1) * UH * HS;
     // One offset = an E/H stage (E_q on the lane's pixels, horizontal sums, H rows to this step's buffer, window moved
     // on) and an edge stage (the 18 H values of the lane's six centres, vertical sums, exp, row sums, stores).  They
@@ -852,11 +858,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           Sf[m + HL] = su.y;
           Sf[m] = su.x + tot.y;
         });
-        static_for(std::make_integer_sequence<int, L>{}, [&](auto kc) {
-          constexpr int k = decltype(kc)::value, last = k + KW - 1;
-          if constexpr (last < L) hs[k] = k == 0 ? Pf[last] : Sf[k];
-          else hs[k] = Sf[k] + quad_next<1>(Pf[last - L]);
-        });
+        // every window of this lane map ends in the next lane (k + 12 >= L): hs[k] = Sf[k] + (next lane's Pf[k]) as ONE
+        // v_add_f32_dpp each instead of a DPP move and an addition -- these waves pay per instruction (DESIGN section
+        // 4).  The hazard recogniser does not see into the statement: the s_nop covers the VALU-write -> DPP-read wait
+        // states of the Pf registers.
+        static_assert(KW - 1 >= L && L == 12, "all twelve windows reach into the next lane");
+#pragma unroll
+        for (int k = 0; k < L; ++k) hs[k] = Sf[k];
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %6, %0 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %1, %7, %1 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %2, %8, %2 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %3, %9, %3 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %4, %10, %4 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %5, %11, %5 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "+v"(hs[0]), "+v"(hs[1]), "+v"(hs[2]), "+v"(hs[3]), "+v"(hs[4]), "+v"(hs[5])
+                     : "v"(Pf[0]), "v"(Pf[1]), "v"(Pf[2]), "v"(Pf[3]), "v"(Pf[4]), "v"(Pf[5]));
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %6, %0 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %1, %7, %1 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %2, %8, %2 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %3, %9, %3 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %4, %10, %4 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_f32_dpp %5, %11, %5 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "+v"(hs[6]), "+v"(hs[7]), "+v"(hs[8]), "+v"(hs[9]), "+v"(hs[10]), "+v"(hs[11])
+                     : "v"(Pf[6]), "v"(Pf[7]), "v"(Pf[8]), "v"(Pf[9]), "v"(Pf[10]), "v"(Pf[11]));
       } else {
         // (|I|^2 does not depend on q_y: left alone, the compiler hoists the sums of the taps left behind out of the
         // q_y loop -- 144 registers)
@@ -885,10 +911,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           hs[k + HL] = t.y;
         }
       }
-      float *hw = qxi % 2 == 0 ? hw_even : hw_odd;
+      // (no predicate: the lanes whose centres lie outside the strip's 32 columns -- group 3, and group 2 from its
+      // ninth centre on -- point at a few dummy words instead, chosen once per offset row)
+      float *hwa = qxi % 2 == 0 ? hwa_even : hwa_odd, *hwb = qxi % 2 == 0 ? hwb_even : hwb_odd;
 #pragma unroll
-      for (int k = 0; k < L; ++k)
-        if (L * g + k < DT_X) hw[k] = hs[k];
+      for (int k = 0; k < L; ++k) (k < HSPLIT ? hwa : hwb)[k] = hs[k];
       if (qxi + 1 < KS) {
         constexpr int sl = qxi % L;
 #pragma unroll
@@ -1035,7 +1062,7 @@ int dense_max_strips(int B, int H, int W, int ks) {
 template <int KS, int KW, int C, int NW>
 static int launch_fwd_strip_t(const DenseParams &p, hipStream_t st) {
   constexpr int UH = 16 * NW, HALO = KS / 2 + KW / 2, RS = DT_X + 2 * HALO + 1, HS = DT_X + 1;
-  const size_t lds = sizeof(float) * (size_t)(C * UH * RS + 3 * UH * HS + UH * (DT_X + KW - 1) + 8);
+  const size_t lds = sizeof(float) * (size_t)(C * UH * RS + 3 * UH * HS + UH * (DT_X + KW - 1) + 16);
   static std::atomic<unsigned long long> lds_set{0};
   if (const int rc = ensure_dynamic_lds(ssg_fwd_strip<KS, KW, C, NW>, (int)lds, lds_set)) return rc;
   hipLaunchKernelGGL((ssg_fwd_strip<KS, KW, C, NW>), dim3((unsigned)p.max_strips * p.nimg), dim3(64 * NW), lds, st, p);
