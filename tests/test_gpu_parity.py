@@ -1353,7 +1353,8 @@ def tile_major_ssg(step):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,density,sigma", [((1, 3, 64, 96), 1.1, 1.0), ((2, 3, 70, 100), 0.8, 0.05)])
+@pytest.mark.parametrize("shape,density,sigma", [((1, 3, 64, 96), 1.1, 1.0), ((2, 3, 70, 100), 0.8, 0.05),
+                                                 ((1, 3, 64, 96), 1.1, 0.004)])
 def test_tile_major_fused_step_k49_vs_oracle(dev, shape, density, sigma):
     """The fused k_s = 49 step on tile-major scratch rows (ssg_fwd_dense<..., TM>, ssg_rows_tm, ssg_bwd_dense<..., TM>)
     against the fp64 oracle: full tiles, and ragged tiles with holes on two images.  The SSG rows never leave the

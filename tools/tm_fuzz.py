@@ -1,0 +1,59 @@
+"""Randomised hunt: the fused k_s 49 step (tile-major rows, strips + tiles, or the row-major fallback) against the
+materialising step on random shapes, batch sizes, mask densities, sigmas and capacities.  Prints the worst deviations
+and every case beyond the bounds the tests use (l1 1e-6, kl 1e-4 relative, gradient 1e-4 of its maximum; 1e-3 at sigma = 0.004, where ONE L1 entry whose sign fp32 does not
+decide moves the gradient by that much -- tools/tm_oracle.py holds both steps to the fp64 oracle with the GPU's own signs)."""
+import ctypes
+import sys
+import numpy as np
+import torch
+from ssl_amd import _lib, engine, synth
+
+dev = torch.device("cuda:0")
+T = lambda a: torch.as_tensor(a, device=dev)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+worst = [0.0, 0.0, 0.0]
+bad = n_tm = n_strip = 0
+for it in range(n_cases):
+    B = int(rng.integers(1, 4))
+    H, W = int(rng.integers(49, 150)), int(rng.integers(49, 210))
+    dens = float(rng.choice([1.1, 0.95, 0.8, 0.7, 0.62, 0.5]))
+    sigma = float(rng.choice([1.0, 0.05, 0.004]))
+    gt = np.stack([synth.natural_like(int(rng.integers(1, 10 ** 6)), H, W) for _ in range(B)])
+    sr = np.stack([synth.degrade(gt[i], int(rng.integers(1, 10 ** 6))) for i in range(B)])
+    mask = (rng.random((B, 1, H, W)) < dens).astype(np.float32)
+    if rng.random() < 0.3:          # a band without edge pixels: short / missing strips, sparse tiles
+        y0 = int(rng.integers(0, H - 8))
+        mask[:, :, y0:y0 + int(rng.integers(4, 40))] = 0
+    n = int(mask.sum())
+    cap = [None, n, n + 200, max(n // 2, 1)][int(rng.integers(0, 4))]
+    a = engine.LossStep(B, 3, H, W, 49, 13, sigma, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True, capacity=cap)
+    b = engine.LossStep(B, 3, H, W, 49, 13, sigma, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True, capacity=cap,
+                        materialise=False)
+    la, ga = a(T(sr), T(gt), T(mask))
+    la, ga = la.clone(), ga.clone()
+    lb, gb = b(T(sr), T(gt), T(mask))
+    lb, gb = lb.clone(), gb.clone()
+    lb2, gb2 = b(T(sr), T(gt), T(mask))
+    torch.cuda.synchronize()
+    # which path the fused step took: tile-major rows carry a negative row scale; strips are listed in the plan
+    lay = (ctypes.c_size_t * 9)()
+    _lib.lib().ssg_loss_workspace_layout(B, H, W, b.capacity, 49, lay)
+    nrow = min(int(b.counts[0]), b.capacity)
+    tm = bool((b.ws[lay[3]: lay[3] + 8 * nrow].view(torch.float64) < 0).any())
+    ns = B * ((H + 3) // 4) * ((W + 31) // 32)
+    strips = int(b.ws[lay[2] + 4 * (4 + ns): lay[2] + 4 * (5 + ns)].view(torch.int32)[0])
+    n_tm += tm
+    n_strip += tm and strips > 0
+    gm = float(ga.abs().max())
+    e1 = abs(float(la[0] - lb[0])) / max(abs(float(la[0])), 1e-30)
+    e2 = abs(float(la[1] - lb[1])) / max(abs(float(la[1])), 1e-30)
+    eg = float((ga - gb).abs().max()) / max(gm, 1e-30)
+    same = torch.equal(gb, gb2) and torch.equal(lb, lb2)
+    worst = [max(worst[0], e1), max(worst[1], e2), max(worst[2], eg)]
+    flag = e1 > 1e-6 or e2 > 1e-4 or eg > (1e-3 if sigma < 0.01 else 1e-4) or not same or not bool(torch.isfinite(gb).all())
+    bad += flag
+    if flag or it < 3:
+        print(f"{'BAD ' if flag else ''}case {it}: B={B} {H}x{W} dens={dens} sigma={sigma} cap={cap} N={int(b.counts[0])}: "
+              f"l1 {e1:.1e} kl {e2:.1e} grad {eg:.1e} rerun-equal {same}", flush=True)
+print(f"{n_cases} cases ({n_tm} on tile-major rows, {n_strip} of them with strips), {bad} beyond the bounds; worst l1 {worst[0]:.2e} kl {worst[1]:.2e} grad {worst[2]:.2e}")

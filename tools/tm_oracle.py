@@ -12,7 +12,7 @@ from test_gpu_parity import tile_major_ssg, ref_grad_with_gpu_signs
 
 dev = torch.device("cuda:0")
 T = lambda a: torch.as_tensor(a, device=dev)
-for sigma in (1.0, 0.05):
+for sigma in (1.0, 0.05, 0.004):
     B, H, W, ks, kw = 1, 64, 96, 49, 13
     gt = np.stack([synth.natural_like(700 + i, H, W) for i in range(B)])
     sr = np.stack([synth.degrade(gt[i], 750 + i) for i in range(B)])
