@@ -252,9 +252,13 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
  * region (count <= capacity / 128) and are >= 60 % full on average -- decided on the device from the plan's counts,
  * for all tiles of the call or none -- keeps the dense tiles' rows there: the forward stores whole 256-byte runs,
  * ssg_rows_tm reads them once (criteria, sum_q g s, border sums), and the dense backward forms G = dL/dD itself
- * from the two rows instead of reading G rows (C5: 21 -> 15 GB per step).  Same loss and gradient as the row-major
- * step up to fp32 rounding (measured: l1 <= 2e-7, kl <= 3e-6 relative, gradient <= 2e-7 of its maximum);
- * bit-reproducible run to run in deterministic mode.  SSG_TILE_MAJOR=0 (environment) keeps every row row-major.
+ * from the two rows instead of reading G rows (C5: 21 -> 15.7 GB per step, 7.7 -> 5.7 ms); whole strips of nine heavy
+ * tiles (36 x 32 pixels, consecutive slots) get their forward rows from ssg_fwd_strip.  Same loss and gradient as the
+ * row-major step up to fp32 rounding: l1 <= 2e-7, kl <= 5e-6 relative; the gradient is within 5e-7 of the fp64
+ * oracle's like the row-major step's, and within 4e-5 of its maximum of the row-major step's (the strip forward
+ * rounds e differently, and a few L1 entries whose sign(s_sr - s_gt) fp32 does not decide flip).  Bit-reproducible
+ * run to run in deterministic mode.  SSG_TILE_MAJOR=0 (environment) keeps every row row-major, SSG_STRIPS=0 leaves
+ * the forward to the tile kernel.
  * ssg_loss_workspace_layout() reports where the pieces of the workspace live (byte offsets; tests and tools read
  * the scratch rows of a finished call through it): out[0] edge list, [1] rank map, [2] plan, [3] row scales
  * (2 x capacity doubles, negative = tile-major row), [4] / [5] row-major rows of sr / gt, [6] / [7] tile-major
