@@ -1280,7 +1280,7 @@ def test_fused_step_without_ssg_output(dev, ks, kw, shape, density, tile_major):
         assert abs(float(la[0] - lb[0])) <= 1e-6 * float(la[0]) and abs(float(la[1] - lb[1])) <= 1e-5 * float(la[1])
         # (the strip forward sums the same terms in another order: e differs in its last bit, and a few of the L1 entries
         # whose sign(s_sr - s_gt) fp32 does not decide -- 50 to 500 per case -- flip; each moves the gradient by ~1e-5 of
-        # its maximum.  With the GPU's own signs both steps are within 5e-7 of the fp64 oracle: tools/tm_oracle.py and
+        # its maximum.  With the GPU's own signs both steps are within 5e-7 of the fp64 oracle: tests/measure_tm_oracle.py and
         # test_tile_major_fused_step_k49_vs_oracle.  Measured here: 1.9e-5.)
         assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
         lb1, gb1 = lb.clone(), gb.clone()

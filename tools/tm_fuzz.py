@@ -1,7 +1,7 @@
 """Randomised hunt: the fused k_s 49 step (tile-major rows, strips + tiles, or the row-major fallback) against the
 materialising step on random shapes, batch sizes, mask densities, sigmas and capacities.  Prints the worst deviations
 and every case beyond the bounds the tests use (l1 1e-6, kl 1e-4 relative, gradient 1e-4 of its maximum; 1e-3 at sigma = 0.004, where ONE L1 entry whose sign fp32 does not
-decide moves the gradient by that much -- tools/tm_oracle.py holds both steps to the fp64 oracle with the GPU's own signs)."""
+decide moves the gradient by that much -- tests/measure_tm_oracle.py holds both steps to the fp64 oracle with the GPU's own signs)."""
 import ctypes
 import sys
 import numpy as np
