@@ -1,6 +1,6 @@
 """Randomised hunt: shared-term kernels (threshold 1 or 28) vs direct kernels (threshold 0) over random shapes,
 densities and capacities -- SSG rows (2e-6), losses (1e-5), gradients (deterministic mode, 2e-5 of max), and the
-fused step against the materialising one (bits).  Usage: python tools/fuzz_dense_vs_direct.py [cases] [seed]"""
+fused step against the materialising one (bits; k_s 49: tolerances).  Usage: python tests/measure_fuzz_dense_vs_direct.py [cases] [seed]"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ssl_amd import engine, synth
@@ -43,7 +43,14 @@ for it in range(ncases):
                 fu = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True,
                                      materialise=False)
                 lf, gf = fu(T(sr), T(gt), T(mask))
-                if not (torch.equal(lf, loss) and torch.equal(gf, grad)):
+                if ks == 49:   # (may run on tile-major rows: same numbers up to fp32 rounding and L1 sign ties)
+                    gm = float(grad.abs().max())
+                    same = (abs(float(lf[0] - loss[0])) <= 1e-6 * abs(float(loss[0])) and
+                            abs(float(lf[1] - loss[1])) <= 1e-4 * abs(float(loss[1])) and
+                            float((gf - grad).abs().max()) <= (1e-3 if sigma < 0.01 else 1e-4) * gm)
+                else:
+                    same = torch.equal(lf, loss) and torch.equal(gf, grad)
+                if not same:
                     bad += 1
                     print("FUSED MISMATCH", ks, B, H, W, dens, sigma, thr)
         finally:
