@@ -492,51 +492,58 @@ def main():
             res["config"]["l1"], res["config"]["kl"] = float(loss[0]), float(loss[1])
             b_alg = alg_bytes_per_edge_px(cfg, n_edges, B) - (8.0 * cfg["ks"] ** 2 if args.no_ssg_output else 0.0)
             it = max(3, min(args.steps, 10))
-            if args.no_kernel_table:
+            # The per-kernel table launches the kernels one at a time through the separate entry points.  It is skipped
+            # on request (rocprofv3 runs of one step's own kernels) and for k_s = 49, where the timed step runs on
+            # tile-major rows (ssg_fwd_strip, ssg_rows_tm[_mat], ssg_bwd_dense<..., TM>) while the separate entry points
+            # run the row-major kernels: that step's per-kernel figures are the committed rocprofv3 stats.
+            key = ("c5f" if args.no_ssg_output else "c5") if args.config == "c5" else (None if args.no_ssg_output else "c2")
+            if args.no_kernel_table or cfg["ks"] == 49:
                 step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), it)
                 ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
-                res["roofline"] = {"alg_bytes_per_edge_px": b_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS}}
-                print(json.dumps(res))
-                if use_dist:
-                    dist.barrier()
-                    dist.destroy_process_group()
-                return
-            # (per-kernel times: through the separate entry points, which need SSG tensors of their own)
-            step_k = step if not args.no_ssg_output else engine.LossStep(
-                B, C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1, W_KL, device=dev,
-                capacity=n_edges + 1024)
-            if step_k is not step:
-                step_k(sr, gt, mask)
-            stages = stage_times(step_k, sr, gt, mask, n_edges, it, cfg)
-            del step_k
-            step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), it)
-            dom = max((k for k in stages if k.startswith("ssg_") and "launches" not in k and "+" not in k),
-                      key=lambda k: stages[k])
-            ach = b_alg * n_edges / (stages[dom] * 1e-3) / 1e9
-            ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
-            tflops = alg_flops_per_edge_px(cfg) * n_edges / (step_gpu_ms * 1e-3) / 1e12
-            bound, evidence = binding_resource(dom, stages[dom])
-            res["roofline"] = {
-                # `achieved / peak / frac` are the HBM figures BASELINE.json's metric asks for (algorithmic bytes of the
-                # step over the dominant kernel's duration); `bound` names the resource that kernel actually keeps
-                # busiest by its counters -- "hbm", "valu" or "lds" (no MFMA on this path) -- see `bound_evidence`
-                "bound": bound, "bound_evidence": evidence,
-                "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "alg_bytes_per_edge_px": b_alg,
-                "kernel_ms": stages,
-                "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS,
-                         "traffic": pmc_step_bytes(None if args.no_ssg_output and args.config == "c2" else
-                                                   ("c5f" if args.no_ssg_output else args.config)),
-                         "traffic_note": "HBM bytes the whole step moves by the committed PMC passes (scratch rows, "
-                                         "G rows, atomics included); / gpu_ms = the step's real HBM rate"},
-                "valu": {"reference_equivalent_tflops": tflops, "fp32_vector_peak_tflops": FP32_PEAK_TFLOPS,
-                         "alg_flops_per_edge_px": alg_flops_per_edge_px(cfg),
-                         "note": "SURVEY's DIRECT flop count over the step's GPU time; the dense-tile kernels do "
-                                 "~10x fewer real flops per (pixel, offset), so this is throughput in "
-                                 "reference-equivalent flops and may exceed the peak -- NOT a utilisation "
-                                 "(`issued` prices the instructions actually issued)",
-                         "issued": pmc_issue(args.config, step_gpu_ms)}}
+                moved = pmc_step_bytes(key)
+                res["roofline"] = {"bound": "hbm", "alg_bytes_per_edge_px": b_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS, "traffic": moved,
+                                   "kernel": "whole step (per-kernel durations: profiles/r3_bench_%s_kernel_stats.csv)" % (key or "c2"),
+                                   "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS,
+                                            "traffic": moved,
+                                            "traffic_GBps": None if not moved else moved / (step_gpu_ms * 1e-3) / 1e9,
+                                            "traffic_frac": None if not moved else moved / (step_gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            else:
+                # (per-kernel times: through the separate entry points, which need SSG tensors of their own)
+                step_k = step if not args.no_ssg_output else engine.LossStep(
+                    B, C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1, W_KL, device=dev,
+                    capacity=n_edges + 1024)
+                if step_k is not step:
+                    step_k(sr, gt, mask)
+                stages = stage_times(step_k, sr, gt, mask, n_edges, it, cfg)
+                del step_k
+                step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), it)
+                dom = max((k for k in stages if k.startswith("ssg_") and "launches" not in k and "+" not in k),
+                          key=lambda k: stages[k])
+                ach = b_alg * n_edges / (stages[dom] * 1e-3) / 1e9
+                ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
+                tflops = alg_flops_per_edge_px(cfg) * n_edges / (step_gpu_ms * 1e-3) / 1e12
+                bound, evidence = binding_resource(dom, stages[dom])
+                res["roofline"] = {
+                    # `achieved / peak / frac` are the HBM figures BASELINE.json's metric asks for (algorithmic bytes of the
+                    # step over the dominant kernel's duration); `bound` names the resource that kernel actually keeps
+                    # busiest by its counters -- "hbm", "valu" or "lds" (no MFMA on this path) -- see `bound_evidence`
+                    "bound": bound, "bound_evidence": evidence,
+                    "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "alg_bytes_per_edge_px": b_alg,
+                    "kernel_ms": stages,
+                    "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS,
+                             "traffic": pmc_step_bytes(None if args.no_ssg_output and args.config == "c2" else
+                                                       ("c5f" if args.no_ssg_output else args.config)),
+                             "traffic_note": "HBM bytes the whole step moves by the committed PMC passes (scratch rows, "
+                                             "G rows, atomics included); / gpu_ms = the step's real HBM rate"},
+                    "valu": {"reference_equivalent_tflops": tflops, "fp32_vector_peak_tflops": FP32_PEAK_TFLOPS,
+                             "alg_flops_per_edge_px": alg_flops_per_edge_px(cfg),
+                             "note": "SURVEY's DIRECT flop count over the step's GPU time; the dense-tile kernels do "
+                                     "~10x fewer real flops per (pixel, offset), so this is throughput in "
+                                     "reference-equivalent flops and may exceed the peak -- NOT a utilisation "
+                                     "(`issued` prices the instructions actually issued)",
+                             "issued": pmc_issue(args.config, step_gpu_ms)}}
             if not args.no_module and not args.no_ssg_output:
                 mm = module_time_ms(cfg, sr, gt, mask, n_edges, it if cfg["dense_mask"] else max(it, 30))
                 res["module"] = {"what": "ssl_amd.SSGLoss forward + autograd backward (drop-in path)",

@@ -259,13 +259,18 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
  * rounds e differently, and a few L1 entries whose sign(s_sr - s_gt) fp32 does not decide flip).  Bit-reproducible
  * run to run in deterministic mode.  SSG_TILE_MAJOR=0 (environment) keeps every row row-major, SSG_STRIPS=0 leaves
  * the forward to the tile kernel.
- * ssg_loss_workspace_layout() reports where the pieces of the workspace live (byte offsets; tests and tools read
- * the scratch rows of a finished call through it): out[0] edge list, [1] rank map, [2] plan, [3] row scales
- * (2 x capacity doubles, negative = tile-major row), [4] / [5] row-major rows of sr / gt, [6] / [7] tile-major
- * regions of sr / gt (0 when the size has none), out[8] = slots of a tile-major region. */
+ * A MATERIALISING k_s = 49 call (ssg_sr / ssg_gt given) uses the tile-major rows too when its workspace holds
+ * ssg_loss_workspace_bytes() + ssg_loss_tm_bytes(): forward and backward as above, and the row pass
+ * (ssg_rows_tm_mat) also writes the normalised SSG rows into the caller's tensors, 196-byte runs at a time.
+ * ssg_loss_workspace_layout() reports where the pieces of the workspace live (byte offsets; `fused` = 1 for a call
+ * without SSG output; tests and tools read the scratch rows of a finished call through it): out[0] edge list, [1]
+ * rank map, [2] plan, [3] row scales (2 x capacity doubles, negative = tile-major row), [4] / [5] row-major scratch
+ * rows of sr / gt (fused only), [6] / [7] tile-major regions of sr / gt (0 when the size has none), out[8] = slots
+ * of a tile-major region. */
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks);
 size_t ssg_loss_rows_bytes(int capacity, int ks);
-int ssg_loss_workspace_layout(int B, int H, int W, int capacity, int ks, size_t out[9]);
+size_t ssg_loss_tm_bytes(int capacity, int ks);
+int ssg_loss_workspace_layout(int B, int H, int W, int capacity, int ks, int fused, size_t out[9]);
 int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask,
                      int mask_kind, int mask_channels, int B, int C, int H,
                      int W, int ks, int kw, float sigma, float eps,

@@ -41,7 +41,8 @@ PROTOTYPES = {
                                _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ssg_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ssg_loss_rows_bytes": (_sz, [_i, _i]),
-    "ssg_loss_workspace_layout": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_size_t)]),
+    "ssg_loss_tm_bytes": (_sz, [_i, _i]),
+    "ssg_loss_workspace_layout": (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_size_t)]),
     "ssg_filter2d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssg_diffjpeg": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _vp]),
     "ssg_usm_scratch_bytes": (_sz, [_i, _i, _i, _i]),

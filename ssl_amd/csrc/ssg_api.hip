@@ -301,6 +301,10 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
     t.sum_b = sum_b;
     t.partials = p.partials + 2 * (size_t)grow_grid(p.n_host);
     t.gmax_part = p.gfix ? gmax_part + grow_grid(p.n_host) : nullptr;
+    if (!p.rows_scratch) {   // materialising call: the normalised rows of the tile-major tiles are written here
+      t.out[0] = p.ssg;
+      t.out[1] = p.ssg2;
+    }
     rc = (dbg_mask() & (1 << 29)) ? 0 : launch_rows_tm(t, p.ks, p.kw, st);
   }
   if (rc || !p.grad) return rc;
@@ -687,8 +691,9 @@ static size_t rows_region_bytes(int capacity, int ks) {
 static size_t tm_region_bytes(int capacity, int ks) {
   return align_up(sizeof(float) * ((size_t)(capacity > 0 ? capacity : 1) / TM_PX + 1) * ks * ks * TM_PX, 256);
 }
+size_t ssg_loss_tm_bytes(int capacity, int ks) { return ks == 49 ? 2 * tm_region_bytes(capacity, ks) : 0; }
 size_t ssg_loss_rows_bytes(int capacity, int ks) {
-  return 2 * rows_region_bytes(capacity, ks) + (ks == 49 ? 2 * tm_region_bytes(capacity, ks) : 0);
+  return 2 * rows_region_bytes(capacity, ks) + ssg_loss_tm_bytes(capacity, ks);
 }
 
 size_t ssg_loss_workspace_bytes(int B, int H, int W, int capacity, int ks) {
@@ -704,7 +709,7 @@ struct LossWorkspace {
   size_t edges, rank, order, plan, escratch, lscratch, row_scale, base_bytes, rows[2], tm[2];
   int tm_slots;
 };
-static LossWorkspace carve_workspace(int B, int H, int W, int capacity, int ks) {
+static LossWorkspace carve_workspace(int B, int H, int W, int capacity, int ks, bool fused = true) {
   LossWorkspace w{};
   size_t o = 0;
   w.edges = o;
@@ -724,17 +729,18 @@ static LossWorkspace carve_workspace(int B, int H, int W, int capacity, int ks) 
   const size_t region = rows_region_bytes(capacity, ks);
   w.rows[0] = w.base_bytes;
   w.rows[1] = w.rows[0] + region;
-  if (ks == 49) {
-    w.tm[0] = w.rows[1] + region;
+  if (ks == 49) {   // (a materialising call has no row-major scratch rows: the tile-major regions follow the base)
+    w.tm[0] = fused ? w.rows[1] + region : w.base_bytes;
     w.tm[1] = w.tm[0] + tm_region_bytes(capacity, ks);
     w.tm_slots = capacity / TM_PX;
   }
+  if (!fused) w.rows[0] = w.rows[1] = 0;
   return w;
 }
 
-int ssg_loss_workspace_layout(int B, int H, int W, int capacity, int ks, size_t out[9]) {
+int ssg_loss_workspace_layout(int B, int H, int W, int capacity, int ks, int fused, size_t out[9]) {
   if (!out || B <= 0 || H <= 0 || W <= 0 || capacity <= 0 || ks <= 0) return SSG_E_BADARG;
-  const LossWorkspace w = carve_workspace(B, H, W, capacity, ks);
+  const LossWorkspace w = carve_workspace(B, H, W, capacity, ks, fused != 0);
   out[0] = w.edges;
   out[1] = w.rank;
   out[2] = w.plan;
@@ -759,17 +765,20 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   const bool fused = ssg_sr == nullptr;
   const size_t base_bytes = ssg_loss_workspace_bytes(B, H, W, capacity, ks);
   if (workspace_bytes < base_bytes + (fused ? ssg_loss_rows_bytes(capacity, ks) : 0)) return SSG_E_WORKSPACE;
-  const LossWorkspace lw = carve_workspace(B, H, W, capacity, ks);
+  const LossWorkspace lw = carve_workspace(B, H, W, capacity, ks, fused);
   char *ws = (char *)workspace;
   TileMajor tm;
   if (fused) {
     ssg_sr = (float *)(ws + lw.rows[0]);
     ssg_gt = (float *)(ws + lw.rows[1]);
-    if (ks == 49 && kw == 13 && C == 3 && generalization && tile_major_enabled()) {
-      tm.rows[0] = (float *)(ws + lw.tm[0]);
-      tm.rows[1] = (float *)(ws + lw.tm[1]);
-      tm.slots = lw.tm_slots;
-    }
+  }
+  // tile-major rows: always in the fused step; in a materialising call when the caller's workspace has room for the
+  // two regions (ssg_loss_tm_bytes) -- ssg_rows_tm_mat then writes the normalised SSG rows from them
+  if (ks == 49 && kw == 13 && C == 3 && generalization && tile_major_enabled() &&
+      (fused || workspace_bytes >= base_bytes + ssg_loss_tm_bytes(capacity, ks))) {
+    tm.rows[0] = (float *)(ws + lw.tm[0]);
+    tm.rows[1] = (float *)(ws + lw.tm[1]);
+    tm.slots = lw.tm_slots;
   }
   int *edges = (int *)(ws + lw.edges);
   int *rank = (int *)(ws + lw.rank);

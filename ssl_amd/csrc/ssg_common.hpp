@@ -366,6 +366,7 @@ struct TmRowsParams {
   float *sum_b;              // (n) out: sum of G over the border offsets
   float *partials;           // (n_tiles, 2) out: criteria sums per workgroup
   float *gmax_part;          // nullable (n_tiles) out: upper bound of |G| per workgroup
+  const float *out[2];       // nullable: the call's SSG tensors (n, k_s^2) -- ssg_rows_tm_mat writes the normalised rows
 };
 
 // ssg_bwd_dense (ssg_bwd_dense.hip)

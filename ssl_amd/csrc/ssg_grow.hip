@@ -298,9 +298,198 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
   }
 }
 
+// The same pass when the call MATERIALISES its SSG tensors (ssg_sr / ssg_gt are the caller's (n, k_s^2) row-major rows):
+// besides the sums above it writes the normalised rows.  The eight parts of a chunk split the 49 offsets of ONE offset
+// row here (6-7 columns each) instead of the offset rows, so that the whole workgroup finishes an offset row together:
+// the values of two offset rows go through an LDS tile ([image][pixel][2 x 49]; two barriers per hand-over) and leave
+// as 392-byte runs -- a pixel's two adjacent offset rows -- with consecutive lanes on consecutive floats (one row at a
+// time, 196-byte runs: 2.52 ms at C5 against 2.2 -- the partial 32-byte sectors at the ends of a run are written twice).
+// The next offset row's loads are issued before the current one is worked on.
+template <int KS, int KW>
+__global__ __launch_bounds__(1024) void ssg_rows_tm_mat(TmRowsParams p) {
+  constexpr int P = KS * KS, HP = KS / 2, HK = KW / 2, NQ = 8, TY = 4, TX = 32, QMAX = (KS + NQ - 1) / NQ;
+  static_assert(TY * TX == TM_PX && QMAX == 7, "4 x 32 tiles; at most 7 offsets of a row per part");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NR = 2, RUN = NR * KS;                  // offset rows per hand-over: a pixel's run is RUN floats
+  float *stage = lds;                                   // [2 images][TM_PX][RUN]
+  float *red = stage + 2 * TM_PX * RUN;                 // [8][NQ][TM_PX]
+  double *redk = (double *)(red + 8 * NQ * TM_PX);      // [NQ][TM_PX]
+  float *wred = (float *)(redk + NQ * TM_PX);           // [3][16]
+  int *prow = (int *)(wred + 48);                       // [TM_PX] row of every pixel of the tile (-1: hole)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ck = wv & 1, part = wv >> 1;
+  const int tslot = blockIdx.x;
+  if (tslot >= dense_tile_count(p.n_dense) || p.n_dense[1] != TY ||
+      !tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host))) {
+    if (threadIdx.x == 0) {
+      p.partials[2 * tslot] = 0.f;
+      p.partials[2 * tslot + 1] = 0.f;
+      if (p.gmax_part) p.gmax_part[tslot] = 0.f;
+    }
+    return;
+  }
+  const int H = p.H, W = p.W;
+  const int tx_n = (W + TX - 1) / TX, ty_n = (H + TY - 1) / TY;
+  const int tile = dense_tile_id(dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot));
+  const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
+  const int ty0 = (tr / tx_n) * TY, tx0 = (tr % tx_n) * TX;
+  const int nrows = rows_to_do(p.n_dev, p.n_host);
+  const int y = ty0 + tm_pixel_row(ck, lane), x = tx0 + tm_pixel_col(lane);
+  int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+  if (r >= nrows) r = -1;
+  if (part == 0) prow[ck * 64 + lane] = r;
+  const TmScale sa = tm_scale(r >= 0 ? p.row_scale[r] : 0.0), sb = tm_scale(r >= 0 ? p.row_scale[(size_t)p.n_host + r] : 0.0);
+  const float invM = 1.f / ((float)nrows * (float)P);
+  const float u1 = p.upstream ? p.upstream[0] : 1.f, u2 = p.upstream ? p.upstream[1] : 1.f;
+  const float w1m = p.w_l1 * invM * u1, w2m = p.w_kl * invM * u2;
+  const float cl = 1e-10f;
+  const int qx0 = (KS * part) / NQ, qn = (KS * (part + 1)) / NQ - qx0;   // this part's columns of every offset row
+  const float *pa = p.tm[0] + (size_t)tslot * P * TM_PX + (size_t)qx0 * TM_PX + ck * 64 + lane;
+  const float *pb = p.tm[1] + (size_t)tslot * P * TM_PX + (size_t)qx0 * TM_PX + ck * 64 + lane;
+  float l1 = 0.f, d1 = 0.f, d2 = 0.f, bs = 0.f, bg = 0.f, m1 = 0.f, m2 = 0.f;
+  double kld = 0.0;
+  float na[QMAX], nb[QMAX];   // the next offset row's values, in flight while the current row is worked on
+#pragma unroll
+  for (int j = 0; j < QMAX; ++j) {
+    const int jj = j < qn ? j : 0;
+    na[j] = __builtin_nontemporal_load(pa + (size_t)jj * TM_PX);
+    nb[j] = __builtin_nontemporal_load(pb + (size_t)jj * TM_PX);
+  }
+  float *out_a = const_cast<float *>(p.out[0]), *out_b = const_cast<float *>(p.out[1]);
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  lds_barrier();   // (prow)
+#pragma unroll 1
+  for (int qy = 0; qy < KS; ++qy) {
+    float ea[QMAX], eb[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+      ea[j] = na[j];
+      eb[j] = nb[j];
+    }
+    if (qy + 1 < KS) {
+#pragma unroll
+      for (int j = 0; j < QMAX; ++j) {
+        const int jj = j < qn ? j : 0;
+        na[j] = __builtin_nontemporal_load(pa + (size_t)((qy + 1) * KS + jj) * TM_PX);
+        nb[j] = __builtin_nontemporal_load(pb + (size_t)((qy + 1) * KS + jj) * TM_PX);
+      }
+    }
+    const bool yb = qy < HK || qy > KS - 1 - HK, yc = qy == HP;
+    const int rr = qy % NR;
+    float *sta = stage + (ck * 64 + lane) * RUN + rr * KS + qx0, *stb = sta + TM_PX * RUN;
+    float kl = 0.f;
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+      if (j < qn) {   // (wave-uniform: parts 0..6 have six columns, part 7 seven)
+        const int qx = qx0 + j;
+        const float a = tm_apply(ea[j], sa), t = tm_apply(eb[j], sb);
+        sta[j] = a;
+        stb[j] = t;
+        const float ac = fmaxf(a, cl), bc = fmaxf(t, cl);
+        l1 += fabsf(a - t);
+        const float rc = __builtin_amdgcn_rcpf(ac);
+        const float r0 = bc * rc;
+        const float ratio = __builtin_fmaf(__builtin_fmaf(-r0, ac, bc), rc, r0);
+        kl += bc * (0.69314718056f * __builtin_amdgcn_logf(ratio));
+        const float sg = __builtin_amdgcn_fmed3f((a - t) * 0x1p126f, -1.f, 1.f);
+        const float bz = a >= cl ? bc : 0.f;
+        d1 = __builtin_fmaf(sg, a, d1);
+        d2 += bz;
+        const float gs = __builtin_fmaf(w1m * sg, a, -w2m * bz);
+        const float bm = (yb || qx < HK || qx > KS - 1 - HK) ? 1.f : 0.f, cm = (qx == HP && yc) ? 0.f : 1.f;
+        bs = __builtin_fmaf(a, bm, bs);
+        bg = __builtin_fmaf(gs, bm, bg);
+        m1 = fmaxf(m1, a * cm);
+        m2 = fmaxf(m2, fabsf(a - bz) * cm);
+      }
+    }
+    kld += (double)kl;
+    if (rr == NR - 1 || qy == KS - 1) {
+      // (barriers for the LDS hand-over only: a __syncthreads() would also drain the stores of the last hand-over and
+      // the next row's loads -- two memory round trips per hand-over)
+      lds_barrier();   // NR offset rows (the last hand-over: one) are complete in the tile
+      // the tile's 2 x 128 runs: a pixel's NR offset rows are adjacent in its SSG row; element (image, pixel, i)
+      const int len = (rr + 1) * KS, qbase = (qy - rr) * KS;
+      for (int e = threadIdx.x; e < 2 * TM_PX * RUN; e += 1024) {
+        const int img = e >= TM_PX * RUN, e1 = e - img * TM_PX * RUN, px = e1 / RUN, i = e1 - px * RUN;
+        const int row = prow[px];
+        if (row >= 0 && i < len) (img ? out_b : out_a)[(size_t)row * P + qbase + i] = stage[e];
+      }
+      lds_barrier();   // (the tile is free for the next NR rows)
+    }
+  }
+  red[(0 * NQ + part) * TM_PX + ck * 64 + lane] = l1;
+  redk[part * TM_PX + ck * 64 + lane] = kld;
+  red[(2 * NQ + part) * TM_PX + ck * 64 + lane] = d1;
+  red[(3 * NQ + part) * TM_PX + ck * 64 + lane] = d2;
+  red[(4 * NQ + part) * TM_PX + ck * 64 + lane] = bs;
+  red[(5 * NQ + part) * TM_PX + ck * 64 + lane] = bg;
+  red[(6 * NQ + part) * TM_PX + ck * 64 + lane] = m1;
+  red[(7 * NQ + part) * TM_PX + ck * 64 + lane] = m2;
+  __syncthreads();
+  float l1w = 0.f, klw = 0.f, gb = 0.f;
+  if (part == 0) {   // waves 0 and 1: one lane per pixel, the eight parts in a fixed order
+    const int px = ck * 64 + lane;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (k == 1) continue;
+      float t = red[(k * NQ) * TM_PX + px];
+#pragma unroll
+      for (int j = 1; j < NQ; ++j) t += red[(k * NQ + j) * TM_PX + px];
+      v[k] = t;
+    }
+    {
+      double t = redk[px];
+#pragma unroll
+      for (int j = 1; j < NQ; ++j) t += redk[j * TM_PX + px];
+      v[1] = (float)t;
+    }
+#pragma unroll
+    for (int k = 6; k < 8; ++k) {
+      float t = red[(k * NQ) * TM_PX + px];
+#pragma unroll
+      for (int j = 1; j < NQ; ++j) t = fmaxf(t, red[(k * NQ + j) * TM_PX + px]);
+      v[k] = t;
+    }
+    const float kfac = 1.f / (p.sigma * (float)(p.C * KW * KW));
+    v[2] *= w1m;
+    v[3] *= -w2m;
+    const float dot = v[2] + v[3];
+    if (r >= 0) {
+      p.dot[r] = dot;
+      p.sum_b[r] = -kfac * (v[5] - dot * v[4]);
+    }
+    gb = kfac * (v[6] * (fabsf(w1m) + fabsf(v[2]) + fabsf(v[3] + w2m)) + fabsf(w2m) * v[7]) * 1.0001f;
+    l1w = wave_sum(v[0]);
+    klw = wave_sum(v[1]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gb = fmaxf(gb, __shfl_xor(gb, o, 64));
+    if (lane == 0) {
+      wred[0 * 16 + ck] = l1w;
+      wred[1 * 16 + ck] = klw;
+      wred[2 * 16 + ck] = gb;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    p.partials[2 * tslot] = wred[0] + wred[1];
+    p.partials[2 * tslot + 1] = wred[16] + wred[17];
+    if (p.gmax_part) p.gmax_part[tslot] = fmaxf(wred[32], wred[33]);
+  }
+}
+
 int launch_rows_tm(const TmRowsParams &p, int ks, int kw, hipStream_t st) {
   if (p.n_tiles <= 0) return 0;
   if (ks != 49 || kw != 13) return -1;
+  if (p.out[0] && p.out[1]) {
+    constexpr int KS = 49, NQ = 8;
+    const size_t lds = sizeof(float) * (size_t)(2 * TM_PX * 2 * KS + 8 * NQ * TM_PX + 48) + sizeof(double) * NQ * TM_PX +
+                       sizeof(int) * TM_PX;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (const int rc = ensure_dynamic_lds(ssg_rows_tm_mat<49, 13>, (int)lds, lds_set)) return rc;
+    hipLaunchKernelGGL((ssg_rows_tm_mat<49, 13>), dim3((unsigned)p.n_tiles), dim3(1024), lds, st, p);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL((ssg_rows_tm<49, 13>), dim3((unsigned)p.n_tiles), dim3(1024), 0, st, p);
   return (int)hipGetLastError();
 }

@@ -375,6 +375,8 @@ class LossStep:
         self.ws_bytes = L.ssg_loss_workspace_bytes(B, H, W, self.capacity, ks)
         if not materialise:
             self.ws_bytes += L.ssg_loss_rows_bytes(self.capacity, ks)
+        else:   # (k_s 49: room for the tile-major regions, which a materialising call then uses as well; 0 otherwise)
+            self.ws_bytes += L.ssg_loss_tm_bytes(self.capacity, ks)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.fix = _grad_fix(deterministic, self.grad)   # deterministic mode: fixed-point accumulation buffer
         self.use_graph = bool(graph)

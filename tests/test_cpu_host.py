@@ -283,7 +283,7 @@ def test_workspace_layout_of_the_fused_call():
     lay = (ctypes.c_size_t * 9)()
     for ks, cap in ((25, 5000), (49, 5000), (49, 100), (11, 333)):
         B, H, W = 2, 70, 100
-        assert L.ssg_loss_workspace_layout(B, H, W, cap, ks, lay) == 0
+        assert L.ssg_loss_workspace_layout(B, H, W, cap, ks, 1, lay) == 0
         base, rows = L.ssg_loss_workspace_bytes(B, H, W, cap, ks), L.ssg_loss_rows_bytes(cap, ks)
         edges, rank, plan, rsc, r0, r1, t0, t1, slots = list(lay)
         assert 0 == edges < rank < plan < rsc < base == r0 < r1 and all(o % 256 == 0 for o in (rank, plan, rsc, r0, r1))
@@ -294,7 +294,11 @@ def test_workspace_layout_of_the_fused_call():
             assert t1 - t0 >= (slots + 1) * slot_bytes and base + rows - t1 >= (slots + 1) * slot_bytes
         else:
             assert (t0, t1, slots) == (0, 0, 0) and base + rows - r1 == r1 - r0
-    assert L.ssg_loss_workspace_layout(1, 64, 64, 0, 25, lay) == -1 and L.ssg_loss_workspace_layout(1, 64, 64, 10, 25, None) == -1
+        # a materialising call: no row-major scratch rows, the tile-major regions (k_s 49) directly behind the base
+        assert L.ssg_loss_workspace_layout(B, H, W, cap, ks, 0, lay) == 0
+        assert (lay[4], lay[5]) == (0, 0) and lay[6] == (base if ks == 49 else 0)
+        assert L.ssg_loss_tm_bytes(cap, ks) == (2 * (lay[7] - lay[6]) if ks == 49 else 0)
+    assert L.ssg_loss_workspace_layout(1, 64, 64, 0, 25, 1, lay) == -1 and L.ssg_loss_workspace_layout(1, 64, 64, 10, 25, 1, None) == -1
 
 
 def test_plan_built_for_another_tile_height_is_refused():

@@ -1271,7 +1271,7 @@ def test_fused_step_without_ssg_output(dev, ks, kw, shape, density, tile_major):
     assert b.ssg_sr is None and int(a.counts[0]) == int(b.counts[0]) > 0
     L = _lib.lib()
     lay = (ctypes.c_size_t * 9)()
-    assert L.ssg_loss_workspace_layout(B, H, W, b.capacity, ks, lay) == 0
+    assert L.ssg_loss_workspace_layout(B, H, W, b.capacity, ks, 1, lay) == 0
     n = int(b.counts[0])
     scales = b.ws[lay[3]: lay[3] + 8 * n].view(torch.float64)
     if ks in (25, 49):   # (sizes with deferred normalisation: the array is in use; negative = tile-major row)
@@ -1307,7 +1307,7 @@ def tile_major_ssg(step):
     ks, cap = step.cfg[0], step.capacity
     P = ks * ks
     lay = (ctypes.c_size_t * 9)()
-    assert _lib.lib().ssg_loss_workspace_layout(B, H, W, cap, ks, lay) == 0 and lay[6] > 0
+    assert _lib.lib().ssg_loss_workspace_layout(B, H, W, cap, ks, 1, lay) == 0 and lay[6] > 0
     ws = step.ws
     n = int(step.counts[0])
     rank = ws[lay[1]: lay[1] + 4 * B * H * W].view(torch.int32).view(B, H, W).cpu().numpy()
@@ -1389,6 +1389,18 @@ def test_tile_major_fused_step_k49_vs_oracle(dev, shape, density, sigma):
     assert maxerr(grad.cpu(), gref) <= 1e-5 * np.abs(gref).max()
     loss2, grad2 = step(T(sr, dev), T(gt, dev), T(mask, dev))
     assert torch.equal(loss, loss2) and torch.equal(grad, grad2)
+    # the MATERIALISING step on tile-major rows (workspace with ssg_loss_tm_bytes): ssg_rows_tm_mat writes the SSG
+    # tensors from the same rows -- the values rebuilt above, bit for bit up to a double-rounding tie of the emulation --
+    # and the direct kernels theirs; losses and gradient as for the fused step
+    step_m = engine.LossStep(B, C, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True)
+    loss_m, grad_m = step_m(T(sr, dev), T(gt, dev), T(mask, dev))
+    m_sr, m_gt = step_m.ssg_sr[:n].cpu().numpy(), step_m.ssg_gt[:n].cpu().numpy()
+    assert np.abs(m_sr - s_sr).max() <= 1.2e-7 * max(s_sr.max(), 1e-30) and np.abs(m_gt - s_gt).max() <= 1.2e-7 * max(s_gt.max(), 1e-30)
+    assert float((m_sr != s_sr).mean()) < 1e-4 and float((m_gt != s_gt).mean()) < 1e-4
+    assert maxerr(m_sr, ref["s_sr"]) <= 1e-5 and maxerr(m_gt, ref["s_gt"]) <= 1e-5
+    assert abs(float(loss_m[0]) - ref["l1"]) <= 1e-5 * ref["l1"] and abs(float(loss_m[1]) - kl_same) <= 3e-5 * kl_same
+    gref_m, _ = ref_grad_with_gpu_signs(sr, mask[:, 0], ks, kw, sigma, ref, m_sr, m_gt)
+    assert maxerr(grad_m.cpu(), gref_m) <= 1e-5 * np.abs(gref_m).max()
     # fp32 atomics (the reference's accumulation): same gradient up to the order of the additions
     step_a = engine.LossStep(B, C, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, deterministic=False,
                              materialise=False)

@@ -13,6 +13,6 @@ python - "$O/bench_$cfg.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 print("ms_per_step %.4f  value %.3f M  module %.4f" % (d["ms_per_step"], d["value"] / 1e6, d.get("module", {}).get("ms_per_step", 0)))
-for k, v in d["roofline"]["kernel_ms"].items():
+for k, v in d["roofline"].get("kernel_ms", {}).items():
     print("  %-55s %.4f" % (k, v))
 PY

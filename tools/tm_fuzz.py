@@ -38,7 +38,7 @@ for it in range(n_cases):
     torch.cuda.synchronize()
     # which path the fused step took: tile-major rows carry a negative row scale; strips are listed in the plan
     lay = (ctypes.c_size_t * 9)()
-    _lib.lib().ssg_loss_workspace_layout(B, H, W, b.capacity, 49, lay)
+    _lib.lib().ssg_loss_workspace_layout(B, H, W, b.capacity, 49, 1, lay)
     nrow = min(int(b.counts[0]), b.capacity)
     tm = bool((b.ws[lay[3]: lay[3] + 8 * nrow].view(torch.float64) < 0).any())
     ns = B * ((H + 3) // 4) * ((W + 31) // 32)
