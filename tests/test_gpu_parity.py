@@ -1296,6 +1296,40 @@ def test_fused_step_without_ssg_output(dev, ks, kw, shape, density, tile_major):
     assert rc == -3   # SSG_E_WORKSPACE
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("materialise", [False, True])
+def test_tile_major_steps_replay_as_hip_graph(dev, materialise):
+    """The k_s = 49 steps on tile-major rows (fused, and materialising through ssg_rows_tm_mat) recorded as a HIP graph:
+    the replay must reproduce the per-kernel launches bit for bit (deterministic accumulation), also after the
+    input content -- and with it the tile list, the strips and the tile-major decision -- changes at the recorded
+    addresses."""
+    from ssl_amd import engine, synth
+    B, H, W, ks, kw, sigma = 1, 64, 96, 49, 13, 0.05
+    kwargs = dict(device=dev, deterministic=True, materialise=materialise)
+    eager = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, **kwargs)
+    graph = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, graph=True, **kwargs)
+    gt_np = synth.natural_like(41, H, W)[None]
+    sr, gt = T(synth.degrade(gt_np[0], 42)[None], dev), T(gt_np, dev)
+    mask = torch.ones((B, 1, H, W), device=dev)
+
+    def same():
+        l0, g0 = eager(sr, gt, mask)
+        l0, g0 = l0.clone(), g0.clone()
+        l1, g1 = graph(sr, gt, mask)
+        n = int(eager.counts[0])
+        assert int(graph.counts[0]) == n and n > 0 and torch.equal(l0, l1) and torch.equal(g0, g1)
+        if materialise:
+            assert torch.equal(eager.ssg_sr[:n], graph.ssg_sr[:n]) and torch.equal(eager.ssg_gt[:n], graph.ssg_gt[:n])
+        return n
+
+    n1 = same()
+    assert same() == n1 and graph._graph is not None                   # replay
+    mask.copy_((torch.rand((B, 1, H, W), device=dev) < 0.4).float())   # sparse now: row-major rows, other kernels run
+    assert same() < n1
+    mask.fill_(1.0)
+    assert same() == n1
+
+
 def tile_major_ssg(step):
     """(s_sr, s_gt), each (N, k_s^2) float32 in edge-list order, of a finished fused k_s = 49 call, rebuilt from its
     workspace (ssg_loss_workspace_layout): the plan's dense-tile list gives every tile its slot, the slot holds
