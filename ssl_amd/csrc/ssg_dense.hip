@@ -32,6 +32,12 @@
 // the number of edge pixels, plus ~20 per 64 edge pixels of the tile; the direct kernels spend 2 C k_w^2 lane-ops per
 // (edge pixel, offset).  Break-even is ~16-28 edge pixels per 256-pixel tile (flat: tools/thr_sweep.sh); the
 // edge-list builder routes tiles at or above the threshold here.
+//
+// Two more things live in this file for k_s = 49 (round 3): the TM variant of the tile kernel, which leaves e in the
+// TILE-MAJOR scratch region ([slot][offset][128 pixels]: every wave store one aligned 256-byte run, no store
+// buffering) instead of the caller's row-major rows, and ssg_fwd_strip, which computes the forward rows of whole strips
+// of nine heavy tiles at once for tile-major calls (E/H shared by 36 centre rows).  ssg_common.hpp (TM_PX, tm_active,
+// TmRowsParams) and DESIGN.md sections 3-5 describe the layout and who reads it.
 #include "ssg_common.hpp"
 
 namespace ssg {

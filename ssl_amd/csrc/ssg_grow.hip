@@ -13,6 +13,10 @@
 // is truncated by the zero rule (similarity.cu:43-47): the dense-tile backward needs it for the
 // |I|^2 part of the distance.  G at the centre offset multiplies (A - B) == 0 exactly and is written
 // as 0 (it is the largest entry of a row by orders of magnitude at small sigma).
+//
+// Rows that live in the tile-major region of a k_s = 49 call (negative row scale) are not touched by ssg_grad_rows:
+// ssg_rows_tm (fused step) / ssg_rows_tm_mat (materialising call: it also writes the normalised SSG rows) below walk
+// them with lanes = pixels, and the dense backward forms their G itself.
 #include "ssg_common.hpp"
 
 namespace ssg {
