@@ -451,6 +451,25 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           Sf[m] = su.x + tot.y;
         });
         float hs[L];
+        if constexpr (KW == 9 && L == 10) {
+          // windows 0 and 1 lie inside the lane; windows 2..9 end in the next lane: Sf[k] + (next lane's Pf[k-2]) as ONE
+          // v_add_f32_dpp each (a DPP move and an addition before).  The hazard recogniser does not see into the
+          // statement: the s_nop covers the VALU-write -> DPP-read wait states of the Pf registers.
+          hs[0] = Pf[KW - 1];
+#pragma unroll
+          for (int k = 1; k < L; ++k) hs[k] = Sf[k];
+          asm volatile("s_nop 1\n\t"
+                       "v_add_f32_dpp %0, %8, %0 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_add_f32_dpp %1, %9, %1 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_add_f32_dpp %2, %10, %2 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_add_f32_dpp %3, %11, %3 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_add_f32_dpp %4, %12, %4 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_add_f32_dpp %5, %13, %5 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_add_f32_dpp %6, %14, %6 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_add_f32_dpp %7, %15, %7 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                       : "+v"(hs[2]), "+v"(hs[3]), "+v"(hs[4]), "+v"(hs[5]), "+v"(hs[6]), "+v"(hs[7]), "+v"(hs[8]), "+v"(hs[9])
+                       : "v"(Pf[0]), "v"(Pf[1]), "v"(Pf[2]), "v"(Pf[3]), "v"(Pf[4]), "v"(Pf[5]), "v"(Pf[6]), "v"(Pf[7]));
+        } else {
         static_for(std::make_integer_sequence<int, L>{}, [&](auto kc) {
           constexpr int k = decltype(kc)::value, last = k + KW - 1;  // window [k, last] in the lane's own coordinates
           if constexpr (last < L) {
@@ -460,6 +479,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             hs[k] = Sf[k] + quad_next<1>(Pf[last - L]);
           }
         });
+        }
 #pragma unroll
         for (int k = 0; k < HL; ++k) Hs[k] = f2{hs[k], hs[k + HL]};
       } else {
