@@ -50,9 +50,41 @@ CONFIGS = {
                name="C2: batch 16 x 3x256x256 per GPU, Laplacian mask, k_s=25 k_w=9 sigma=1.0, L1+KL w=1e3, SSGs materialised"),
     "c5": dict(ks=49, kw=13, sigma=1.0, batch=1, H=512, W=512, dense_mask=True,
                name="C5: 1 x 3x512x512 per GPU, dense (100 %) mask, k_s=49 k_w=13 sigma=1.0, L1+KL w=1e3, SSGs materialised"),
+    # BASELINE configs[3], the loss workload of one GPU of the LDM-SR step (Diffusion-Based-SR/ldm/models/diffusion/
+    # ddpmssl.py:438-513, configs/StableSRISSLStage1/*.yml:32-41,268-277): bs 8 over 4 GPUs = 2 crops of 512 x 512,
+    # Laplacian mask AND the stride-3 pattern (~0.8 % of the pixels), eps 1e-20, scaling_factor 0.004, weights 5e2
+    "c4": dict(ks=25, kw=9, sigma=0.004, batch=2, H=512, W=512, dense_mask=False, eps=1e-20, stride=3, w=5e2, seed0=2000,
+               name="C4: 2 x 3x512x512 per GPU, Laplacian mask x stride-3 pattern, k_s=25 k_w=9 sigma=0.004 eps=1e-20, "
+                    "L1+KL w=5e2, SSGs materialised"),
 }
 EPS, C = 1e-10, 3
 W_L1 = W_KL = 1e3
+
+
+def cfg_eps(cfg):
+    return cfg.get("eps", EPS)
+
+
+def cfg_w(cfg):
+    return cfg.get("w", W_L1)
+
+
+def cfg_stride(cfg):
+    return cfg.get("stride", 0)
+
+
+def effective_mask(cfg, mask_np):
+    """The mask the loss step really uses: the given mask AND the stride pattern (realesrganssl_model.py:64-72)."""
+    from ssl_amd import synth
+    if cfg_stride(cfg) <= 1:
+        return mask_np
+    return mask_np * synth.mask_stride_pattern(cfg["H"], cfg["W"], cfg_stride(cfg))[None, None].astype(mask_np.dtype)
+
+
+def make_step(cfg, B, dev, capacity, **kw):
+    from ssl_amd import engine
+    return engine.LossStep(B, C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], cfg_eps(cfg), True, cfg_w(cfg),
+                           cfg_w(cfg), mask_stride=cfg_stride(cfg), device=dev, capacity=capacity, **kw)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
@@ -123,7 +155,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     from ssl_amd import _lib, engine
     # geometry and kernel sizes come from the LossStep itself (`cfg` is kept for callers that pass it)
     _, _, H, W = step.shape
-    KS, KW, SIGMA = step.cfg[0], step.cfg[1], step.cfg[2]
+    KS, KW, SIGMA, EPS_, _, WL1, WKL, STRIDE, THR = step.cfg
     # the PROFILING build of the library (libssg_hip_prof.so, -DSSG_PROFILE): the only one that can mask launches out;
     # same kernels, same launch code -- the timed step of main() runs on the product library
     L = _lib.lib_prof()
@@ -139,16 +171,16 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     p = engine._ptr
 
     def f_edges():
-        _lib.check(L.ssg_edge_list(p(mask), 0, 1, B, H, W, 0, 20.0, KS, p(edges), step.capacity, p(step.counts),
+        _lib.check(L.ssg_edge_list(p(mask), 0, 1, B, H, W, STRIDE, THR, KS, p(edges), step.capacity, p(step.counts),
                                    p(rank), p(order), p(plan), p(scratch), st))
 
     def f_fwd():
         _lib.check(L.ssg_map_forward(p(sr), p(gt), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts),
-                                     n_edges, KS, KW, SIGMA, EPS, 1, p(step.ssg_sr), p(step.ssg_gt), p(rsc), st))
+                                     n_edges, KS, KW, SIGMA, EPS_, 1, p(step.ssg_sr), p(step.ssg_gt), p(rsc), st))
 
     def f_bwd():
         _lib.check(L.ssg_loss_backward(p(sr), B, C, H, W, p(edges), p(order), p(rank), p(plan), p(step.counts), n_edges,
-                                       KS, KW, SIGMA, 1, p(step.ssg_sr), p(step.ssg_gt), W_L1, W_KL, None, p(step.loss),
+                                       KS, KW, SIGMA, 1, p(step.ssg_sr), p(step.ssg_gt), WL1, WKL, None, p(step.loss),
                                        p(step.grad), p(lscratch), None, p(rsc), 0, st))
 
     def only(fn, keep, group):
@@ -187,7 +219,8 @@ def module_time_ms(cfg, sr, gt, mask, n_edges, iters):
     """The step through the drop-in module: SSGLoss forward (edge list, SSGs, criteria, gradient) + autograd backward."""
     import torch
     from ssl_amd import SSGLoss
-    crit = SSGLoss(cfg["ks"], cfg["kw"], cfg["sigma"], True, W_L1, W_KL, capacity=n_edges + 1024)
+    crit = SSGLoss(cfg["ks"], cfg["kw"], cfg["sigma"], True, cfg_w(cfg), cfg_w(cfg), mask_stride=cfg_stride(cfg),
+                   eps=cfg_eps(cfg), capacity=n_edges + 1024)
     x = sr.clone().requires_grad_(True)
 
     def one():
@@ -207,6 +240,8 @@ def cpu_baseline(cfg, sr, gt, mask, budget_s=20.0):
     (about budget_s seconds of wall time: whole images, as many as fit; C5: a strip of edge pixels)."""
     from oracle import ssg_oracle as orc
     KS, KW, SIGMA = cfg["ks"], cfg["kw"], cfg["sigma"]
+    W_L1 = W_KL = cfg_w(cfg)
+    mask = effective_mask(cfg, mask)
     cores = os.cpu_count() or 1
     orc.ssg_loss(sr[:1, :, :64, :64], gt[:1, :, :64, :64], mask[:1, 0, :64, :64], KS, KW, SIGMA, W_L1, W_KL)  # warm up
     if cfg["dense_mask"]:
@@ -218,13 +253,13 @@ def cpu_baseline(cfg, sr, gt, mask, budget_s=20.0):
         what = f"{r['n_edges']} of {mask[0, 0].size} edge px (rows 0-63 of the image)"
     else:
         t0 = time.time()
-        r = orc.ssg_loss(sr[:1], gt[:1], mask[:1, 0], KS, KW, SIGMA, W_L1, W_KL)     # calibrate on image 0
+        r = orc.ssg_loss(sr[:1], gt[:1], mask[:1, 0], KS, KW, SIGMA, W_L1, W_KL, eps=cfg_eps(cfg))     # calibrate on image 0
         per_img = max(time.time() - t0, 1e-3)
         nimg = int(min(sr.shape[0], max(1, round(budget_s / per_img))))
         dt = per_img
         if nimg > 1:
             t0 = time.time()
-            r = orc.ssg_loss(sr[:nimg], gt[:nimg], mask[:nimg, 0], KS, KW, SIGMA, W_L1, W_KL)
+            r = orc.ssg_loss(sr[:nimg], gt[:nimg], mask[:nimg, 0], KS, KW, SIGMA, W_L1, W_KL, eps=cfg_eps(cfg))
             dt = time.time() - t0
         what = f"first {nimg} of {sr.shape[0]} images ({r['n_edges']} edge px)"
     return {"value": r["n_edges"] / dt, "unit": "edge-px/s", "cores": cores, "kind": "port",
@@ -315,7 +350,7 @@ def pmc_issue(config_key, step_gpu_ms):
         return None
 
 
-def extra_line(cfg_key, fused, dev, steps, warmup):
+def extra_line(cfg_key, fused, dev, steps, warmup, maskgen=False):
     """One more (config, mode) measured in the same process for the driver's JSON line: wall-clock over `steps` steps
     between two synchronisations, its own algorithmic bytes (materialised B_alg = 8 k_s^2 + (12C+4)HW/N,
     fused B_alg' = (12C+4)HW/N -- never mixed)."""
@@ -323,11 +358,12 @@ def extra_line(cfg_key, fused, dev, steps, warmup):
     from ssl_amd import engine
     cfg = CONFIGS[cfg_key]
     sr_np, gt_np, mask_np = make_inputs(cfg, 0, 1, "weak")
-    n = int(mask_np.sum())
+    n = int(effective_mask(cfg, mask_np).sum())
     B = sr_np.shape[0]
     sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
-    step = engine.LossStep(B, C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1, W_KL,
-                           device=dev, capacity=n + 1024, materialise=not fused)
+    step = make_step(cfg, B, dev, n + 1024, materialise=not fused)
+    if maskgen:
+        mask = None          # mask_kind 2: the reference's offline Laplacian mask generated from GT inside the edge-list kernels
     for _ in range(warmup):
         step(sr, gt, mask)
     torch.cuda.synchronize()
@@ -339,18 +375,115 @@ def extra_line(cfg_key, fused, dev, steps, warmup):
     assert int(step.counts[0]) == n
     loss = step.loss.cpu().numpy()
     b_alg = alg_bytes_per_edge_px(cfg, n, B) - (8.0 * cfg["ks"] ** 2 if fused else 0.0)
+    if maskgen:
+        b_alg -= 4.0 * cfg["H"] * cfg["W"] * B / max(n, 1)     # (the fp32 mask read is 0 when generated on the GPU)
     ach = b_alg * n / (ms * 1e-3) / 1e9
     del step, sr, gt, mask
     torch.cuda.empty_cache()
     # what the step really moves (scratch rows included): the committed PMC passes of this configuration
     moved = pmc_step_bytes({"c2": "c2", "c5": "c5f" if fused else "c5"}.get(cfg_key) if not (fused and cfg_key == "c2") else None)
-    return {"workload": cfg["name"].replace("SSGs materialised", "fused step: no SSG output") if fused else cfg["name"],
+    return {"workload": (cfg["name"].replace("SSGs materialised", "fused step: no SSG output") if fused else cfg["name"]) +
+                        (" [mask=None: Laplacian edge mask of GT generated on the device, generate_mask.py:22-31]" if maskgen else ""),
             "ms_per_step": ms, "value": n / (ms * 1e-3), "unit": "edge-px/s", "steps": steps, "warmup": warmup,
             "edge_px": n, "l1": float(loss[0]), "kl": float(loss[1]),
             "roofline": {"step": {"alg_bytes_per_edge_px": b_alg, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": ach / HBM_PEAK_GBS, "traffic": moved,
                                   "traffic_GBps": None if not moved else moved / (ms * 1e-3) / 1e9,
                                   "traffic_frac": None if not moved else moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}}
+
+
+def ref_api_lines(cfg, sr, gt, mask, n_edges, headline_ms):
+    """Row R1: the reference's UNCHANGED caller loop (ssl_amd/reference_loop.py = realesrganssl_model.py:379-430) on the
+    headline's inputs -- per image: mask slice, `mask.sum() == 0` (host sync), two clones + `similarity_map` for SR, the
+    same for GT; then torch.cat, L1Loss, KLDistanceLoss, `.backward()` -- against ssl_amd's drop-in modules, for every
+    `ssl_mode` ('cuda' is the reference YAML's default, train_RealESRGANSSL_x4.yml:115), with deferred handles
+    (ssl_amd/losses/lazy.py, the default) and with eager tensors (SSG_LAZY=0).  Wall clock between two
+    synchronisations, forward + backward.  `caller_floor` is the same loop around a `similarity_map` that computes
+    nothing: what the loop's own clones, synchronisations, cat and autograd bookkeeping cost on this box."""
+    import torch
+    from ssl_amd.losses import KLDistanceLoss, L1Loss, similarity_map, set_lazy
+    from ssl_amd.reference_loop import gan_selfsim_block
+    cri1, cri2 = L1Loss(loss_weight=cfg_w(cfg)), KLDistanceLoss(loss_weight=cfg_w(cfg))
+    x = sr.clone().requires_grad_(True)
+    P = cfg["ks"] ** 2
+
+    class nothing:            # a similarity_map that only keeps autograd's structure: (1, 1, k_s^2) view of the image
+        def __init__(self, img, mask=None, **kw):
+            self.s = img.reshape(1, 1, -1)[:, :, :P]
+
+        def getitem(self):
+            return self.s
+
+    def loop(smap, mode):
+        x.grad = None
+        setting = dict(ssl_mode=mode, kernel_size_search=cfg["ks"], generalization=True,
+                       kernel_size_window=cfg["kw"], sigma=cfg["sigma"])
+        out = x * 1.0
+        l1, kl = gan_selfsim_block(smap, cri1, cri2, out, gt, mask, setting)
+        (l1 + kl).backward()
+        return l1, kl
+
+    def timed(smap, mode, iters, warm):
+        for _ in range(warm):
+            loop(smap, mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            l1, kl = loop(smap, mode)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3, float(l1), float(kl)
+
+    out = {"what": "unchanged per-image caller loop (similarity_map x2 per image, torch.cat, L1Loss, KLDistanceLoss, "
+                   "backward) on the headline's 16 images; ms per loop, forward + backward, wall clock",
+           "headline_step_ms": headline_ms}
+    floor, _, _ = timed(nothing, "cuda", 10, 3)
+    out["caller_floor_ms"] = floor
+    for lz in (True, False):
+        prev = set_lazy(lz)
+        try:
+            for mode in ("cuda", "pytorch", "hip"):
+                ms, l1, kl = timed(similarity_map, mode, 10 if lz else 3, 2 if lz else 1)
+                out[f"{mode}{'' if lz else '_eager'}"] = {
+                    "ms": ms, "value": n_edges / (ms * 1e-3), "unit": "edge-px/s", "x_headline": ms / headline_ms,
+                    "ms_above_caller_floor": ms - floor, "l1": l1, "kl": kl}
+        finally:
+            set_lazy(prev)
+        torch.cuda.empty_cache()
+    return out
+
+
+def operator_line(cfg, sr, mask):
+    """INTEGRATION Level 0 / 0a: the reference's native operator on ONE image of the headline batch --
+    compute_similarity(image (C,H,W), mask (H,W), psize, ksize) -> raw distances (N, psize, psize) and its backward
+    (similaritywrapper.py:25-69 on the C ABI of similarity.h:2-23).  Wall clock incl. the wrapper's reflect pad and
+    torch.nonzero (a host synchronisation, as in the reference)."""
+    import torch
+    from ssl_amd import compute_similarity
+    img = sr[0].clone().requires_grad_(True)
+    m = mask[0, 0]
+    n = int(m.sum())
+    cot = torch.rand(n, cfg["ks"], cfg["ks"], device=sr.device)
+
+    def fwd():
+        return compute_similarity(image=img, mask=m, psize=cfg["ks"], ksize=cfg["kw"])
+
+    def both():
+        img.grad = None
+        fwd().backward(cot)
+
+    res = {}
+    for name, fn in (("fwd", fwd), ("fwd_bwd", both)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        res[name + "_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    res.update(what="compute_similarity forward / forward + backward on one 3x256x256 image of the batch (wall clock)",
+               edge_px=n, value=n / (res["fwd_bwd_ms"] * 1e-3), unit="edge-px/s")
+    return res
 
 
 def make_inputs(cfg, rank, world, scaling):
@@ -362,11 +495,12 @@ def make_inputs(cfg, rank, world, scaling):
         gt = np.stack([synth.natural_like(300 + rank * B + i, H, W) for i in range(B)])
         sr = np.stack([synth.degrade(gt[i], 7 + rank * B + i) for i in range(B)])
         return sr, gt, np.ones((B, 1, H, W), np.float32)
+    seed0 = cfg.get("seed0", 100)
     if scaling == "strong":
         lo, hi = shard_images(B, rank, world)
-        sr, gt, mask = synth.make_batch(B, H, W, seed0=100)
+        sr, gt, mask = synth.make_batch(B, H, W, seed0=seed0)
         return sr[lo:hi], gt[lo:hi], mask[lo:hi]
-    return synth.make_batch(B, H, W, seed0=100 + B * rank)
+    return synth.make_batch(B, H, W, seed0=seed0 + B * rank)
 
 
 def main():
@@ -419,7 +553,7 @@ def main():
     from ssl_amd import synth
     sr_np, gt_np, mask_np = make_inputs(cfg, rank, world, args.scaling)
     B = sr_np.shape[0]
-    n_edges = int(mask_np.sum())
+    n_edges = int(effective_mask(cfg, mask_np).sum())
 
     def sync_all():
         if not args.dry_run:
@@ -435,11 +569,9 @@ def main():
         def run_step():
             return None
     else:
-        from ssl_amd import engine
         sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
-        step = engine.LossStep(max(B, 1), C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1,
-                               W_KL, device=dev, capacity=n_edges + 1024, graph=args.graph,
-                               materialise=not args.no_ssg_output) if B else None
+        step = make_step(cfg, max(B, 1), dev, n_edges + 1024, graph=args.graph,
+                         materialise=not args.no_ssg_output) if B else None
 
         def run_step():
             if step is not None:
@@ -467,8 +599,9 @@ def main():
     if rank == 0:
         value = total_edges * args.steps / elapsed
         res = {
-            "metric": ("SSG-loss edge-pixels/sec (fwd+bwd) 3x256x256 k_s=25 k_w=9" if args.config == "c2" else
-                       "SSG-loss edge-pixels/sec (fwd+bwd) 3x512x512 k_s=49 k_w=13 dense mask") +
+            "metric": {"c2": "SSG-loss edge-pixels/sec (fwd+bwd) 3x256x256 k_s=25 k_w=9",
+                       "c4": "SSG-loss edge-pixels/sec (fwd+bwd) 3x512x512 k_s=25 k_w=9 mask_stride=3 eps=1e-20",
+                       "c5": "SSG-loss edge-pixels/sec (fwd+bwd) 3x512x512 k_s=49 k_w=13 dense mask"}[args.config] +
                       (" [fused step, no SSG output: B_alg' = (12C+4)HW/N]" if args.no_ssg_output else ""),
             "value": value, "unit": "edge-px/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
@@ -496,7 +629,7 @@ def main():
             # on request (rocprofv3 runs of one step's own kernels) and for k_s = 49, where the timed step runs on
             # tile-major rows (ssg_fwd_strip, ssg_rows_tm[_mat], ssg_bwd_dense<..., TM>) while the separate entry points
             # run the row-major kernels: that step's per-kernel figures are the committed rocprofv3 stats.
-            key = ("c5f" if args.no_ssg_output else "c5") if args.config == "c5" else (None if args.no_ssg_output else "c2")
+            key = ("c5f" if args.no_ssg_output else "c5") if args.config == "c5" else (None if args.no_ssg_output else args.config)
             if args.no_kernel_table or cfg["ks"] == 49:
                 step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), it)
                 ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
@@ -510,9 +643,7 @@ def main():
                                             "traffic_frac": None if not moved else moved / (step_gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
             else:
                 # (per-kernel times: through the separate entry points, which need SSG tensors of their own)
-                step_k = step if not args.no_ssg_output else engine.LossStep(
-                    B, C, cfg["H"], cfg["W"], cfg["ks"], cfg["kw"], cfg["sigma"], EPS, True, W_L1, W_KL, device=dev,
-                    capacity=n_edges + 1024)
+                step_k = step if not args.no_ssg_output else make_step(cfg, B, dev, n_edges + 1024)
                 if step_k is not step:
                     step_k(sr, gt, mask)
                 stages = stage_times(step_k, sr, gt, mask, n_edges, it, cfg)
@@ -552,7 +683,11 @@ def main():
                 # the other configuration / mode lines, driver-visible (about 2 s of GPU time in all)
                 res["extra"] = {"c5": extra_line("c5", False, dev, 10, 3),
                                 "c2_fused": extra_line("c2", True, dev, 30, 5),
-                                "c5_fused": extra_line("c5", True, dev, 10, 3)}
+                                "c5_fused": extra_line("c5", True, dev, 10, 3),
+                                "c4": extra_line("c4", False, dev, 50, 10),
+                                "c2_maskgen": extra_line("c2", False, dev, 30, 5, maskgen=True),
+                                "ref_api": ref_api_lines(cfg, sr, gt, mask, n_edges, elapsed / args.steps * 1e3),
+                                "operator": operator_line(cfg, sr, mask)}
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg, sr_np, gt_np, mask_np)
                 res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]

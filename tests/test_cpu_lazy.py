@@ -1,0 +1,191 @@
+"""Host logic of the deferred SSG handles (ssl_amd/losses/lazy.py) on the CPU.
+
+What needs the GPU -- the eager rows of one image and the batched step's autograd node -- is replaced by the
+ORACLE here (the checker standing in for the kernels; the GPU suite, tests/test_gpu_ref_api.py, runs the same loop
+through the C ABI).  What is under test is everything around them: the `__torch_function__` dispatch of the
+reference's unchanged caller loop (`torch.cat`, `F.l1_loss` ... `.mean()`, `torch.clamp(...).log()`, `F.kl_div`),
+one shared node for both criteria, the qualification rules, and that every other use of a handle falls back to the
+tensor with the same values.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ssg_oracle as orc
+
+KS, KW, SIGMA = 7, 3, 0.5
+
+
+class _Rows(torch.autograd.Function):
+    """similarity_map(...).getitem() of one image by the oracle (fp64 inside)."""
+
+    @staticmethod
+    def forward(ctx, img, mask2d, ks, kw, sigma, eps, gen):
+        im = img.detach().numpy()[0].astype(np.float64)
+        pos = orc.mask_to_pos(mask2d.numpy())
+        S = orc.ssg_epilogue(orc.distance(im, pos, ks, kw), kw, im.shape[0], sigma, gen, eps)
+        ctx.meta = (im, pos, ks, kw, sigma, gen, S)
+        return torch.as_tensor(S, dtype=torch.float32)[None]
+
+    @staticmethod
+    def backward(ctx, g):
+        im, pos, ks, kw, sigma, gen, S = ctx.meta
+        gD = orc.ssg_epilogue_backward(S, g.numpy()[0].astype(np.float64), ks, kw, im.shape[0], sigma, gen)
+        return (torch.as_tensor(orc.distance_backward(im, pos, ks, kw, gD), dtype=torch.float32)[None],) + (None,) * 6
+
+
+def oracle_rows(img, mask, conv, ks, kw, sigma, eps, gen):
+    chans = range(mask.shape[1]) if conv == 'all' else [0]
+    return torch.cat([_Rows.apply(img, (mask[0, c] == 1).to(torch.uint8), ks, kw, sigma, eps, gen) for c in chans], dim=1)
+
+
+class _Step(torch.autograd.Function):
+    """Stand-in for lazy._LazyStepFn: (l1 mean, kl mean, count) of a batch by the oracle's caller loop."""
+    calls = 0
+
+    @staticmethod
+    def forward(ctx, x, y, mask, ks, kw, sigma, eps, gen, det):
+        _Step.calls += 1
+        sr, gt = x.detach().numpy().astype(np.float64), y.numpy().astype(np.float64)
+        m = (mask.numpy()[:, 0] == 1).astype(np.uint8)
+        r1 = orc.ssg_loss(sr, gt, m, ks, kw, sigma, 1.0, 0.0, eps=eps)
+        r2 = orc.ssg_loss(sr, gt, m, ks, kw, sigma, 0.0, 1.0, eps=eps)
+        ctx.grads = (torch.as_tensor(r1["grad"], dtype=torch.float32), torch.as_tensor(r2["grad"], dtype=torch.float32))
+        f = lambda v: torch.tensor(float(v), dtype=torch.float32)
+        return f(r1["l1"]), f(r2["kl"]), f(r1["n_edges"] * ks * ks)
+
+    @staticmethod
+    def backward(ctx, g1, g2, _g3):
+        return (ctx.grads[0] * g1 + ctx.grads[1] * g2,) + (None,) * 8
+
+
+@pytest.fixture
+def lazy_on_cpu(monkeypatch):
+    from ssl_amd import engine
+    from ssl_amd.losses import lazy, loss_util
+    monkeypatch.setattr(lazy, "_LazyStepFn", _Step)
+    monkeypatch.setattr(lazy, "_on_gpu", lambda t: True)
+    monkeypatch.setattr(loss_util, "eager_rows", oracle_rows)
+    monkeypatch.setattr(engine, "_need_gpu", lambda *t: None)
+    prev = lazy.set_lazy(True)
+    _Step.calls = 0
+    yield lazy
+    lazy.set_lazy(prev)
+
+
+def batch(seed=0, B=3, H=20, W=22):
+    rng = np.random.default_rng(seed)
+    gt = rng.random((B, 3, H, W), dtype=np.float32)
+    sr = np.clip(gt + 0.05 * rng.standard_normal((B, 3, H, W)).astype(np.float32), 0, 1)
+    mask = (rng.random((B, 1, H, W)) < 0.08).astype(np.float32)
+    if B > 1:
+        mask[1] = 0                                         # an image the loop skips
+    return torch.as_tensor(sr), torch.as_tensor(gt), torch.as_tensor(mask)
+
+
+def run_loop(mode, sr, gt, mask, w1=1e3, w2=1e3):
+    from ssl_amd.losses import KLDistanceLoss, L1Loss, similarity_map
+    from ssl_amd.reference_loop import gan_selfsim_block
+    x = sr.clone().requires_grad_(True)
+    setting = dict(ssl_mode=mode, kernel_size_search=KS, generalization=True, kernel_size_window=KW, sigma=SIGMA)
+    l1, kl = gan_selfsim_block(similarity_map, L1Loss(w1), KLDistanceLoss(w2), x * 1.0, gt, mask, setting)
+    (l1 + kl).backward()
+    return float(l1), float(kl), x.grad
+
+
+@pytest.mark.parametrize("mode", ["cuda", "pytorch", "hip"])
+def test_unchanged_loop_runs_as_one_batched_step(lazy_on_cpu, mode):
+    sr, gt, mask = batch()
+    l1, kl, grad = run_loop(mode, sr, gt, mask)
+    assert _Step.calls == 1                                  # both criteria, all images: one evaluation
+    m = mask.numpy()[:, 0].astype(np.uint8)
+    ref = orc.ssg_loss(sr.numpy().astype(np.float64), gt.numpy().astype(np.float64), m, KS, KW, SIGMA, 1e3, 1e3)
+    assert abs(l1 - ref["l1"]) <= 1e-6 * ref["l1"] and abs(kl - ref["kl"]) <= 1e-6 * ref["kl"]
+    assert float((grad - torch.as_tensor(ref["grad"], dtype=torch.float32)).abs().max()) <= 1e-6 * np.abs(ref["grad"]).max()
+    assert float(grad[1].abs().max()) == 0.0
+    # the same loop on eager tensors (per-image rows, torch criteria): same numbers
+    lazy_on_cpu.set_lazy(False)
+    e1, e2, egrad = run_loop(mode, sr, gt, mask)
+    assert _Step.calls == 1
+    assert abs(e1 - l1) <= 2e-6 * l1 and abs(e2 - kl) <= 2e-5 * kl
+    assert float((egrad - grad).abs().max()) <= 2e-5 * float(grad.abs().max())
+
+
+def test_three_channel_masks_keep_the_modes_conventions(lazy_on_cpu):
+    from ssl_amd.losses import similarity_map
+    sr, gt, mask = batch(1)
+    m3 = mask.repeat(1, 3, 1, 1)
+    a = run_loop("pytorch", sr, gt, m3)
+    b = run_loop("cuda", sr, gt, mask)
+    assert _Step.calls == 2 and abs(a[0] - b[0]) <= 1e-7 * b[0] and torch.equal(a[2], b[2])
+    # rows of a materialised 'pytorch' handle are listed once per channel, of a 'cuda' handle once
+    n = int(mask[0].sum())
+    hp = similarity_map(sr[:1], m3[:1], 'pytorch', KS, True, KW, SIGMA).getitem()
+    hc = similarity_map(sr[:1], m3[:1], 'cuda', KS, True, KW, SIGMA).getitem()
+    assert tuple(hp.shape) == (1, 3 * n, KS * KS) and tuple(hc.shape) == (1, n, KS * KS)
+    # channels that differ: the fused step does not apply, eager rows do
+    m3b = m3.clone()
+    m3b[0, 1] = 0
+    before = _Step.calls
+    run_loop("pytorch", sr, gt, m3b)
+    assert _Step.calls == before
+
+
+def test_handles_fall_back_to_tensors(lazy_on_cpu):
+    from ssl_amd.losses import KLDistanceLoss, L1Loss, LazySSG, similarity_map
+    sr, gt, mask = batch(2)
+    mk = lambda img, gen=True, m=mask: similarity_map(img[:1], m[:1], 'hip', KS, gen, KW, SIGMA).getitem()
+    h = mk(sr)
+    assert isinstance(h, LazySSG) and h._t is None and "deferred" in repr(h)
+    want = oracle_rows(sr[:1], mask[:1], 'ch0', KS, KW, SIGMA, 1e-10, True)
+    assert tuple(h.shape) == tuple(want.shape) and h._t is not None
+    for got in (h * 2.0, 2.0 * h, h + h, torch.exp(h).log() * 2, torch.stack([h, h]).sum(0)):
+        assert torch.allclose(got, 2 * want, atol=1e-6)
+    assert torch.equal(h[0, 1], want[0, 1]) and len(h) == 1
+    # a materialised handle inside torch.cat, or tensors mixed in: plain tensors come back
+    c = torch.cat([h, mk(gt)], dim=1)
+    assert isinstance(c, torch.Tensor) and c.shape[1] == 2 * want.shape[1]
+    assert isinstance(torch.cat([mk(sr), want], dim=1), torch.Tensor)
+    assert isinstance(torch.cat([mk(sr), mk(sr)], dim=0), torch.Tensor)      # (not the loop's dim)
+    # options outside the fused step
+    n0 = _Step.calls
+    a, b = mk(sr), mk(gt)
+    w = torch.ones_like(want)
+    assert abs(float(L1Loss(1.0)(a, b, weight=w)) - float((a.materialise() - b.materialise()).abs().mean())) < 1e-7
+    assert float(KLDistanceLoss(1.0, softmax=True)(mk(sr), mk(gt))) >= 0
+    assert float(L1Loss(1.0)(mk(sr), mk(gt, gen=False))) > 0          # settings differ between the sides
+    g2 = gt.clone().requires_grad_(True)
+    assert float(L1Loss(1.0)(mk(sr), mk(g2))) > 0                       # a target that wants a gradient
+    assert float(L1Loss(1.0)(mk(sr), want)) >= 0                        # tensor on one side
+    assert _Step.calls == n0
+    # F.l1_loss's own reductions and KL with another clamp: fused / not fused
+    assert abs(float(F.l1_loss(mk(sr), mk(gt))) - float((mk(sr).materialise() - mk(gt).materialise()).abs().mean())) < 1e-7
+    assert _Step.calls == n0 + 1
+    x, y = mk(sr), mk(gt)
+    F.kl_div(torch.clamp(input=x, min=1e-6).log(), torch.clamp(input=y, min=1e-6), reduction='mean')
+    assert _Step.calls == n0 + 1 and x._t is not None
+    # masks that differ between the two sides of a fused pair
+    m2 = mask.clone()
+    m2[0, 0, 0, 0] = 1 - m2[0, 0, 0, 0]
+    assert torch.isnan(L1Loss(1.0)(mk(sr), mk(gt, m=m2)))
+
+
+def test_reference_style_criteria_and_separate_upstream_gradients(lazy_on_cpu):
+    """The reference's own basic_loss.py call sequences (weighted_loss -> F.l1_loss(reduction='none') ->
+    weight_reduce_loss's .mean(); F.kl_div(torch.clamp(input=x, min=1e-10).log(), ...)) and two DIFFERENT incoming
+    gradients for the two criteria."""
+    from ssl_amd.losses import similarity_map
+    sr, gt, mask = batch(3, B=1)
+    x = sr.clone().requires_grad_(True)
+    a = torch.cat([similarity_map(x.clone(), mask.clone(), 'cuda', KS, True, KW, SIGMA).getitem()], dim=1)
+    b = torch.cat([similarity_map(gt.clone(), mask.clone(), 'cuda', KS, True, KW, SIGMA).getitem()], dim=1)
+    loss = F.l1_loss(a, b, reduction='none')
+    l1 = 3.0 * (loss.mean() if F._Reduction.get_enum('mean') == 1 else loss.sum())
+    kl = 0.25 * F.kl_div(torch.clamp(input=a, min=1e-10).log(), torch.clamp(input=b, min=1e-10), reduction='mean')
+    assert _Step.calls == 1 and a._t is None and b._t is None
+    (l1 + kl).backward()
+    m = mask.numpy()[:, 0].astype(np.uint8)
+    ref = orc.ssg_loss(sr.numpy().astype(np.float64), gt.numpy().astype(np.float64), m, KS, KW, SIGMA, 3.0, 0.25)
+    assert abs(float(l1) - ref["l1"]) <= 1e-6 * ref["l1"] and abs(float(kl) - ref["kl"]) <= 1e-6 * ref["kl"]
+    assert float((x.grad - torch.as_tensor(ref["grad"], dtype=torch.float32)).abs().max()) <= 1e-6 * np.abs(ref["grad"]).max()
