@@ -180,14 +180,14 @@ static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (k
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Waves per tile of the dense-tile backward (each takes a contiguous range of offset rows); SSG_BWD_QSPLIT
-// overrides it for experiments.
-static int bwd_qsplit() {
+// Waves per tile of the dense-tile backward (each takes a contiguous range of offset rows): by default chosen on the
+// device so that the launch fills the chip about once; SSG_BWD_QSPLIT fixes it for experiments.
+static int bwd_qsplit() {   // 0 = chosen on the device from the number of dense tiles (DenseBwdParams::qsplit)
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("SSG_BWD_QSPLIT");
-    v = e ? atoi(e) : 1;
-    if (v < 1) v = 1;
+    v = e ? atoi(e) : 0;
+    if (v < 0) v = 0;
     if (v > 25) v = 25;
   }
   return v;

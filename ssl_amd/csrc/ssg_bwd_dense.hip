@@ -188,7 +188,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   const int ty0 = (tr / tx_n) * TY, tx0 = (tr % tx_n) * TX;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
   const float gsc = grad_fix_scale(p.gfix, (size_t)p.B * C * H * W);
-  const int qy0 = (KS * (int)blockIdx.y) / p.qsplit, qy1 = (KS * ((int)blockIdx.y + 1)) / p.qsplit;
+  // offset rows of this wave: a fixed split, or (qsplit 0) one chosen from the tile count -- wave-uniform scalars
+  int qs = p.qsplit;
+  if (qs <= 0) {
+    const int want = p.auto_slots / (dense_tile_count(p.n_dense) * G::NHALF);
+    qs = want < 1 ? 1 : (want > (int)gridDim.y ? (int)gridDim.y : want);
+  }
+  if ((int)blockIdx.y >= qs) return;
+  const int qy0 = (KS * (int)blockIdx.y) / qs, qy1 = (KS * ((int)blockIdx.y + 1)) / qs;
 
   // ---- census of the tile's edge pixels (row-major inside the tile) ----
   int n_e = 0;
@@ -706,14 +713,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
 // ------------------------------------------------------------------ host ----
 bool dense_bwd_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }
 
+// qsplit 0: the grid carries this many offset-row parts per tile, the device uses 1 .. QSPLIT_AUTO_MAX of them
+constexpr int QSPLIT_AUTO_MAX = 5;
+
 template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM = false>
 static int launch_one(const DenseBwdParams &p, int n_tiles, hipStream_t st) {
   using G = DenseBwdGeo<KS, KW, C, TY, RG>;
   if (n_tiles <= 0) return 0;
   static std::atomic<unsigned long long> lds_set{0};
   if (const int rc = ensure_dynamic_lds(ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM>, (int)G::lds_bytes(), lds_set)) return rc;
-  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM>), dim3((unsigned)n_tiles, (unsigned)p.qsplit, G::NHALF),
-                     dim3(64), G::lds_bytes(), st, p);
+  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM>),
+                     dim3((unsigned)n_tiles, (unsigned)(p.qsplit > 0 ? p.qsplit : QSPLIT_AUTO_MAX), G::NHALF), dim3(64),
+                     G::lds_bytes(), st, p);
   return (int)hipGetLastError();
 }
 
@@ -721,6 +732,18 @@ int launch_bwd_dense(const DenseBwdParams &p0, int ks, int kw, int C, hipStream_
   if (!dense_bwd_supported(ks, kw, C)) return -1;
   if (p0.max_tiles == 0) return 0;
   DenseBwdParams p = p0;
+  if (p.qsplit <= 0) {   // wave slots of the device for this kernel: (25,9) 2 waves per SIMD, (49,13) one
+    static std::atomic<int> cus{0};
+    int n = cus.load(std::memory_order_relaxed);
+    if (n <= 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
+      cus.store(n, std::memory_order_relaxed);
+    }
+    p.qsplit = 0;
+    p.auto_slots = n * 4 * (ks == 49 ? 1 : 2);
+  }
   // 4 x 32 tiles: at most 128 edge pixels.  One wave per tile: the two-waves-per-tile layout (RG = 8, 48 padded
   // columns, prefix rows through LDS) was measured slower here, 3.16 vs 2.27 ms at C5 -- with 4 tile rows each half
   // repeats a W stage that is most of its work.  With a tile-major region (fused step) both variants are launched

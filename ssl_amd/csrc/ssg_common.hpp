@@ -383,7 +383,11 @@ struct DenseBwdParams {
   const int *n_dev;    // rows computed at all (capacity clamp), nullable
   int n_host;
   int B, H, W;
-  int qsplit;          // waves per tile, each taking a contiguous range of offset rows
+  int qsplit;          // waves per tile, each taking a contiguous range of offset rows; 0 = chosen on the device from
+                       // the number of dense tiles so that the launch fills the chip's wave slots about once (a wave's
+                       // sweep of all k_s^2 offsets takes 0.2-0.3 ms however few tiles there are: sparse / strided
+                       // masks -- BASELINE's C4 has 183 tiles -- would leave 80 % of the chip idle for that long)
+  int auto_slots;      // qsplit == 0: wave slots of the device for this kernel (CUs x SIMDs x waves per SIMD)
   int dbg;
   // tile-major rows (TmRowsParams), when tm_active(): the TM variant forms G = -(s k)(g - dot) itself from the two e
   // rows, the row scales and ssg_rows_tm's dot; otherwise the other variant reads the row-major G rows
