@@ -52,9 +52,19 @@ typedef void *ssg_stream_t; /* hipStream_t */
 #define SSG_E_TOOLARGE (-2)   /* search tile does not fit the 160 KiB LDS of a CU               */
 #define SSG_E_WORKSPACE (-3)  /* caller's workspace is smaller than ssg_loss_workspace_bytes()   */
 #define SSG_E_IMAGESMALL (-4) /* H or W <= k_s/2: reflect padding undefined (torch raises too)   */
+#define SSG_E_ALIGN (-5)      /* fused step: workspace / grad_fix / grad_sr not 16-byte aligned      */
+#define SSG_E_PLAN (-6)       /* ssg_device_status(): a plan cut for another tile height was used   */
 
 int ssg_abi_version(void);
 const char *ssg_status_string(int status);
+/* Device-side refusals that no return value can carry (everything is asynchronous): waits for `stream`, then returns
+ * SSG_E_PLAN if, since the last call, a dense-tile kernel of ssg_map_forward / ssg_map_backward / ssg_loss_backward was
+ * handed a fwd_plan cut for another tile height than its k_s uses (ssg_edge_list's plan_ks: 8-row tiles for k_s <= 25,
+ * 4-row tiles for k_s = 49) -- such a launch leaves its rows / gradient untouched instead of decoding tile ids with
+ * the wrong geometry -- else 0.  Clears the word.  The status word (4 bytes per device) is the one thing the library
+ * allocates, at the first forward / backward call that takes a plan.  ssg_loss_fwd_bwd / ssg_loss_step build their own
+ * plan and cannot set it. */
+int ssg_device_status(ssg_stream_t stream);
 
 /* ---------------------------------------------------------------- (A) ----
  * Reference operator, same argument meaning as similarity.h:2-11 plus a
@@ -135,9 +145,9 @@ int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int plan_ks /* k_s the fwd_plan is built for (tile rows: 8, or 4 for k_s = 49); 0 = 25.
                                * CONSTRAINT: a plan is only valid for calls whose k_s uses the same tile height --
                                * the plan records it (fwd_plan[2]) and the dense kernels of ssg_map_forward /
-                               * ssg_map_backward / ssg_loss_backward trap (launch failure at the next sync)
-                               * when it differs from theirs, instead of decoding tile ids with the wrong
-                               * geometry.  ssg_loss_fwd_bwd builds its own plan and cannot get this wrong. */,
+                               * ssg_map_backward / ssg_loss_backward do NOTHING when it differs from theirs
+                               * (ssg_device_status() then returns SSG_E_PLAN), instead of decoding tile ids with
+                               * the wrong geometry.  ssg_loss_fwd_bwd builds its own plan and cannot get this wrong. */,
                   int *edges, int capacity, int *counts,
                   int *rank_map /* nullable */, int *tile_order /* nullable */,
                   int *fwd_plan /* nullable */, void *scratch,
@@ -238,6 +248,11 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
  * SSG(sr), SSG(gt), both criteria and the gradient.  ssg_sr / ssg_gt
  * (capacity, k_s*k_s) receive the SSG tensors; `counts` as in ssg_edge_list;
  * workspace >= ssg_loss_workspace_bytes(B,H,W,capacity,ks).
+ * ALIGNMENT: `workspace`, `grad_fix` and `grad_sr` must be 16-byte aligned (SSG_E_ALIGN otherwise): the edge-list
+ * builder's first kernel clears the row scales, the fixed-point sums and (ssg_loss_step) the gradient with 16-byte
+ * stores.  Fresh allocations are; an offset view into a larger buffer has to keep the alignment.
+ * OVERFLOW: counts[0] > capacity means the step has used the first `capacity` edge pixels only; loss_out is then
+ * {NaN, NaN}, so that a truncated step cannot pass for a complete one (grad_sr holds the truncated step's gradient).
  *
  * Fused step, no SSG output (SURVEY 8d's B_alg' mode): ssg_sr == ssg_gt == NULL.  The rows then live in the
  * workspace, which must hold ssg_loss_workspace_bytes(...) + ssg_loss_rows_bytes(capacity, ks); the dense-tile

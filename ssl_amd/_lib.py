@@ -64,6 +64,7 @@ PROTOTYPES = {
     "ssg_ref_compute_similarity": (None, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "ssg_ref_compute_similarity_backward": (None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "ssg_last_status": (_i, []),
+    "ssg_device_status": (_i, [_vp]),
 }
 PROF_PROTOTYPES = {"ssg_set_profile_mask": (_i, [_i])}   # libssg_hip_prof.so only
 # C++-linkage symbols of include/similarity.h (Itanium mangling of the reference's declarations, similarity.h:2-23)

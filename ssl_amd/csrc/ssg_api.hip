@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "ssg_common.hpp"
 
@@ -14,7 +15,7 @@ int launch_bwd(const BwdParams &p, hipStream_t st);
 unsigned bwd_grid(const BwdParams &p);
 size_t bwd_max_partials(int B, int H, int W, int n_rows);
 int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
-                         float w_kl, float *loss_out, hipStream_t st);
+                         float w_kl, float *loss_out, int nan_on_overflow, hipStream_t st);
 const char *fwd_kernel_name(int ks, int kw);
 const char *bwd_kernel_name(int ks, int kw);
 size_t edge_scratch_bytes(int B, int H, int W);
@@ -44,6 +45,7 @@ struct DenseParams {
   int grid_tiles;
   const int *strips;
   int max_strips;
+  int *status;
 };
 int fwd_plan_strip_offset(int B, int H, int W);
 int dense_max_strips(int B, int H, int W, int ks);
@@ -176,6 +178,28 @@ static int join_to(hipStream_t st, SideStream *s) {
   return rc;
 }
 
+// One 4-byte status word per device, owned by the library (allocated at the first call that can set it, never freed):
+// kernels that refuse their input without a host-visible error -- a dense kernel handed a plan cut for another tile
+// height -- set a bit in it; ssg_device_status() reads and clears it.
+static int *device_status_word() {
+  constexpr int MAXDEV = 64;
+  static std::mutex mu;
+  static int *tab[MAXDEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tab[dev]) {
+    int *w = nullptr;
+    if (hipMalloc(&w, sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(w, 0, sizeof(int)) != hipSuccess) {
+      (void)hipFree(w);
+      return nullptr;
+    }
+    tab[dev] = w;
+  }
+  return tab[dev];
+}
+
 static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (kw & 1) && kw <= ks; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -234,6 +258,7 @@ struct FinalizeArgs {
   int n_host, P;
   float w_l1, w_kl;
   float *loss_out;
+  int nan_on_overflow;
 };
 
 // nparts of a split backward's criteria sums: ssg_grad_rows' workgroups, then ssg_rows_tm's
@@ -330,6 +355,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   d.W = p.W;
   d.qsplit = bwd_qsplit();
   d.dbg = p.dbg;
+  d.status = device_status_word();
   if (n_tm > 0) {
     d.tm[0] = tm->rows[0];
     d.tm[1] = tm->rows[1];
@@ -345,7 +371,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   hipStream_t st2 = (dbg_mask() & ((1 << 27) | (1 << 28))) ? st : fork_from(st, p.ks, fk);
   if (fin && fk && st2 != st) {   // (only when there IS a side stream: on one stream it would only delay the backward)
     rc = launch_loss_finalize(fin->partials, fin->nparts, fin->n_dev, fin->n_host, fin->P, fin->w_l1, fin->w_kl,
-                              fin->loss_out, st2);
+                              fin->loss_out, fin->nan_on_overflow, st2);
     if (rc) return rc;
     if (fin_done) *fin_done = true;
   }
@@ -392,6 +418,8 @@ const char *ssg_status_string(int status) {
     case SSG_E_TOOLARGE: return "ssg: search tile does not fit the 160 KiB LDS of a CU";
     case SSG_E_WORKSPACE: return "ssg: workspace too small";
     case SSG_E_IMAGESMALL: return "ssg: image side <= k_s/2, reflect padding undefined";
+    case SSG_E_ALIGN: return "ssg: workspace / grad_fix / grad_sr of the fused step must be 16-byte aligned";
+    case SSG_E_PLAN: return "ssg: a dense kernel was handed a plan cut for another tile height (k_s 25 vs 49); that launch did nothing";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "ssg: unknown status";
   }
 }
@@ -533,6 +561,7 @@ static int map_forward_impl(const float *img, const float *img2, int B, int C, i
     d.generalization = generalization;
     d.dbg = (dbg_mask() >> 16) & 0xff;
     d.row_scale = row_scale;
+    d.status = device_status_word();
     if (tm && tm->slots > 0 && row_scale && img2) {
       d.tm[0] = tm->rows[0];
       d.tm[1] = tm->rows[1];
@@ -621,7 +650,7 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
                          float sigma, int generalization, float *ssg_sr, float *ssg_gt, float w_l1, float w_kl,
                          const float *upstream, float *loss_out, float *grad_sr, void *scratch, void *grad_fix,
                          const double *row_scale, bool rows_scratch, bool fix_zeroed, bool grad_is_output,
-                         ssg_stream_t stream, const TileMajor *tm = nullptr) {
+                         ssg_stream_t stream, const TileMajor *tm = nullptr, bool nan_on_overflow = false) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
@@ -660,7 +689,7 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   bool fin_done = false;
   if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
     nparts = (int)grow_grid(n_rows) + split_tm_tiles(p, tm);
-    const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out};
+    const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0};
     rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done, tm);
   } else {
     if (p.gfix) rc = launch_grad_fix_bound(p, st);
@@ -669,7 +698,7 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   }
   if (!rc) rc = det_end(p, st, grad_is_output);
   if (rc || fin_done) return rc;
-  return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, st);
+  return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0, st);
 }
 
 int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *tile_order,
@@ -765,6 +794,9 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   const bool fused = ssg_sr == nullptr;
   const size_t base_bytes = ssg_loss_workspace_bytes(B, H, W, capacity, ks);
   if (workspace_bytes < base_bytes + (fused ? ssg_loss_rows_bytes(capacity, ks) : 0)) return SSG_E_WORKSPACE;
+  // the edge-list builder's first kernel clears the row scales, the fixed-point sums and (ssg_loss_step) the gradient
+  // with 16-byte stores: offset views of a larger buffer must keep that alignment (include/ssg_hip.h)
+  if ((((uintptr_t)workspace) | ((uintptr_t)grad_fix) | ((uintptr_t)grad_sr)) & 15) return SSG_E_ALIGN;
   const LossWorkspace lw = carve_workspace(B, H, W, capacity, ks, fused);
   char *ws = (char *)workspace;
   TileMajor tm;
@@ -812,7 +844,7 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   if (rc) return rc;
   return loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
                        ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix,
-                       defer ? row_scale : nullptr, fused, zero_fix, grad_is_output && zero_fix, stream, &tm);
+                       defer ? row_scale : nullptr, fused, zero_fix, grad_is_output && zero_fix, stream, &tm, true);
 }
 
 int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,
@@ -876,6 +908,17 @@ int ssg_diffjpeg(const float *img, float *out, int B, int H, int W, const float 
   if (B == 0) return 0;
   if (!img || !out || (!quality_dev && !(quality > 0.f))) return SSG_E_BADARG;
   return launch_jpeg(img, out, B, H, W, quality_dev, quality, (hipStream_t)stream);
+}
+
+int ssg_device_status(ssg_stream_t stream) {
+  int *w = device_status_word();
+  if (!w) return 0;
+  int v = 0;
+  int rc = (int)hipMemcpyAsync(&v, w, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (!rc && v) rc = (int)hipMemsetAsync(w, 0, sizeof(int), (hipStream_t)stream);
+  if (!rc) rc = (int)hipStreamSynchronize((hipStream_t)stream);
+  if (rc) return rc;
+  return (v & 1) ? SSG_E_PLAN : 0;
 }
 
 const char *ssg_kernel_name(int ks, int kw, int backward) {

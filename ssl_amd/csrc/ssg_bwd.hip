@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
 // loss_out[0] = w_l1 * sum|a-b| / M, loss_out[1] = w_kl * sum t'(log t' - log s') / M.
 // One workgroup, fp64, fixed summation order (lane-strided partial sums, then lane order).
 __global__ __launch_bounds__(1024) void ssg_loss_finalize(const float *partials, int nparts, const int *n_dev,
-                                                          int n_host, int P, float w_l1, float w_kl, float *loss_out) {
+                                                          int n_host, int P, float w_l1, float w_kl, float *loss_out,
+                                                          int nan_on_overflow) {
   __shared__ double s1[1024], s2[1024];
   const float2 *pp = (const float2 *)partials;
   double a = 0, b = 0;
@@ -679,6 +680,9 @@ __global__ __launch_bounds__(1024) void ssg_loss_finalize(const float *partials,
     const double M = (double)nrows * (double)P;
     loss_out[0] = nrows > 0 ? (float)((double)w_l1 * s1[0] / M) : 0.f;
     loss_out[1] = nrows > 0 ? (float)((double)w_kl * s2[0] / M) : 0.f;
+    // the fused entry points: a step that found more edge pixels than the caller's capacity has used the first
+    // `capacity` of them only -- its losses are NaN, so that a truncated step cannot pass for a complete one
+    if (nan_on_overflow && n_dev && *n_dev > n_host) loss_out[0] = loss_out[1] = __builtin_nanf("");
   }
 }
 
@@ -813,9 +817,9 @@ int launch_bwd(const BwdParams &p, hipStream_t st) {
 }
 
 int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
-                         float w_kl, float *loss_out, hipStream_t st) {
+                         float w_kl, float *loss_out, int nan_on_overflow, hipStream_t st) {
   hipLaunchKernelGGL(ssg_loss_finalize, dim3(1), dim3(1024), 0, st, partials, nparts, n_dev, n_host, P, w_l1, w_kl,
-                     loss_out);
+                     loss_out, nan_on_overflow);
   return (int)hipGetLastError();
 }
 

@@ -180,7 +180,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   if (tslot >= dense_tile_count(p.n_dense)) return;
   if (p.tm_slots > 0 && tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host)) != TM) return;
   if (TM && p.tm_slots <= 0) return;
-  if (p.n_dense[1] != TY) __builtin_trap();   // plan cut for another tile height (see ssg_fwd_dense)
+  if (p.n_dense[1] != TY) {   // plan cut for another tile height (see ssg_fwd_dense): nothing is done, the status word says so
+    if (p.status && lane == 0) atomicOr(p.status, 1);
+    return;
+  }
   const int H = p.H, W = p.W;
   const int tx_n = (W + TX - 1) / TX, ty_n = (H + TY - 1) / TY;
   const int tile = dense_tile_id(dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot));

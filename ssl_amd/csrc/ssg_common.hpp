@@ -397,6 +397,7 @@ struct DenseBwdParams {
   int tm_slots;
   float sigma, w_l1, w_kl;
   const float *upstream;
+  int *status;         // nullable: library-owned device status word (ssg_device_status)
 };
 
 __device__ __forceinline__ int rows_to_do(const int *n_dev, int n_host) {

@@ -119,6 +119,7 @@ struct DenseParams {
   int grid_tiles;  // plan slots this launch covers (per image)
   const int *strips;  // k_s 49 tile-major calls: [0] number of strips, then (strip id, first slot) pairs; nullable
   int max_strips;     // launch bound per image
+  int *status;        // nullable: library-owned device status word (ssg_device_status): bit 0 = plan of another tile height
 };
 
 constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1) (8 for k_w = 9, 4 for k_w = 13)
@@ -187,9 +188,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if (p.tm_slots > 0 && tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host)) != TM) return;
   if (TM && p.tm_slots <= 0) return;
   // the plan records the tile height it was cut for (ssg_edge_list's plan_ks): walking an 8-row plan with 4-row
-  // tiles (or the reverse) would decode garbage tile ids -- stop loudly instead (the Python host raises before
-  // it gets here, engine.check_plan)
-  if (p.n_dense[1] != DT_Y) __builtin_trap();
+  // tiles (or the reverse) would decode garbage tile ids -- leave, and say so in the device status word (the Python
+  // host raises before it gets here, engine.check_plan; C callers ask ssg_device_status())
+  if (p.n_dense[1] != DT_Y) {   // (the launch does nothing; ssg_device_status() reports SSG_E_PLAN)
+    if (p.status && tid == 0) atomicOr(p.status, 1);
+    return;
+  }
   const int H = p.H, W = p.W;
   const int tx_n = (W + DT_X - 1) / DT_X, ty_n = (H + DT_Y - 1) / DT_Y;
   const int listed = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);

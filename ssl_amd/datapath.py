@@ -272,11 +272,26 @@ class Draws:
     def jpeg_quality(self, n, lo, hi, device):          # out.new_zeros(b).uniform_(lo, hi)
         return torch.zeros(n, dtype=torch.float32, device=device).uniform_(lo, hi)
 
-    def any_gray(self, gray):
+    def any_gray(self, gray, channels=3, gray_prob=None):
         """Whether a gray-noise field has to be drawn.  The reference asks `torch.sum(gray_noise) > 0` on the host (a
-        device synchronisation per noise stage, degradations.py:479,619); here the field is always drawn -- it is
-        multiplied by gray = 0 where unused -- so the pipeline never waits for the device."""
+        device synchronisation per noise stage, degradations.py:479,619); here the answer comes from what the host
+        already knows: never for images that are not 3-channel (the gray blend is defined for RGB; the reference runs
+        1-channel input with gray_prob = 0) or when gray_prob == 0, otherwise always -- the field is multiplied by
+        gray = 0 where unused, so the pipeline never waits for the device.  Consequence for seeded runs: with
+        gray_prob > 0 the gray field is drawn even when no sample of the batch turned out gray, so torch's generator
+        stream advances differently from a seeded reference run from that stage on (`ReferenceOrderDraws` below pays
+        the synchronisation and keeps the reference's order)."""
+        if channels != 3 or (gray_prob is not None and gray_prob <= 0):
+            return False
         return True
+
+
+class ReferenceOrderDraws(Draws):
+    """Draws that ask the device, like the reference does, whether any sample has gray noise before drawing the gray
+    field (one host synchronisation per noise stage): the generator stream then matches a seeded reference run."""
+
+    def any_gray(self, gray, channels=3, gray_prob=None):
+        return channels == 3 and bool(torch.sum(gray) > 0)
 
 
 @torch.no_grad()
@@ -332,17 +347,17 @@ def random_add_gaussian_noise(img, sigma_range, gray_prob, draws, clip=True, rou
     B, C, H, W = img.shape
     sigma = draws.rand(B, img.device) * (sigma_range[1] - sigma_range[0]) + sigma_range[0]
     gray = (draws.rand(B, img.device) < gray_prob).float()
-    fg = draws.randn((H, W), img.device) if draws.any_gray(gray) else None
+    fg = draws.randn((H, W), img.device) if draws.any_gray(gray, C, gray_prob) else None
     fc = draws.randn((B, C, H, W), img.device)
     return add_gaussian_noise(img, sigma, gray, fc, fg, clip, rounds)
 
 
 def random_add_poisson_noise(img, scale_range, gray_prob, draws, clip=True, rounds=False):
     """random_add_poisson_noise_pt (degradations.py:706-720)."""
-    B = img.shape[0]
+    B, C = img.shape[0], img.shape[1]
     scale = draws.rand(B, img.device) * (scale_range[1] - scale_range[0]) + scale_range[0]
     gray = (draws.rand(B, img.device) < gray_prob).float()
-    with_gray = draws.any_gray(gray)
+    with_gray = draws.any_gray(gray, C, gray_prob)
     rate, rate_gray, vals = poisson_rates(img, with_gray)
     dg = draws.poisson(rate_gray) if with_gray else None
     dc = draws.poisson(rate)

@@ -350,6 +350,12 @@ class LossStep:
     This is the path bench.py times.  No host synchronisation happens inside; `counts[0]`
     (device) holds the edge-pixel count N of the last step, `loss` the two scalars.
 
+    Memory (k_s = 49): besides the two SSG tensors (2 x capacity x k_s^2 x 4 bytes) a materialising step holds the two
+    TILE-MAJOR regions the dense kernels work in (ssg_loss_tm_bytes: about the same again -- +5 GB at capacity 512 x 512),
+    the fused step (materialise=False) four row regions in its workspace instead of two.  tile_major=False leaves the
+    regions out of a materialising step's workspace: the row-major kernels run (C5: 8.4 instead of 7.3 ms per step).
+    A step that finds more edge pixels than `capacity` returns NaN losses (it has used the first `capacity` only).
+
     graph=True records the step's ~17 launches (memset, edge-list builder, two forward variants,
     backward, finalize) into a HIP graph on first use and replays it afterwards: nothing in the
     step depends on host-side values (the edge count stays on the device), so the recording is
@@ -358,7 +364,7 @@ class LossStep:
 
     def __init__(self, B, C, H, W, ks=25, kw=9, sigma=0.004, eps=1e-10, generalization=True, w_l1=1.0, w_kl=1.0,
                  mask_stride=0, lap_threshold=20.0, capacity=None, device="cuda", graph=False, deterministic=None,
-                 materialise=True):
+                 materialise=True, tile_major=True):
         L = _lib.lib()
         self.shape = (B, C, H, W)
         self.cfg = (ks, kw, float(sigma), float(eps), int(bool(generalization)), float(w_l1), float(w_kl),
@@ -375,7 +381,7 @@ class LossStep:
         self.ws_bytes = L.ssg_loss_workspace_bytes(B, H, W, self.capacity, ks)
         if not materialise:
             self.ws_bytes += L.ssg_loss_rows_bytes(self.capacity, ks)
-        else:   # (k_s 49: room for the tile-major regions, which a materialising call then uses as well; 0 otherwise)
+        elif tile_major:   # (k_s 49: room for the tile-major regions, which a materialising call then uses as well; 0 otherwise)
             self.ws_bytes += L.ssg_loss_tm_bytes(self.capacity, ks)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.fix = _grad_fix(deterministic, self.grad)   # deterministic mode: fixed-point accumulation buffer

@@ -72,7 +72,9 @@ class SSGLoss(nn.Module):
 
     Memory: one call holds 2 * capacity * k_s^2 * 4 bytes of SSG rows (+ the same again / 2 of
     backward scratch) while it runs -- 0.5 GB per 100 k edge pixels at k_s = 25 -- and keeps only
-    the (B,C,H,W) gradient for backward.  `capacity` bounds the number of edge pixels of a call
+    the (B,C,H,W) gradient for backward.  At k_s = 49 the workspace holds FOUR row regions (two
+    row-major, two tile-major: ssg_loss_rows_bytes in include/ssg_hip.h): 4 * capacity * 2401 * 4
+    bytes = 10 GB at capacity 512 x 512; size `capacity` accordingly for dense masks at that size.  `capacity` bounds the number of edge pixels of a call
     without a host round trip.  Default (capacity=None): a quarter of the call's pixels (edge masks
     are ~7 % dense; computed per call, so a small first batch does not pin it) or the largest count
     seen so far plus 1/8, whichever is larger.  DENSE masks (mask_stride patterns over textured
@@ -84,9 +86,11 @@ class SSGLoss(nn.Module):
         RuntimeError is raised (on_overflow='raise');
       * later calls copy their count to pinned host memory asynchronously; it is looked at one or
         more calls later, so nothing stalls.  A call that overflowed then HAS used only the first
-        `capacity` edge pixels in batch order: every such call is reported (warning / RuntimeError),
-        the capacity grows, and the next call is checked synchronously.  `flush()` waits for the
-        outstanding counts (call it after the last / a single forward, e.g. in validation).
+        `capacity` edge pixels in batch order: its two losses are NaN (set on the device by the step
+        itself: a truncated step never passes for a complete one), every such call is reported
+        (warning / RuntimeError), the capacity grows, and the next call is checked synchronously.
+        `flush()` waits for the outstanding counts (call it after the last / a single forward, e.g.
+        in validation); switching the module to eval() and its deletion do so too.
 
     deterministic=True makes the gradient bit-reproducible from run to run (fixed-point integer
     accumulation instead of fp32 atomics; include/ssg_hip.h `ssg_grad_fix_bytes`).
@@ -153,6 +157,18 @@ class SSGLoss(nn.Module):
     def flush(self):
         """Wait for the outstanding edge counts and report any overflow (after the last or a single forward)."""
         self._check_previous(wait=True)
+
+    def train(self, mode=True):
+        if not mode and self._pending:      # leaving training: nothing may stay unreported
+            self.flush()
+        return super().train(mode)
+
+    def __del__(self):
+        try:
+            if self._pending:
+                self.flush()
+        except Exception:                   # (interpreter shutdown, 'raise' mode inside a finaliser)
+            pass
 
     def _run(self, sr, gt, mask, cap):
         B = sr.shape[0]

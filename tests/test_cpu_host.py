@@ -269,6 +269,10 @@ def test_argument_checks_need_no_gpu():
                              None, None) == -1
     assert L.ssg_loss_fwd_bwd(one, one, one, 0, 1, 1, 3, 40, 40, 25, 9, 1.0, 1e-10, 1, 1.0, 1.0, 0, 20.0, 100, one, one,
                               one, one, one, one, 16, None, None) == -3
+    # fused step: workspace / grad_fix / grad_sr must be 16-byte aligned (its clears are 16-byte stores): SSG_E_ALIGN
+    assert L.ssg_loss_fwd_bwd(one, one, one, 0, 1, 1, 3, 40, 40, 25, 9, 1.0, 1e-10, 1, 1.0, 1.0, 0, 20.0, 100, one, one,
+                              one, one, one, one, 1 << 40, None, None) == -5
+    assert b"aligned" in L.ssg_status_string(-5) and b"plan" in L.ssg_status_string(-6)
     assert L.ssg_augment_crop(one, one, 2, 1, 3, 8, 8, 4, 4, one, None) == -1            # element size 2
     assert L.ssg_grad_fix_bytes(2, 3, 16, 16) == 8 * (2 * 3 * 16 * 16 + 8)
     assert L.ssg_backward_scratch_bytes(100, 25) >= 100 * 625 * 4

@@ -1739,7 +1739,7 @@ class _Replay:
     def jpeg_quality(self, n, lo, hi, device):
         return T(self.rec.pop("jpeg_q"), self.dev)
 
-    def any_gray(self, gray):
+    def any_gray(self, gray, channels=3, gray_prob=None):
         return bool(gray.sum() > 0)      # (the recorded run drew the gray field only then, like the reference)
 
 
@@ -1808,6 +1808,15 @@ def test_degradation_production_draws_shapes_and_ranges(dev):
             assert out["gt_mask"].shape == (B, 1, 64, 64) and out["gt_mask"].dtype == torch.uint8
             assert float(lq.min()) >= 0 and float(lq.max()) <= 1 and bool(torch.isfinite(lq).all())
             assert float((lq * 255 - (lq * 255).round()).abs().max()) < 1e-3
+    # 1-channel input / gray_prob 0 (the reference's gray-scale configurations): no gray field is requested, the
+    # noise stages run (the Poisson stage returned SSG_E_BADARG for C != 3 when it was always asked for a gray rate)
+    g1 = T(gt[:, :1], dev)
+    d = datapath.Draws()
+    assert not d.any_gray(None, channels=1, gray_prob=0.4) and not d.any_gray(None, channels=3, gray_prob=0.0)
+    for fn, rng_ in ((datapath.random_add_gaussian_noise, [1, 30]), (datapath.random_add_poisson_noise, [0.05, 3])):
+        o = fn(g1, rng_, 0.0, d, clip=True, rounds=False)
+        assert o.shape == g1.shape and bool(torch.isfinite(o).all()) and float((o - g1).abs().max()) > 0
+    assert isinstance(datapath.ReferenceOrderDraws().any_gray(torch.zeros(2, device=dev)), bool)
 
 
 @pytest.mark.parametrize("det", [True, False])
@@ -1846,3 +1855,64 @@ def test_loss_step_gradient_is_an_output(dev, det):
             assert np.abs(out["acc"][1] - out["out"][1]).max() <= 1e-6 * max(np.abs(out["acc"][1]).max(), 1e-30)
         if dens == 0.0:
             assert not out["out"][1].any() and not out["out"][0].any()
+
+
+def test_c_abi_refusals_plan_height_overflow_and_alignment(dev):
+    """What a direct C-ABI caller gets instead of a crash or a silently wrong number: (1) a plan cut for 8-row tiles
+    handed to the k_s = 49 kernels -- the dense launches do nothing, ssg_device_status() returns SSG_E_PLAN once (the
+    kernels used to trap and take the HIP context with them); (2) a fused step whose capacity is smaller than its edge
+    count returns NaN losses; (3) misaligned workspace / gradient views are SSG_E_ALIGN."""
+    from ssl_amd import _lib, engine, synth
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.ssg_device_status(st) == 0
+    B, H, W = 1, 64, 96
+    gt = synth.natural_like(4100, H, W)[None]
+    img = T(gt, dev)
+    mask = torch.ones(B, 1, H, W, device=dev)
+    el = engine.edge_list(mask=mask, ks=25)                      # 8-row tiles
+    n = B * H * W
+    ssg = torch.full((n, 49 * 49), -7.0, device=dev)
+    rc = L.ssg_map_forward(img.data_ptr(), None, B, 3, H, W, el.edges.data_ptr(), el.order.data_ptr(), el.rank.data_ptr(),
+                           el.plan.data_ptr(), el.counts.data_ptr(), n, 49, 13, 1.0, 1e-10, 1, ssg.data_ptr(), None, None, st)
+    assert rc == 0
+    assert L.ssg_device_status(st) == -6 and L.ssg_device_status(st) == 0      # reported once, then cleared
+    torch.cuda.synchronize()                                                    # the context is alive
+    dense_rows = el.rank[0, :8, :32].reshape(-1).long()                        # a tile the plan lists as dense
+    assert bool((ssg[dense_rows] == -7.0).all())                                # its rows were left alone
+    # (2) overflow -> NaN losses, counts[0] still reports N
+    sr_np, gt_np, m_np = synth.make_batch(1, 64, 64, seed0=4200)
+    n_edges = int(m_np.sum())
+    step = engine.LossStep(1, 3, 64, 64, 11, 5, 0.5, device=dev, capacity=n_edges // 2)
+    loss, _ = step(T(sr_np, dev), T(gt_np, dev), T(m_np, dev))
+    assert int(step.counts[0]) == n_edges and bool(torch.isnan(loss).all())
+    step = engine.LossStep(1, 3, 64, 64, 11, 5, 0.5, device=dev, capacity=n_edges)
+    loss, _ = step(T(sr_np, dev), T(gt_np, dev), T(m_np, dev))
+    assert bool(torch.isfinite(loss).all())
+    # (3) alignment of the fused step's buffers
+    ws = torch.empty(step.ws_bytes + 64, dtype=torch.uint8, device=dev)
+    args = lambda wsp, gp: (T(sr_np, dev).data_ptr(), T(gt_np, dev).data_ptr(), T(m_np, dev).data_ptr(), 0, 1, 1, 3, 64, 64,
+                            11, 5, 0.5, 1e-10, 1, 1.0, 1.0, 0, 20.0, n_edges, step.ssg_sr.data_ptr(),
+                            step.ssg_gt.data_ptr(), step.counts.data_ptr(), step.loss.data_ptr(), gp, wsp, step.ws_bytes,
+                            None, st)
+    assert L.ssg_loss_step(*args(ws.data_ptr() + 4, step.grad.data_ptr())) == -5
+    assert L.ssg_loss_step(*args(ws.data_ptr(), step.grad.data_ptr() + 4)) == -5
+    assert L.ssg_loss_step(*args(ws.data_ptr() + 16, step.grad.data_ptr())) == 0
+    torch.cuda.synchronize()
+
+
+def test_k49_materialising_step_without_tile_major_regions(dev):
+    """LossStep(tile_major=False): the k_s = 49 materialising step without the two extra regions in its workspace runs
+    the row-major kernels; same losses (2e-6) and gradient (1e-4 of its maximum, see the tile-major tests) as the default."""
+    from ssl_amd import engine, synth
+    gt = synth.natural_like(4300, 64, 96)[None]
+    sr = synth.degrade(gt[0], 4301)[None]
+    mask = np.ones((1, 1, 64, 96), np.float32)
+    res = []
+    for tm in (True, False):
+        step = engine.LossStep(1, 3, 64, 96, 49, 13, 1.0, device=dev, tile_major=tm)
+        loss, grad = step(T(sr, dev), T(gt, dev), T(mask, dev))
+        res.append((loss.clone(), grad.clone(), step.ws_bytes))
+    assert res[1][2] < res[0][2]
+    assert float((res[0][0] - res[1][0]).abs().max() / res[1][0].abs().max()) <= 5e-6
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-4 * float(res[1][1].abs().max())
