@@ -1,7 +1,7 @@
 """profiles/r*_pmc_summary.txt (per-dispatch counter means written by tools/r*_final.sh) -> profiles/pmc_traffic.json:
 HBM bytes, issued VALU wave-instructions and LDS-active cycles per launch of every SSG kernel.
 
-    python tools/pmc_to_json.py [profiles/r3_pmc_summary.txt]
+    python tools/pmc_to_json.py [profiles/r4_pmc_summary.txt]
 
 Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): rocprofv3 reports FETCH_SIZE /
 WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts 128-byte read requests as 64 bytes for wide coalesced streams (x2);
@@ -9,9 +9,9 @@ that factor is uncalibrated for narrow / scattered reads, so the raw figures are
 `hbm_bytes_per_launch` = raw_write + 2 * raw_fetch, an upper bound for the scattered tile fills."""
 import collections, json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "profiles", "r3_pmc_summary.txt")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "profiles", "r4_pmc_summary.txt")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, --kernel-trace only, "
-                 "SSG_OVERLAP=0) over bench.py --config {c2,c5} --steps 3 (tools/r3_final.sh -> " + os.path.relpath(src, root) +
+                 "SSG_OVERLAP=0) over bench.py --config {c2,c4,c5} --steps 3 (tools/r4_final.sh -> " + os.path.relpath(src, root) +
                  ", per-dispatch means); units and gfx950 corrections per MI355X_MICROARCH.md (HBM section): counters "
                  "are KiB, FETCH_SIZE counts 128-byte read requests as 64 bytes for wide coalesced streams (x2; an upper "
                  "bound for scattered reads), WRITE_SIZE is uncalibrated for partial-line stores",
@@ -28,7 +28,7 @@ for line in open(src):
     vals[(cfg, name)].update((k, float(v)) for k, v in re.findall(r"([A-Z_]+)=([0-9.e+-]+)", line))
 for (cfg, name), d in vals.items():
     fetch, write = d.get("FETCH_SIZE", 0) * 1024, d.get("WRITE_SIZE", 0) * 1024
-    out["kernels"][name if cfg != "c5f" or name not in out["kernels"] else name + "@c5f"] = {"config": cfg, "fetch_bytes_raw": fetch, "write_bytes_raw": write,
+    out["kernels"][name if name not in out["kernels"] else name + "@" + cfg] = {"config": cfg, "fetch_bytes_raw": fetch, "write_bytes_raw": write,
                             "hbm_bytes_per_launch": write + 2 * fetch,
                             "valu_insts_per_launch": d.get("SQ_INSTS_VALU", 0.0),            # wave-instructions
                             "lds_active_cycles_per_launch": d.get("SQ_LDS_IDX_ACTIVE", 0.0),   # summed over the CUs
