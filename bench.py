@@ -131,6 +131,18 @@ def spawn_ranks(args):
         raise SystemExit(f"bench ranks exited with {rcs}")
 
 
+def gpu_clock():
+    """Shader clock as rocm-smi reports it right after the timed region (string, or None without the tool)."""
+    try:
+        out = subprocess.run(["rocm-smi", "-c"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            if "sclk" in line.lower():
+                return line.split(":", 1)[-1].strip() if "GPU[0]" in line else line.strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return None
+
+
 def event_time_ms(fn, iters):
     """Mean duration of fn() on torch's current stream (HIP events)."""
     import torch
@@ -431,7 +443,7 @@ def ref_api_lines(cfg, sr, gt, mask, n_edges, headline_ms):
         for _ in range(iters):
             l1, kl = loop(smap, mode)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters * 1e3, float(l1), float(kl)
+        return (time.perf_counter() - t0) / iters * 1e3, float(l1.detach()), float(kl.detach())
 
     out = {"what": "unchanged per-image caller loop (similarity_map x2 per image, torch.cat, L1Loss, KLDistanceLoss, "
                    "backward) on the headline's 16 images; ms per loop, forward + backward, wall clock",
@@ -449,6 +461,53 @@ def ref_api_lines(cfg, sr, gt, mask, n_edges, headline_ms):
         finally:
             set_lazy(prev)
         torch.cuda.empty_cache()
+    return out
+
+
+def ref_api_dm_line(dev):
+    """The diffusion fork's unchanged `issl` loop (ddpmssl.py:438-513, ssl_amd/reference_loop.dm_issl) at C4: 2 crops of
+    512 x 512, its constructor arguments (`simself_strategy` areaarea_mask_nonlocalavg_cuda_v1 = eps 1e-20, kernel_size
+    25, kernel_size_center 9, scaling_factor 0.004, softmax), mask_stride 3, weights 5e2 -- against
+    ssl_amd.losses.dm_loss_util.similarity_map and ssl_amd's criterion modules, deferred and eager."""
+    import torch
+    from ssl_amd.losses import KLDistanceLoss, L1Loss, set_lazy
+    from ssl_amd.losses.dm_loss_util import similarity_map
+    from ssl_amd.reference_loop import dm_issl, stride_pattern
+    cfg = CONFIGS["c4"]
+    sr_np, gt_np, mask_np = make_inputs(cfg, 0, 1, "weak")
+    n = int(effective_mask(cfg, mask_np).sum())
+    sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
+    sslopt = dict(mask_stride=cfg_stride(cfg), simself_strategy="areaarea_mask_nonlocalavg_cuda_v1", kernel_size=cfg["ks"],
+                  scaling_factor=cfg["sigma"], softmax_sr=True, softmax_gt=True, kernel_size_center=cfg["kw"])
+    pat = stride_pattern(cfg["H"], cfg_stride(cfg), dev)
+    cri1, cri2 = L1Loss(loss_weight=cfg_w(cfg)), KLDistanceLoss(loss_weight=cfg_w(cfg))
+    x = sr.clone().requires_grad_(True)
+
+    def loop():
+        x.grad = None
+        l1, kl = dm_issl(similarity_map, cri1, cri2, x * 1.0, gt, mask, sslopt, pat)
+        (l1 + kl).backward()
+        return l1, kl
+
+    out = {"what": "unchanged DM-fork issl loop at C4 (2 x 3x512x512, stride 3, eps 1e-20), forward + backward, wall clock",
+           "edge_px": n}
+    for lz in (True, False):
+        prev = set_lazy(lz)
+        try:
+            for _ in range(2):
+                loop()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            iters = 10 if lz else 5
+            for _ in range(iters):
+                l1, kl = loop()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            out["deferred" if lz else "eager"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "edge-px/s",
+                                                  "l1": float(l1.detach()), "kl": float(kl.detach())}
+        finally:
+            set_lazy(prev)
+    torch.cuda.empty_cache()
     return out
 
 
@@ -586,6 +645,18 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
 
+    # two more blocks of the same K steps, for information only (`config.ms_per_step_blocks`): the first entry is the
+    # timed region above; a clock still ramping after the warm-up shows up as a first block slower than the others
+    blocks = [elapsed / max(args.steps, 1) * 1e3]
+    if not args.dry_run and world == 1:
+        for _ in range(2):
+            sync_all()
+            tb = time.perf_counter()
+            for _ in range(args.steps):
+                run_step()
+            sync_all()
+            blocks.append((time.perf_counter() - tb) / max(args.steps, 1) * 1e3)
+
     tot_edges = torch.tensor([float(n_edges)], device=dev, dtype=torch.float64)
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     ranks_seen = 1
@@ -614,6 +685,7 @@ def main():
                        "mask_density": n_edges / max(B * cfg["H"] * cfg["W"], 1),
                        "input_checksum": synth.checksum(sr_np, gt_np, mask_np),
                        "gradient_accumulation": "fixed-point integer atomics (bit-reproducible, the shipped default)",
+                       "ms_per_step_blocks": blocks, "sclk_after_timed_region": gpu_clock(),
                        "parallelism": f"images sharded x{world}, no data-path collective"},
         }
         if args.dry_run:
@@ -687,6 +759,7 @@ def main():
                                 "c4": extra_line("c4", False, dev, 50, 10),
                                 "c2_maskgen": extra_line("c2", False, dev, 30, 5, maskgen=True),
                                 "ref_api": ref_api_lines(cfg, sr, gt, mask, n_edges, elapsed / args.steps * 1e3),
+                                "ref_api_dm": ref_api_dm_line(dev),
                                 "operator": operator_line(cfg, sr, mask)}
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg, sr_np, gt_np, mask_np)

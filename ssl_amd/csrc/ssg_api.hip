@@ -824,6 +824,9 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   if (!defer) tm.slots = 0;
   // with the plan in use every kernel takes its job order from it: the full tile-major order is not built (3 launches)
   if (defer) order = nullptr;
+  // kernel sizes without shared-term kernels ((11,5), other channel counts) have no use for a plan: not built
+  // (4 launches of 4-5 us each: BASELINE's C1 step is 14 dependent launches long)
+  if (!dense_supported(ks, kw, C)) plan = nullptr;
   // the row scales and the fixed-point gradient sums start at zero: cleared by the edge-list builder's first kernel
   // (16-byte granules: both sizes are multiples of 16)
   const bool zero_fix = grad_fix && grad_sr;

@@ -413,7 +413,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < HL; ++t) w[c][t] = f2{rq[c * RH * RS + t], rq[c * RH * RS + t + HL]};
-    constexpr int SB = 13;  // consecutive offsets per edge pixel buffered in registers and stored together
+    // consecutive offsets per edge pixel buffered in registers and stored together; the (49,13) row-major variant (the
+    // fallback of tile-major calls: masks under 60 % tile fill) keeps 7 (seven groups per offset row) -- with 13 it spilled 10 values per lane, 44 B of scratch
+    constexpr int SB = (KS == 49 && !TM) ? 7 : 13;
     float evb[TM ? 1 : NCHUNK][TM ? 1 : SB];   // (tile-major rows: nothing is buffered)
     float *tmq = nullptr;                      // tile-major: this wave's offset row, + 64 ck + lane
     if constexpr (TM) tmq = p.tm[which] + ((size_t)tslot * P + (size_t)qyi * KS) * (size_t)NE_MAX + lane;

@@ -1178,7 +1178,7 @@ def test_dense_and_direct_paths_agree_on_random_shapes(dev):
     (threshold 1: every non-empty tile) and the direct kernels (threshold 0) give the same SSG rows (<= 2e-6), the
     same losses (rel 1e-5) and gradients that both sit within the oracle tolerance of the fp64 oracle -- including
     images whose sides are not multiples of the tile sizes, empty images, and a capacity smaller than N (the first
-    `capacity` rows only, in both paths)."""
+    `capacity` rows only, in both paths; the losses of such a step are NaN)."""
     from ssl_amd import engine, synth
     rng = np.random.default_rng(2024)
     cases = [(25, 9, 2, 37, 61, 0.2, None), (25, 9, 3, 64, 33, 0.6, None), (25, 9, 1, 26, 90, 1.0, None),
@@ -1204,7 +1204,10 @@ def test_dense_and_direct_paths_agree_on_random_shapes(dev):
                 engine.set_dense_threshold(prev)
         (l0, g0, a0, b0), (l1, g1, a1, b1) = res[0], res[1]
         assert maxerr(a0, a1) <= 2e-6 and maxerr(b0, b1) <= 2e-6, (ks, B, H, W)
-        assert np.all(np.abs(l0 - l1) <= 1e-5 * np.abs(l0) + 1e-12), (l0, l1)
+        if cap is not None and n > cap:   # a truncated fused step says so: NaN losses (include/ssg_hip.h, OVERFLOW)
+            assert np.isnan(l0).all() and np.isnan(l1).all()
+        else:
+            assert np.all(np.abs(l0 - l1) <= 1e-5 * np.abs(l0) + 1e-12), (l0, l1)
         if cap is None:
             ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask[:, 0], ks, kw, 0.05, 1e3, 1e3)
             tol = grad_tol_from_oracle(sr, gt, mask[:, 0], ks, kw, 0.05, ref)

@@ -292,3 +292,27 @@ def test_loop_with_different_weights_and_a_single_criterion(dev, golden):
             assert float((sr.grad - x.grad).abs().max()) <= 3e-6 * float(x.grad.abs().max())
     finally:
         set_lazy(prev)
+
+
+def test_unchanged_loop_at_c2_full_size_equals_the_batched_step(dev):
+    """BASELINE configs[1] at full size (16 x 3x256x256, Laplacian masks): the reference's unchanged loop on deferred
+    handles gives the batched step's numbers -- losses to 2e-6, gradient to 3e-6 of its maximum (the batched step is
+    checked against the fp64 oracle at this size in test_c2_full_size_properties)."""
+    from ssl_amd import engine, synth
+    from ssl_amd.losses import KLDistanceLoss, L1Loss, similarity_map, set_lazy
+    from ssl_amd.reference_loop import gan_selfsim_block
+    sr_np, gt_np, mask_np = synth.make_batch(16, 256, 256, seed0=100)
+    n = int(mask_np.sum())
+    step = engine.LossStep(16, 3, 256, 256, 25, 9, 0.004, 1e-10, True, 1e3, 1e3, device=dev, capacity=n + 64)
+    loss, grad = step(T(sr_np, dev), T(gt_np, dev), T(mask_np, dev))
+    setting = dict(ssl_mode='cuda', kernel_size_search=25, generalization=True, kernel_size_window=9, sigma=0.004)
+    prev = set_lazy(True)
+    try:
+        sr = T(sr_np, dev).requires_grad_(True)
+        l1, kl = gan_selfsim_block(similarity_map, L1Loss(1e3), KLDistanceLoss(1e3), sr * 1.0, T(gt_np, dev),
+                                   T(mask_np, dev), setting)
+        (l1 + kl).backward()
+    finally:
+        set_lazy(prev)
+    assert abs(float(l1) - float(loss[0])) <= 2e-6 * float(loss[0]) and abs(float(kl) - float(loss[1])) <= 2e-6 * float(loss[1])
+    assert float((sr.grad - grad).abs().max()) <= 3e-6 * float(grad.abs().max())
