@@ -80,7 +80,8 @@ struct ZeroRanges {
 };
 
 // (also zeroes the order tiles' counters that edge_scatter fills, and the caller's ZeroRanges)
-__global__ __launch_bounds__(256) void edge_count(EdgeParams p, int *blockcnt, int *tcnt, int nt, ZeroRanges z) {
+__global__ __launch_bounds__(256) void edge_count(EdgeParams p, int *blockcnt, int *tcnt, int nt, ZeroRanges z,
+                                                  uint8_t *bits_out) {
   __shared__ int wsum[4];
   if (tcnt)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gridDim.x * 256) tcnt[i] = 0;
@@ -92,6 +93,9 @@ __global__ __launch_bounds__(256) void edge_count(EdgeParams p, int *blockcnt, i
   }
   int b, pix0;
   const unsigned bits = chunk_bits(p, b, pix0);
+  // the predicate of the lane's four pixels, kept for edge_scatter (with the on-device Laplacian mask it is 15 gathers
+  // and three fixed-point gray conversions per pixel: evaluated once instead of twice)
+  bits_out[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint8_t)bits;
   int c = __popc(bits);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
@@ -137,10 +141,11 @@ __global__ __launch_bounds__(1024) void edge_scan(const int *blockcnt, int *bloc
 }
 
 __global__ __launch_bounds__(256) void edge_scatter(EdgeParams p, const int *blockoff, int *edges, int capacity,
-                                                    int *rank, int *tcnt) {
+                                                    int *rank, int *tcnt, const uint8_t *bits_in) {
   __shared__ int wtot[4];
-  int b, pix0;
-  const unsigned bits = chunk_bits(p, b, pix0);
+  const int b = blockIdx.x / p.nblk_img;
+  const int pix0 = (blockIdx.x - b * p.nblk_img) * CHUNK + 4 * threadIdx.x;
+  const unsigned bits = bits_in[(size_t)blockIdx.x * 256 + threadIdx.x];   // (edge_count's)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = __popc(bits);
   int incl = c;  // inclusive scan over the 256 lanes: shuffles inside the waves + the 4 wave totals
@@ -449,7 +454,8 @@ static size_t n_super_tiles(int B, int H, int W) { return (size_t)B * ((H + 3) /
 
 size_t edge_scratch_bytes(int B, int H, int W) {
   const size_t nblk = (size_t)B * (((size_t)H * W + CHUNK - 1) / CHUNK);
-  return (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64;
+  // (+ one predicate byte per lane of edge_count, behind the int arrays)
+  return (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64 + nblk * 256;
 }
 
 static size_t n_strips(int B, int H, int W) { return (size_t)B * ((H + STRIP_ROWS - 1) / STRIP_ROWS) * ((W + 31) / 32); }
@@ -485,11 +491,12 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;
   int *tcnt = blockoff + nblk, *toff = tcnt + nt;
   const bool need_tiles = order || plan;  // rows per 8x8 order tile, counted while the edges are scattered
+  uint8_t *bits = (uint8_t *)(toff + nt + n_super_tiles(B, H, W)) + 64;
   const ZeroRanges z{{zero_a, zero_b, zero_c}, {zero_a ? zero_a_bytes : 0, zero_b ? zero_b_bytes : 0, zero_c ? zero_c_bytes : 0}};
-  hipLaunchKernelGGL(edge_count, dim3(nblk), dim3(256), 0, st, p, blockcnt, need_tiles ? tcnt : nullptr, nt, z);
+  hipLaunchKernelGGL(edge_count, dim3(nblk), dim3(256), 0, st, p, blockcnt, need_tiles ? tcnt : nullptr, nt, z, bits);
   hipLaunchKernelGGL(edge_scan, dim3(1), dim3(1024), 0, st, blockcnt, blockoff, nblk, p.nblk_img, B, counts, plan);
   hipLaunchKernelGGL(edge_scatter, dim3(nblk), dim3(256), 0, st, p, blockoff, edges, capacity, rank,
-                     need_tiles ? tcnt : nullptr);
+                     need_tiles ? tcnt : nullptr, bits);
   // (with a forward plan the group flags of both orders are set by one launch at the end)
   if (order) build_order(rank, B, H, W, order, capacity, edges, counts, !plan, tcnt, toff, st);
   if (plan) {

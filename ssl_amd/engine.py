@@ -89,14 +89,16 @@ class EdgeList(tuple):
         return self
 
 
-def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=None, ks=25):
+def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=None, ks=25, order=True):
     """Device-side edge list of a batch.
 
     mask: (B,c1,H,W) float32 or uint8 (channel 0 is used) -- or None with
     gt (B,3,H,W) float32 in [0,1] to generate the reference's Laplacian mask
     on the fly.  Returns (edges (capacity,3) int32 [b,y,x], counts (B+2) int32
     on device: counts[0] = N).  No host synchronisation.  `ks` is the search size the dense/direct
-    work split (`.plan`) is built for: pass the k_s the list will be used with.
+    work split (`.plan`) is built for: pass the k_s the list will be used with.  order=False leaves the
+    separate tile-major order out (`.order` None, three launches less) for callers whose kernels all take
+    their job order from the plan (sizes with shared-term kernels: (25,9,3), (49,13,3)).
     """
     L = _lib.lib()
     if mask is not None:
@@ -118,7 +120,7 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     edges = torch.empty((max(capacity, 1), 3), dtype=torch.int32, device=dev)
     counts = torch.empty(B + 2, dtype=torch.int32, device=dev)
     rank = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-    order = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    order = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev) if order else None
     plan = torch.empty(L.ssg_forward_plan_bytes(B, H, W, capacity) // 4, dtype=torch.int32, device=dev)
     scratch = torch.empty(L.ssg_edge_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):   # launches go to the tensors' GPU, whatever the current device is

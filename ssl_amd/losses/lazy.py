@@ -255,7 +255,8 @@ class _LazyStepFn(torch.autograd.Function):
         B, C, H, W = x.shape
         dev = x.device
         with torch.cuda.device(dev):
-            el = engine.edge_list(mask=mask, capacity=B * H * W, ks=ks)
+            dense = (ks, kw, C) in ((25, 9, 3), (49, 13, 3))      # sizes whose kernels all work from the plan
+            el = engine.edge_list(mask=mask, capacity=B * H * W, ks=ks, order=not dense)
             n = int(el.counts[0])        # ONE host synchronisation per step (the loop itself has one per image)
             loss = torch.zeros(2, dtype=torch.float32, device=dev)
             ctx.n = n
@@ -267,7 +268,7 @@ class _LazyStepFn(torch.autograd.Function):
             ssg_gt = torch.empty((n, P), dtype=torch.float32, device=dev)
             order, rank, plan = el.fwd
             rsc = None
-            if (ks, kw, C) in ((25, 9, 3), (49, 13, 3)):
+            if dense:
                 rsc = torch.empty(2 * n, dtype=torch.float64, device=dev)   # deferred normalisation (ssg_hip.h)
             else:
                 rank = plan = None
