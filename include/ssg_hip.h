@@ -244,6 +244,20 @@ int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
                       void *scratch, void *grad_fix /* nullable: deterministic mode */,
                       const double *row_scale /* nullable */, int rows_are_scratch, ssg_stream_t stream);
 
+/* The two criteria on tensors that already exist (L1Loss basic_loss.py:41-66 with l1_loss :14-16; KLDistanceLoss
+ * basic_loss.py:269-282): sums_out[0] = sum |pred - target|, sums_out[1] = sum t' (log t' - log s') with
+ * s' = max(pred, 1e-10), t' = max(target, 1e-10), over n fp32 elements, in one streaming pass (fp64 accumulation in a
+ * fixed order: bit-reproducible); the caller applies reduction and loss_weight (mean = sum / n).  `scratch`:
+ * ssg_criteria_scratch_bytes() bytes.  ssg_criteria_grad: grad_pred[i] = coef[0] * sign(pred - target) - coef[1] *
+ * t'/s' (second term 0 where pred < 1e-10: the clamp's derivative), coef = 2 DEVICE floats (the upstream gradients
+ * times weight / n: no host round trip).  The engine's fused entry points below compute the same terms inside their
+ * row passes; these two serve SSG tensors that were materialised (eager `similarity_map`, INTEGRATION.md Level 1). */
+size_t ssg_criteria_scratch_bytes(void);
+int ssg_criteria_sums(const float *pred, const float *target, size_t n, void *scratch, float *sums_out,
+                      ssg_stream_t stream);
+int ssg_criteria_grad(const float *pred, const float *target, size_t n, const float *coef, float *grad_pred,
+                      ssg_stream_t stream);
+
 /* Everything in one call: edge list (from a mask or from GT's Laplacian),
  * SSG(sr), SSG(gt), both criteria and the gradient.  ssg_sr / ssg_gt
  * (capacity, k_s*k_s) receive the SSG tensors; `counts` as in ssg_edge_list;

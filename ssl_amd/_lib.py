@@ -65,6 +65,9 @@ PROTOTYPES = {
     "ssg_ref_compute_similarity_backward": (None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "ssg_last_status": (_i, []),
     "ssg_device_status": (_i, [_vp]),
+    "ssg_criteria_scratch_bytes": (_sz, []),
+    "ssg_criteria_sums": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "ssg_criteria_grad": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
 }
 PROF_PROTOTYPES = {"ssg_set_profile_mask": (_i, [_i])}   # libssg_hip_prof.so only
 # C++-linkage symbols of include/similarity.h (Itanium mangling of the reference's declarations, similarity.h:2-23)

@@ -58,6 +58,9 @@ bool grow_supported(int ks, int kw);
 unsigned grow_grid(int n_host);
 int launch_grad_rows(const GrowParams &p, int ks, int kw, hipStream_t st);
 int launch_rows_tm(const TmRowsParams &p, int ks, int kw, hipStream_t st);
+size_t criteria_scratch_bytes();
+int launch_criteria_sums(const float *a, const float *b, size_t n, void *scratch, float *sums_out, hipStream_t st);
+int launch_criteria_grad(const float *a, const float *b, size_t n, const float *coef, float *g, hipStream_t st);
 bool dense_bwd_supported(int ks, int kw, int C);
 int launch_bwd_dense(const DenseBwdParams &p, int ks, int kw, int C, hipStream_t st);
 int launch_augment_crop(const void *src, void *dst, int elem_bytes, int B, int C, int Hs, int Ws, int Ho, int Wo,
@@ -911,6 +914,23 @@ int ssg_diffjpeg(const float *img, float *out, int B, int H, int W, const float 
   if (B == 0) return 0;
   if (!img || !out || (!quality_dev && !(quality > 0.f))) return SSG_E_BADARG;
   return launch_jpeg(img, out, B, H, W, quality_dev, quality, (hipStream_t)stream);
+}
+
+size_t ssg_criteria_scratch_bytes(void) { return criteria_scratch_bytes(); }
+
+int ssg_criteria_sums(const float *pred, const float *target, size_t n, void *scratch, float *sums_out,
+                      ssg_stream_t stream) {
+  if (!sums_out || !scratch) return SSG_E_BADARG;
+  if (n == 0) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(float), (hipStream_t)stream);
+  if (!pred || !target) return SSG_E_BADARG;
+  return launch_criteria_sums(pred, target, n, scratch, sums_out, (hipStream_t)stream);
+}
+
+int ssg_criteria_grad(const float *pred, const float *target, size_t n, const float *coef, float *grad_pred,
+                      ssg_stream_t stream) {
+  if (n == 0) return 0;
+  if (!pred || !target || !coef || !grad_pred) return SSG_E_BADARG;
+  return launch_criteria_grad(pred, target, n, coef, grad_pred, (hipStream_t)stream);
 }
 
 int ssg_device_status(ssg_stream_t stream) {

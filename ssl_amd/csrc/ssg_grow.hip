@@ -498,6 +498,122 @@ int launch_rows_tm(const TmRowsParams &p, int ks, int kw, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// ---- the two criteria on plain tensors (rows a8 / a9 standalone: L1Loss, KLDistanceLoss of basic_loss.py:41-66,269-282
+// applied to SSG tensors that already exist -- the eager `similarity_map` path and every fallback of the deferred
+// handles).  One streaming pass gives both sums (fp32 inside a lane's ~100 elements, fp64 from there on, fixed order:
+// bit-reproducible); one pass gives d(c1 sum|a-b| + c2 sum kl)/da with the two coefficients read on the device.
+constexpr int CRIT_GRID = 2048;
+
+__global__ __launch_bounds__(256) void criteria_sums_kernel(const float *a, const float *b, size_t n, double *part) {
+  __shared__ double w1[4], w2[4];
+  float l1 = 0.f, kl = 0.f;
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
+  const float4 *a4 = (const float4 *)a, *b4 = (const float4 *)b;
+  const bool vec = (((size_t)a | (size_t)b) & 15) == 0;
+  double L1 = 0.0, KL = 0.0;
+  if (vec) {
+    int run = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 x = a4[i], y = b4[i];
+      criteria_elem(x.x, y.x, 0.f, 0.f, l1, kl);
+      criteria_elem(x.y, y.y, 0.f, 0.f, l1, kl);
+      criteria_elem(x.z, y.z, 0.f, 0.f, l1, kl);
+      criteria_elem(x.w, y.w, 0.f, 0.f, l1, kl);
+      if (++run == 32) {   // (128 elements per fp32 partial sum)
+        L1 += (double)l1; KL += (double)kl; l1 = kl = 0.f; run = 0;
+      }
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) criteria_elem(a[i], b[i], 0.f, 0.f, l1, kl);
+  } else {
+    int run = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      criteria_elem(a[i], b[i], 0.f, 0.f, l1, kl);
+      if (++run == 128) {
+        L1 += (double)l1; KL += (double)kl; l1 = kl = 0.f; run = 0;
+      }
+    }
+  }
+  L1 += (double)l1;
+  KL += (double)kl;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    L1 += __shfl_down(L1, o, 64);
+    KL += __shfl_down(KL, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    w1[threadIdx.x >> 6] = L1;
+    w2[threadIdx.x >> 6] = KL;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = (w1[0] + w1[1]) + (w1[2] + w1[3]);
+    part[2 * blockIdx.x + 1] = (w2[0] + w2[1]) + (w2[2] + w2[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void criteria_finish_kernel(const double *part, int nparts, float *out) {
+  __shared__ double s1[256], s2[256];
+  double x = 0.0, y = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    x += part[2 * i];
+    y += part[2 * i + 1];
+  }
+  s1[threadIdx.x] = x;
+  s2[threadIdx.x] = y;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s1[threadIdx.x] += s1[threadIdx.x + o];
+      s2[threadIdx.x] += s2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = (float)s1[0];
+    out[1] = (float)s2[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void criteria_grad_kernel(const float *a, const float *b, size_t n, const float *coef,
+                                                            float *g) {
+  const float c1 = coef[0], c2 = coef[1];
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
+  float d1 = 0.f, d2 = 0.f;
+  if (((((size_t)a | (size_t)b | (size_t)g)) & 15) == 0) {
+    const float4 *a4 = (const float4 *)a, *b4 = (const float4 *)b;
+    float4 *g4 = (float4 *)g;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 x = a4[i], y = b4[i];
+      float4 r;
+      r.x = criteria_elem(x.x, y.x, c1, c2, d1, d2);
+      r.y = criteria_elem(x.y, y.y, c1, c2, d1, d2);
+      r.z = criteria_elem(x.z, y.z, c1, c2, d1, d2);
+      r.w = criteria_elem(x.w, y.w, c1, c2, d1, d2);
+      g4[i] = r;
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = criteria_elem(a[i], b[i], c1, c2, d1, d2);
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = criteria_elem(a[i], b[i], c1, c2, d1, d2);
+  }
+}
+
+size_t criteria_scratch_bytes() { return sizeof(double) * 2 * CRIT_GRID; }
+
+int launch_criteria_sums(const float *a, const float *b, size_t n, void *scratch, float *sums_out, hipStream_t st) {
+  const size_t want = (n / 4 + 255) / 256;
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want > CRIT_GRID ? CRIT_GRID : want));
+  hipLaunchKernelGGL(criteria_sums_kernel, dim3(grid), dim3(256), 0, st, a, b, n, (double *)scratch);
+  hipLaunchKernelGGL(criteria_finish_kernel, dim3(1), dim3(256), 0, st, (const double *)scratch, (int)grid, sums_out);
+  return (int)hipGetLastError();
+}
+
+int launch_criteria_grad(const float *a, const float *b, size_t n, const float *coef, float *g, hipStream_t st) {
+  const size_t want = (n / 4 + 255) / 256;
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 4 * CRIT_GRID ? 4 * CRIT_GRID : want));
+  hipLaunchKernelGGL(criteria_grad_kernel, dim3(grid), dim3(256), 0, st, a, b, n, coef, g);
+  return (int)hipGetLastError();
+}
+
 bool grow_supported(int ks, int kw) { return (ks == 25 && kw == 9) || (ks == 49 && kw == 13); }
 
 unsigned grow_grid(int n_host) { return (unsigned)((n_host + 3) / 4); }

