@@ -85,11 +85,11 @@ class EdgeList(tuple):
         self = super().__new__(cls, (edges, counts))
         self.edges, self.counts, self.rank, self.order, self.plan = edges, counts, rank, order, plan
         self.ks = int(ks)
-        self.fwd = FwdPlan(order, rank, plan, ks)
+        self.fwd = FwdPlan(order, rank, plan, ks) if plan is not None else None
         return self
 
 
-def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=None, ks=25, order=True):
+def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=None, ks=25, order=True, plan=True):
     """Device-side edge list of a batch.
 
     mask: (B,c1,H,W) float32 or uint8 (channel 0 is used) -- or None with
@@ -98,7 +98,8 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     on device: counts[0] = N).  No host synchronisation.  `ks` is the search size the dense/direct
     work split (`.plan`) is built for: pass the k_s the list will be used with.  order=False leaves the
     separate tile-major order out (`.order` None, three launches less) for callers whose kernels all take
-    their job order from the plan (sizes with shared-term kernels: (25,9,3), (49,13,3)).
+    their job order from the plan (sizes with shared-term kernels: (25,9,3), (49,13,3)).  plan=False leaves the
+    dense/direct plan out instead (`.plan` None, `.fwd` None: direct kernels in tile order; four launches less).
     """
     L = _lib.lib()
     if mask is not None:
@@ -121,7 +122,7 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     counts = torch.empty(B + 2, dtype=torch.int32, device=dev)
     rank = torch.empty((B, H, W), dtype=torch.int32, device=dev)
     order = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev) if order else None
-    plan = torch.empty(L.ssg_forward_plan_bytes(B, H, W, capacity) // 4, dtype=torch.int32, device=dev)
+    plan = torch.empty(L.ssg_forward_plan_bytes(B, H, W, capacity) // 4, dtype=torch.int32, device=dev) if plan else None
     scratch = torch.empty(L.ssg_edge_scratch_bytes(B, H, W), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):   # launches go to the tensors' GPU, whatever the current device is
         _lib.check(L.ssg_edge_list(_ptr(src), kind, c1, B, H, W, int(mask_stride or 0), float(lap_threshold), int(ks),

@@ -56,8 +56,11 @@ def eager_rows(img, mask, conv, kernel_size_search, kernel_size_window, sigma, e
                 blocks.append(eager_rows(img, mask[:, c:c + 1], 'ch0', kernel_size_search, kernel_size_window, sigma,
                                          eps, generalization))
         return torch.cat(blocks, dim=1)
-    el = engine.edge_list(mask=mask, capacity=img.shape[-1] * img.shape[-2], ks=kernel_size_search)
+    cap = img.shape[-1] * img.shape[-2]
+    el = engine.edge_list(mask=mask, capacity=cap, ks=kernel_size_search, plan=cap >= 4 * _PLAN_FROM_ROWS)
     num = int(el.counts[0].item())
+    if el.fwd is None and num >= _PLAN_FROM_ROWS:     # (a small image with an unusually dense mask: now with the plan)
+        el = engine.edge_list(mask=mask, capacity=cap, ks=kernel_size_search)
     # One image rarely has enough dense tiles to fill the chip: its shared-term launch is one resident round (~85 us)
     # whatever the tile count, longer than the direct kernels need for the whole image below ~10 k edge pixels
     # (profiles/r4_operator_vs_plan.txt: 4,820 px 0.086 vs 0.117 ms, 18,417 px 0.187 vs 0.144) -- the plan is used from there.
