@@ -55,6 +55,8 @@ typedef void *ssg_stream_t; /* hipStream_t */
 #define SSG_E_ALIGN (-5)      /* fused step: workspace / grad_fix / grad_sr not 16-byte aligned      */
 #define SSG_E_PLAN (-6)       /* ssg_device_status(): a plan cut for another tile height was used   */
 
+/* 4 (round 4): + ssg_device_status, ssg_criteria_sums / _grad / _scratch_bytes, SSG_E_ALIGN, SSG_E_PLAN; a fused step
+ * whose edge count exceeds its capacity returns NaN losses; a plan of the wrong tile height no longer traps. */
 int ssg_abi_version(void);
 const char *ssg_status_string(int status);
 /* Device-side refusals that no return value can carry (everything is asynchronous): waits for `stream`, then returns

@@ -412,7 +412,7 @@ static bool split_ok(int ks, int kw, int C, const int *rank, const int *plan, co
 
 extern "C" {
 
-int ssg_abi_version(void) { return 3; }
+int ssg_abi_version(void) { return 4; }
 
 const char *ssg_status_string(int status) {
   switch (status) {
