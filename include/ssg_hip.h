@@ -75,6 +75,18 @@ int ssg_device_status(ssg_stream_t stream);
  * is (mc,psize,psize) and is ACCUMULATED into (the reference kernel does
  * `out[...] += d*d` on a zeroed buffer).  Raw squared patch distances, no
  * epilogue.  Asynchronous. */
+/* Calls with many positions build the engine's work split inside the call: from ssg_set_operator_plan_threshold()
+ * positions on for the backward and three times as many for the forward (default 8192 / 24576; n <= 0: never; 1:
+ * always, both; environment SSG_OP_PLAN_FROM) and for the sizes that have shared-term
+ * kernels ((25,9,3), (49,13,3)) the position list becomes a rank map and a plan -- the buffers come from a
+ * library-owned, stream-ordered memory pool (hipMallocFromPoolAsync / hipFreeAsync on `stream`: the reference interface
+ * has no workspace argument) -- and the tiles holding many positions go through the shared-term kernels, the others
+ * through the direct kernels in tile order; `pos` may be in any order and may repeat positions (each row is still
+ * computed).  Same results either way (raw distances rel 2e-6).  Below the threshold, and inside a stream capture,
+ * the direct kernels walk `pos` as it comes.  Measured, launches only (profiles/r4_operator_plan_path.txt): 4,697
+ * positions forward 0.056 ms direct / 0.206 with the plan, backward 0.158 / 0.167; 18,417 positions forward 0.196 /
+ * 0.231, backward 0.462 / 0.258.  Returns the previous threshold. */
+int ssg_set_operator_plan_threshold(int positions);
 int ssg_compute_similarity(const float *image, const int *pos, float *out,
                            int mc, int psize, int ksize, int height, int width,
                            int channel, ssg_stream_t stream);

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ssg_ref_compute_similarity_backward": (None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "ssg_last_status": (_i, []),
     "ssg_device_status": (_i, [_vp]),
+    "ssg_set_operator_plan_threshold": (_i, [_i]),
     "ssg_criteria_scratch_bytes": (_sz, []),
     "ssg_criteria_sums": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "ssg_criteria_grad": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),

@@ -46,6 +46,7 @@ struct DenseParams {
   const int *strips;
   int max_strips;
   int *status;
+  int raw;
 };
 int fwd_plan_strip_offset(int B, int H, int W);
 int dense_max_strips(int B, int H, int W, int ks);
@@ -58,6 +59,9 @@ bool grow_supported(int ks, int kw);
 unsigned grow_grid(int n_host);
 int launch_grad_rows(const GrowParams &p, int ks, int kw, hipStream_t st);
 int launch_rows_tm(const TmRowsParams &p, int ks, int kw, hipStream_t st);
+int launch_pos_to_mask(const int *pos, int mc, int Hp, int Wp, uint8_t *mask, hipStream_t st);
+int launch_pos_relabel(const int *pos, int mc, int Hp, int Wp, int *rank, int *perm, int *dup, int *ndup, int *plan,
+                       int *order2, hipStream_t st);
 size_t criteria_scratch_bytes();
 int launch_criteria_sums(const float *a, const float *b, size_t n, void *scratch, float *sums_out, hipStream_t st);
 int launch_criteria_grad(const float *a, const float *b, size_t n, const float *coef, float *g, hipStream_t st);
@@ -97,6 +101,7 @@ static int dense_threshold() {
   return v;
 }
 
+extern "C" int ssg_set_operator_plan_threshold(int positions);
 extern "C" int ssg_set_dense_threshold(int edge_pixels_per_tile) {
   const int prev = dense_threshold();
   g_dense_thr.store(edge_pixels_per_tile > 0 ? edge_pixels_per_tile : 0, std::memory_order_relaxed);
@@ -405,6 +410,124 @@ static int det_end(const BwdParams &p, hipStream_t st, bool assign = false) {
   return launch_grad_fix_flush(p.gfix, p.grad, (size_t)p.B * p.C * p.H * p.W, assign ? 1 : 0, st);
 }
 
+// ---- the reference operator with many positions: plan built inside the call -------------------------------------------
+// similarity.h's interface has no workspace argument, so the plan's buffers come from a library-owned, stream-ordered
+// memory pool (one per device, release threshold = never: after the first call an allocation is a free-list lookup).
+// Measured (profiles/r4_operator_vs_plan.txt): the plan costs ~45 us per call and a handful of dense tiles are one
+// resident round whatever their number, so the direct kernels in `pos` order win below ~10 k positions (0.134 vs 0.180
+// ms forward at 4,820) and lose above (0.251 vs 0.197 ms at 18,417; forward + backward 0.733 vs 0.454).
+constexpr int OP_PLAN_FROM_DEFAULT = 8192;
+static std::atomic<int> g_op_plan_from{-1};
+// positions from which a call takes the plan path (0x7fffffff = never); SSG_OP_PLAN_FROM / ssg_set_operator_plan_threshold
+// (n <= 0: never)
+static int op_plan_from() {
+  int v = g_op_plan_from.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char *e = getenv("SSG_OP_PLAN_FROM");
+    v = e ? atoi(e) : OP_PLAN_FROM_DEFAULT;
+    if (v <= 0) v = 0x7fffffff;
+    g_op_plan_from.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+static hipMemPool_t op_pool() {
+  constexpr int MAXDEV = 64;
+  static std::mutex mu;
+  static hipMemPool_t tab[MAXDEV] = {};
+  static bool failed[MAXDEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tab[dev] && !failed[dev]) {
+    hipMemPoolProps props{};
+    props.allocType = hipMemAllocationTypePinned;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) != hipSuccess) {
+      failed[dev] = true;
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    unsigned long long keep = ~0ull;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    tab[dev] = pool;
+  }
+  return tab[dev];
+}
+
+struct OpPlan {
+  char *base = nullptr;
+  uint8_t *mask = nullptr;
+  int *edges = nullptr, *counts = nullptr, *rank = nullptr, *plan = nullptr, *perm = nullptr, *dup = nullptr, *ndup = nullptr;
+  void *escratch = nullptr, *bscratch = nullptr;
+};
+
+// true: the call qualifies for the plan path (enough positions, a size with shared-term kernels, not inside a stream capture)
+// (the forward gains less from the shared-term kernel than the backward -- measured at 18,417 positions: forward 0.196 ms
+// direct / 0.231 with the plan, backward 0.462 / 0.258 -- so it takes the plan from three times as many positions)
+static bool op_wants_plan(int mc, int ks, int kw, int C, hipStream_t st, bool forward) {
+  const long from = (long)op_plan_from() * (forward && op_plan_from() > 1 ? 3 : 1);
+  if (from >= 0x7fffffffL || (long)mc < from || !dense_supported(ks, kw, C) || !dense_bwd_supported(ks, kw, C) || !grow_supported(ks, kw)) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return true;
+}
+
+// rank map, plan and duplicate list of `pos` (padded coordinates on a (Hp, Wp) image), everything relabelled to the
+// caller's row numbers.  rc != 0 or o.base == nullptr: fall back to the direct path.
+static int op_plan_build(const int *pos, int mc, int ks, int Hp, int Wp, size_t bwd_scratch_bytes, hipStream_t st, OpPlan &o) {
+  hipMemPool_t pool = op_pool();
+  if (!pool) return 0;
+  const size_t npix = (size_t)Hp * Wp;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += align_up(bytes, 256);
+    return at;
+  };
+  const size_t o_mask = take(npix), o_edges = take(sizeof(int) * 3 * (size_t)mc), o_counts = take(sizeof(int) * 8),
+               o_rank = take(sizeof(int) * npix), o_plan = take(fwd_plan_bytes(1, Hp, Wp, mc)),
+               o_perm = take(sizeof(int) * (size_t)mc), o_dup = take(sizeof(int) * (size_t)mc), o_ndup = take(sizeof(int) * 4),
+               o_es = take(edge_scratch_bytes(1, Hp, Wp)), o_bs = take(bwd_scratch_bytes);
+  void *base = nullptr;
+  if (hipMallocFromPoolAsync(&base, off, pool, st) != hipSuccess || !base) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  o.base = (char *)base;
+  o.mask = (uint8_t *)(o.base + o_mask);
+  o.edges = (int *)(o.base + o_edges);
+  o.counts = (int *)(o.base + o_counts);
+  o.rank = (int *)(o.base + o_rank);
+  o.plan = (int *)(o.base + o_plan);
+  o.perm = (int *)(o.base + o_perm);
+  o.dup = (int *)(o.base + o_dup);
+  o.ndup = (int *)(o.base + o_ndup);
+  o.escratch = o.base + o_es;
+  o.bscratch = bwd_scratch_bytes ? o.base + o_bs : nullptr;
+  int rc = (int)hipMemsetAsync(o.mask, 0, npix, st);
+  if (!rc) rc = (int)hipMemsetAsync(o.perm, 0xff, sizeof(int) * (size_t)mc, st);
+  if (!rc) rc = (int)hipMemsetAsync(o.ndup, 0, sizeof(int) * 4, st);
+  if (!rc) rc = launch_pos_to_mask(pos, mc, Hp, Wp, o.mask, st);
+  if (!rc)
+    rc = launch_edge_list(o.mask, 1, 1, 1, Hp, Wp, 0, 0.f, o.edges, mc, o.counts, o.rank, nullptr, o.plan, dense_threshold(),
+                          dense_tile_rows(ks), o.escratch, nullptr, 0, nullptr, 0, nullptr, 0, st);
+  if (!rc) rc = launch_pos_relabel(pos, mc, Hp, Wp, o.rank, o.perm, o.dup, o.ndup, o.plan, o.plan + fwd_plan_order_offset(1, Hp, Wp), st);
+  return rc;
+}
+
+static int op_plan_free(OpPlan &o, hipStream_t st) {
+  if (!o.base) return 0;
+  const int rc = (int)hipFreeAsync(o.base, st);
+  o.base = nullptr;
+  return rc;
+}
+
 static bool split_ok(int ks, int kw, int C, const int *rank, const int *plan, const void *scratch) {
   return rank && plan && scratch && grow_supported(ks, kw) && dense_bwd_supported(ks, kw, C) &&
          !(dbg_mask() & (1 << 24));
@@ -451,7 +574,47 @@ int ssg_compute_similarity(const float *image, const int *pos, float *out, int m
   p.ks = psize;
   p.kw = ksize;
   p.dbg = dbg_mask() & 0xff;
-  return launch_fwd(p, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (op_wants_plan(mc, psize, ksize, channel, st, true)) {
+    OpPlan o;
+    int rc = op_plan_build(pos, mc, psize, height, width, 0, st, o);
+    if (!rc && o.base) {
+      // dense tiles -> shared-term kernel in raw mode, the rest (the plan's tile order, caller's row numbers) -> the
+      // direct kernels, duplicates of a position -> a direct launch of their own
+      DenseParams d{};
+      d.img[0] = image;
+      d.out[0] = out;
+      d.nimg = 1;
+      d.rank = o.rank;
+      d.n_dense = o.plan + 1;
+      d.tiles = o.plan + 4;
+      d.max_tiles = dense_max_tiles(1, height, width, psize);
+      d.n_host = mc;
+      d.B = 1;
+      d.H = height;
+      d.W = width;
+      d.sigma = 1.f;
+      d.raw = 1;
+      d.dbg = (dbg_mask() >> 16) & 0xff;
+      d.status = device_status_word();
+      SideStream *fk = nullptr;
+      hipStream_t st2 = fork_from(st, psize, fk);
+      rc = launch_fwd_dense(d, psize, ksize, channel, st);
+      FwdParams q = p;
+      q.order = o.plan + fwd_plan_order_offset(1, height, width);
+      q.n_dev = o.plan;   // n_sparse
+      if (!rc) rc = launch_fwd(q, st2);
+      const int rcj = join_to(st, fk);
+      if (!rc) rc = rcj;
+      q.order = o.dup;
+      q.n_dev = o.ndup;
+      if (!rc) rc = launch_fwd(q, st);
+    }
+    const bool used = o.base != nullptr;
+    const int rcf = op_plan_free(o, st);
+    if (used || rc) return rc ? rc : rcf;
+  }
+  return launch_fwd(p, st);
 }
 
 int ssg_compute_similarity_backward(const float *image, const float *grads, const int *pos, float *image_grads,
@@ -477,7 +640,24 @@ int ssg_compute_similarity_backward(const float *image, const float *grads, cons
   p.ks = psize;
   p.kw = ksize;
   p.dbg = (dbg_mask() >> 8) & 0xff;
-  return launch_bwd(p, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (op_wants_plan(mc, psize, ksize, channel, st, false)) {
+    OpPlan o;
+    int rc = op_plan_build(pos, mc, psize, height, width, split_scratch_bytes(mc, psize), st, o);
+    if (!rc && o.base) {
+      // the split backward in GRAD_D mode (`grads` ARE the G rows): border sums by ssg_grad_rows, dense tiles by the
+      // shared-term kernel, the plan's sparse rows by the direct one; then the duplicates of a position on their own
+      rc = split_backward(p, o.rank, o.plan, o.bscratch, st);
+      BwdParams q = p;
+      q.order = o.dup;
+      q.n_dev = o.ndup;
+      if (!rc) rc = launch_bwd(q, st);
+    }
+    const bool used = o.base != nullptr;
+    const int rcf = op_plan_free(o, st);
+    if (used || rc) return rc ? rc : rcf;
+  }
+  return launch_bwd(p, st);
 }
 
 size_t ssg_edge_scratch_bytes(int B, int H, int W) { return edge_scratch_bytes(B, H, W); }
@@ -914,6 +1094,12 @@ int ssg_diffjpeg(const float *img, float *out, int B, int H, int W, const float 
   if (B == 0) return 0;
   if (!img || !out || (!quality_dev && !(quality > 0.f))) return SSG_E_BADARG;
   return launch_jpeg(img, out, B, H, W, quality_dev, quality, (hipStream_t)stream);
+}
+
+int ssg_set_operator_plan_threshold(int positions) {
+  const int prev = op_plan_from();
+  g_op_plan_from.store(positions > 0 ? positions : 0x7fffffff, std::memory_order_relaxed);
+  return prev;
 }
 
 size_t ssg_criteria_scratch_bytes(void) { return criteria_scratch_bytes(); }

@@ -120,6 +120,7 @@ struct DenseParams {
   const int *strips;  // k_s 49 tile-major calls: [0] number of strips, then (strip id, first slot) pairs; nullable
   int max_strips;     // launch bound per image
   int *status;        // nullable: library-owned device status word (ssg_device_status): bit 0 = plan of another tile height
+  int raw;            // 1: the reference operator's output -- out[n, q] += D[n, q] (similarity.cu:49), no epilogue
 };
 
 constexpr int DT_X = 32;  // centre columns per tile; rows: DT_Y = 16 - (k_w - 1) (8 for k_w = 9, 4 for k_w = 13)
@@ -152,8 +153,10 @@ __device__ __forceinline__ int dense_h_col(int ex, int L, int G, bool paired) {
 // workgroup per CU, and a lone wave per SIMD issues a VALU instruction only every ~4 cycles, so 7 waves -- 49 rows
 // are 7 each, with 8 the workgroup waits for the one wave that has a 7th row.
 // TM: the launch writes tile-major scratch rows (k_w 13 only: the fixed pixel map below is the layout's pixel index)
-template <int KS, int KW, int C, int NW, bool TM = false>
+// RAW: raw squared distances ACCUMULATED into the rows (the reference operator, ssg_compute_similarity with a plan)
+template <int KS, int KW, int C, int NW, bool TM = false, bool RAW = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_fwd_dense(DenseParams p) {
+  static_assert(!(TM && RAW), "raw distances go to the caller's row-major rows");
   constexpr int NT = 64 * NW;
   constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK, DT_Y = 16 - 2 * HK;
   constexpr int RH = DT_Y + 2 * HALO, RWD = DT_X + 2 * HALO, RS = RWD + 1;  // image region
@@ -575,9 +578,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           } else {
             d = dpair[ck];
           }
-          const float ev = __builtin_amdgcn_exp2f(d * nk);
-          rs[ck] += (double)ev;
-          asm volatile("" : "+v"(rs[ck]));   // (pinned: the sink pass otherwise moves these additions to the end of the row and keeps every e for them)
+          float ev;
+          if constexpr (RAW) {
+            ev = d;
+          } else {
+            ev = __builtin_amdgcn_exp2f(d * nk);
+            rs[ck] += (double)ev;
+            asm volatile("" : "+v"(rs[ck]));   // (pinned: the sink pass otherwise moves these additions to the end of the row and keeps every e for them)
+          }
           if constexpr (TM) {
             // tile-major scratch rows: the 64 lanes' values of one offset are one aligned 256-byte run (holes
             // included: the consumers skip them by the rank map)
@@ -593,10 +601,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
               for (int t = 0; t + 4 <= cnt; t += 4) {
                 float4 v4 = make_float4(evb[ck][t], evb[ck][t + 1], evb[ck][t + 2], evb[ck][t + 3]);
+                if constexpr (RAW) {   // out += D: the row's own lane is the only writer of these words
+                  float4 old;
+                  __builtin_memcpy(&old, o + q0 + t, 16);
+                  v4.x += old.x; v4.y += old.y; v4.z += old.z; v4.w += old.w;
+                }
                 __builtin_memcpy(o + q0 + t, &v4, 16);
               }
 #pragma unroll
-              for (int t = cnt & ~3; t < cnt; ++t) o[q0 + t] = evb[ck][t];
+              for (int t = cnt & ~3; t < cnt; ++t) {
+                if constexpr (RAW) o[q0 + t] += evb[ck][t];
+                else o[q0 + t] = evb[ck][t];
+              }
             }
           }
           }
@@ -611,7 +627,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (ck * 64 + lane < n_e) rsum[wv * RSTR + ck * 64 + lane] = rs[ck];
   __threadfence_block();
   __syncthreads();
-  if (!p.generalization || SSG_DBG(p, 8)) return;
+  if (RAW || !p.generalization || SSG_DBG(p, 8)) return;
   if (p.row_scale) {
     // deferred normalisation: the consumer that streams the rows anyway (ssg_grad_rows) rescales them; saves this
     // kernel's second pass over its rows (one read + one write of every row)
@@ -1075,14 +1091,14 @@ int dense_max_tiles(int B, int H, int W, int ks) {
   return B * ((H + ty - 1) / ty) * ((W + DT_X - 1) / DT_X);
 }
 
-template <int KS, int KW, int C, int NW, bool TM>
+template <int KS, int KW, int C, int NW, bool TM, bool RAW = false>
 static int launch_fwd_dense_t(DenseParams p, int n_tiles, hipStream_t st) {
   if (n_tiles <= 0) return 0;
   const size_t lds = dense_lds_bytes<KS, KW, C, NW>();
   static std::atomic<unsigned long long> lds_set{0};
-  if (const int rc = ensure_dynamic_lds(ssg_fwd_dense<KS, KW, C, NW, TM>, (int)lds, lds_set)) return rc;
+  if (const int rc = ensure_dynamic_lds(ssg_fwd_dense<KS, KW, C, NW, TM, RAW>, (int)lds, lds_set)) return rc;
   p.grid_tiles = n_tiles;
-  hipLaunchKernelGGL((ssg_fwd_dense<KS, KW, C, NW, TM>), dim3((unsigned)n_tiles * p.nimg), dim3(64 * NW), lds, st, p);
+  hipLaunchKernelGGL((ssg_fwd_dense<KS, KW, C, NW, TM, RAW>), dim3((unsigned)n_tiles * p.nimg), dim3(64 * NW), lds, st, p);
   return (int)hipGetLastError();
 }
 
@@ -1109,6 +1125,13 @@ int launch_fwd_dense(const DenseParams &p0, int ks, int kw, int C, hipStream_t s
   DenseParams p = p0;
   const bool tm = ks == 49 && p.tm[0] && p.tm_slots > 0 && p.row_scale && p.generalization && (p.nimg == 1 || p.tm[1]);
   if (!tm) p.tm_slots = 0;
+  if (p.raw) {   // the reference operator: raw distances accumulated into row-major rows, no row scales, no tile-major region
+    p.tm_slots = 0;
+    p.row_scale = nullptr;
+    p.strips = nullptr;
+    if (ks == 25) return launch_fwd_dense_t<25, 9, 3, 4, false, true>(p, p.max_tiles, st);
+    return launch_fwd_dense_t<49, 13, 3, 7, false, true>(p, p.max_tiles, st);
+  }
   if (ks == 25) return launch_fwd_dense_t<25, 9, 3, 4, false>(p, p.max_tiles, st);
   if (!tm) p.strips = nullptr;
   int rc = (tm && p.strips && p.max_strips > 0) ? launch_fwd_strip_t<49, 13, 3, 3>(p, st) : 0;

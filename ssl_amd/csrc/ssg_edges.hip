@@ -447,6 +447,69 @@ __global__ __launch_bounds__(256) void tile_group_flags(int *order_a, const int 
   order[k0] = first | (ok ? ORDER_FLAG : 0);
 }
 
+// ---- the reference operator's position list -> the engine's plan (ssg_compute_similarity[_backward] with many positions,
+// ssg_api.hip).  The caller's `pos` (mc (Y,X) pairs in any order, duplicates allowed) becomes a uint8 mask; the regular
+// builder makes edge list, rank map and plan from it in ITS row order (row-major); then everything that names a row is
+// relabelled to the CALLER's row numbers, so that the kernels read and write the caller's (mc, k_s^2) rows in place:
+//   pos_perm    perm[internal row] = the largest caller row at that pixel
+//   pos_dups    caller rows that lost that election (duplicates of a position): listed for a direct launch of their own
+//   pos_relabel rank map and the plan's sparse order: internal row -> caller row
+__global__ __launch_bounds__(256) void pos_to_mask(const int *pos, int mc, int Hp, int Wp, uint8_t *mask) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= mc) return;
+  const int Y = pos[2 * n], X = pos[2 * n + 1];
+  if ((unsigned)Y < (unsigned)Hp && (unsigned)X < (unsigned)Wp) mask[(size_t)Y * Wp + X] = 1;
+}
+
+__global__ __launch_bounds__(256) void pos_perm(const int *pos, int mc, int Hp, int Wp, const int *rank, int *perm) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= mc) return;
+  const int Y = pos[2 * n], X = pos[2 * n + 1];
+  if ((unsigned)Y >= (unsigned)Hp || (unsigned)X >= (unsigned)Wp) return;
+  const int r = rank[(size_t)Y * Wp + X];
+  if (r >= 0) atomicMax(&perm[r], n);
+}
+
+__global__ __launch_bounds__(256) void pos_dups(const int *pos, int mc, int Hp, int Wp, const int *rank, const int *perm,
+                                                int *dup, int *ndup) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= mc) return;
+  const int Y = pos[2 * n], X = pos[2 * n + 1];
+  if ((unsigned)Y >= (unsigned)Hp || (unsigned)X >= (unsigned)Wp) return;   // (a position outside the image: no row work)
+  const int r = rank[(size_t)Y * Wp + X];
+  if (r < 0 || perm[r] != n) dup[atomicAdd(ndup, 1)] = n;
+}
+
+__global__ __launch_bounds__(256) void pos_relabel(int *rank, size_t npix, const int *perm, int *order2, const int *plan,
+                                                   int capacity) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < npix) {
+    const int r = rank[i];
+    if (r >= 0) rank[i] = perm[r];
+  }
+  int ns = plan[0];
+  ns = ns < capacity ? ns : capacity;
+  if (i < (size_t)ns) {
+    const int e = order2[i];
+    order2[i] = (e & ORDER_FLAG) | perm[e & ORDER_MASK];
+  }
+}
+
+int launch_pos_to_mask(const int *pos, int mc, int Hp, int Wp, uint8_t *mask, hipStream_t st) {
+  hipLaunchKernelGGL(pos_to_mask, dim3((mc + 255) / 256), dim3(256), 0, st, pos, mc, Hp, Wp, mask);
+  return (int)hipGetLastError();
+}
+
+int launch_pos_relabel(const int *pos, int mc, int Hp, int Wp, int *rank, int *perm, int *dup, int *ndup, int *plan,
+                       int *order2, hipStream_t st) {
+  const unsigned g = (unsigned)((mc + 255) / 256);
+  hipLaunchKernelGGL(pos_perm, dim3(g), dim3(256), 0, st, pos, mc, Hp, Wp, rank, perm);
+  hipLaunchKernelGGL(pos_dups, dim3(g), dim3(256), 0, st, pos, mc, Hp, Wp, rank, perm, dup, ndup);
+  const size_t npix = (size_t)Hp * Wp, nthr = npix > (size_t)mc ? npix : (size_t)mc;
+  hipLaunchKernelGGL(pos_relabel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, rank, npix, perm, order2, plan, mc);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------ host ----
 static size_t n_order_tiles(int B, int H, int W) { return (size_t)B * ((H + OT - 1) / OT) * ((W + OT - 1) / OT); }
 // (sized for the smallest super-tile height, 4 rows)

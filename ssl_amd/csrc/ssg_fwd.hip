@@ -467,7 +467,9 @@ static int launch_fwd_tiled(const FwdParams &p, hipStream_t st) {
 // the second); without an order (reference operator, raw distances) the single variant alone in row order.
 template <class G>
 static int launch_fwd_pair(FwdParams p, hipStream_t st) {
-  const bool can_merge = p.order && !p.raw && fwd_lds_bytes<G, true>(p.C) <= 160 * 1024;
+  // (raw distances -- the reference operator -- take the same two variants when the caller brings a tile order: the
+  // operator's plan path, ssg_api.hip; without an order the single variant walks the rows as they come)
+  const bool can_merge = p.order && fwd_lds_bytes<G, true>(p.C) <= 160 * 1024;
   if (!can_merge) p.order = nullptr;
   if (can_merge) {
     const int rc = launch_fwd_tiled<G, true>(p, st);
@@ -481,7 +483,7 @@ int launch_fwd(const FwdParams &p_in, hipStream_t st) {
   if (p.ks == 25 && p.kw == 9) return launch_fwd_pair<Geo<25, 9, 5, 128>>(p, st);
   // (49,13): 5 jobs x 49 lanes in 256-lane workgroups; the merged variant needs 48 KB of LDS (3 workgroups
   // per CU), the single one 147 KB (groups that straddle tiles or images only)
-  if (p.ks == 49 && p.kw == 13 && p.order && !p.raw && fwd_lds_bytes<Geo<49, 13, 7, 256>, false>(p.C) <= 160 * 1024)
+  if (p.ks == 49 && p.kw == 13 && p.order && fwd_lds_bytes<Geo<49, 13, 7, 256>, false>(p.C) <= 160 * 1024)
     return launch_fwd_pair<Geo<49, 13, 7, 256>>(p, st);
   p.order = nullptr;  // the other geometries run in row order
   if (p.ks == 11 && p.kw == 5) return launch_fwd_tiled<Geo<11, 5, 4, 64>, false>(p, st);

@@ -1919,3 +1919,69 @@ def test_k49_materialising_step_without_tile_major_regions(dev):
     assert res[1][2] < res[0][2]
     assert float((res[0][0] - res[1][0]).abs().max() / res[1][0].abs().max()) <= 5e-6
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-4 * float(res[1][1].abs().max())
+
+
+@pytest.mark.parametrize("ks,kw,H,W,dens", [(25, 9, 120, 150, 0.35), (25, 9, 64, 200, 0.06), (49, 13, 90, 110, 0.5)])
+def test_reference_operator_plan_path_equals_direct_path(dev, ks, kw, H, W, dens):
+    """ssg_compute_similarity[_backward] with the plan built inside the call (many positions: rank map + dense/direct
+    plan from `pos`, buffers from the library's stream-ordered pool) against the direct kernels walking `pos`, on the
+    SAME inputs through the SAME reference-named C entry points: positions in shuffled order, some of them repeated,
+    `out` / `image_grads` pre-filled (both accumulate).  Raw distances rel 2e-6 (+ the pre-fill), gradients 1e-5 of their
+    maximum; the forward also against the fp64 oracle."""
+    from ssl_amd import _lib, synth
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    hp = ks // 2
+    rng = np.random.default_rng(ks * 1000 + H)
+    img = synth.natural_like(int(rng.integers(1 << 20)), H, W)
+    Hp, Wp = H + 2 * hp, W + 2 * hp
+    pad = np.pad(img, ((0, 0), (hp, hp), (hp, hp)), mode="reflect")
+    m = rng.random((H, W)) < dens
+    m[H // 3: H // 3 + 20, W // 4: W // 4 + 40] |= rng.random((20, 40)) < 0.8          # a block of dense tiles
+    ys, xs = np.nonzero(m)
+    pos = np.stack([ys + hp, xs + hp], 1).astype(np.int32)
+    pos = np.concatenate([pos, pos[rng.choice(len(pos), 37, replace=False)], pos[:5]])  # duplicates (some of them twice)
+    pos = pos[rng.permutation(len(pos))]
+    mc = len(pos)
+    image = T(pad, dev)
+    posd = torch.as_tensor(pos, device=dev)
+    base = torch.rand(mc, ks, ks, device=dev)
+    cot = torch.rand(mc, ks, ks, device=dev) - 0.3
+    gbase = torch.rand(3, Hp, Wp, device=dev)
+    res = {}
+    prev = L.ssg_set_operator_plan_threshold(1)
+    try:
+        for name, thr in (("plan", 1), ("direct", 0)):
+            L.ssg_set_operator_plan_threshold(thr)
+            out = base.clone()
+            _lib.check(L.ssg_compute_similarity(image.data_ptr(), posd.data_ptr(), out.data_ptr(), mc, ks, kw, Hp, Wp, 3, st))
+            g = gbase.clone()
+            _lib.check(L.ssg_compute_similarity_backward(image.data_ptr(), cot.data_ptr(), posd.data_ptr(), g.data_ptr(), mc,
+                                                         ks, kw, Hp, Wp, 3, st))
+            torch.cuda.synchronize()
+            res[name] = (out - base, g - gbase)
+    finally:
+        L.ssg_set_operator_plan_threshold(prev)
+    assert L.ssg_device_status(st) == 0
+    (dp, gp), (dd, gd) = res["plan"], res["direct"]
+    scale = float(dd.abs().max())
+    assert float((dp - dd).abs().max()) <= 3e-6 * scale + 2e-6, float((dp - dd).abs().max()) / scale   # (+ the pre-fill's ulp)
+    assert float((gp - gd).abs().max()) <= 1e-5 * float(gd.abs().max())
+    sel = rng.choice(mc, 48, replace=False)
+    want = orc.distance(img.astype(np.float64), pos[sel] - hp, ks, kw)
+    assert maxerr(dp[torch.as_tensor(sel, device=dev)].cpu(), want) <= 3e-6 * np.abs(want).max() + 2e-6
+    # the Python operator (autograd Function on the same entry points) with the plan path on
+    from ssl_amd import compute_similarity
+    prev = L.ssg_set_operator_plan_threshold(1)
+    try:
+        x = T(img, dev).requires_grad_(True)
+        q = compute_similarity(image=x, mask=torch.as_tensor(m.astype(np.float32), device=dev), psize=ks, ksize=kw)
+        n = int(m.sum())
+        c2 = torch.rand(n, ks, ks, device=dev)
+        q.backward(c2)
+        want = orc.distance(img.astype(np.float64), orc.mask_to_pos(m.astype(np.uint8)), ks, kw)
+        assert maxerr(q.detach().cpu(), want) <= 5e-6 * np.abs(want).max()      # (fp32 sums of up to 507 squares)
+        gref = orc.distance_backward(img.astype(np.float64), orc.mask_to_pos(m.astype(np.uint8)), ks, kw, c2.cpu().numpy().astype(np.float64))
+        assert maxerr(x.grad.cpu(), gref) <= 1e-5 * np.abs(gref).max()
+    finally:
+        L.ssg_set_operator_plan_threshold(prev)
