@@ -87,6 +87,10 @@ int ssg_device_status(ssg_stream_t stream);
  * positions forward 0.056 ms direct / 0.206 with the plan, backward 0.158 / 0.167; 18,417 positions forward 0.196 /
  * 0.231, backward 0.462 / 0.258.  Returns the previous threshold. */
 int ssg_set_operator_plan_threshold(int positions);
+/* The pool keeps what the largest call needed (mask, rank map, plan: ~24 bytes per padded pixel + 20 per position; the
+ * backward's scratch: 4 k_s^2 bytes per position) so that later calls allocate without a system call;
+ * ssg_operator_pool_trim() hands the unused part back to the driver (after the work that used it has finished). */
+int ssg_operator_pool_trim(void);
 int ssg_compute_similarity(const float *image, const int *pos, float *out,
                            int mc, int psize, int ksize, int height, int width,
                            int channel, ssg_stream_t stream);

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "ssg_last_status": (_i, []),
     "ssg_device_status": (_i, [_vp]),
     "ssg_set_operator_plan_threshold": (_i, [_i]),
+    "ssg_operator_pool_trim": (_i, []),
     "ssg_criteria_scratch_bytes": (_sz, []),
     "ssg_criteria_sums": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "ssg_criteria_grad": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),

@@ -1096,6 +1096,11 @@ int ssg_diffjpeg(const float *img, float *out, int B, int H, int W, const float 
   return launch_jpeg(img, out, B, H, W, quality_dev, quality, (hipStream_t)stream);
 }
 
+int ssg_operator_pool_trim(void) {
+  hipMemPool_t pool = op_pool();
+  return pool ? (int)hipMemPoolTrimTo(pool, 0) : 0;
+}
+
 int ssg_set_operator_plan_threshold(int positions) {
   const int prev = op_plan_from();
   g_op_plan_from.store(positions > 0 ? positions : 0x7fffffff, std::memory_order_relaxed);

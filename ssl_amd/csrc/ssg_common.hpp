@@ -164,6 +164,7 @@ struct FwdParams {
   int raw;  // 1: out += D (reference operator)   0: SSG epilogue
   int ks, kw;  // used by the generic kernel only
   int dbg;     // profiling ablations (0 in production): bit0 skip fill, bit1 skip compute, bit2 skip epilogue/store
+  int small;   // direct forward, set by its launcher: which variants of a (25,9) launch run (ssg_fwd.hip, small_call)
 };
 
 // How the backward kernel obtains G = dL/dD for a job.

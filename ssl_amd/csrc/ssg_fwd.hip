@@ -43,6 +43,14 @@ __device__ __forceinline__ void load_row(const float *tc, int rs, const float *z
 //                 loads and 17 KB instead of 40 KB of LDS per workgroup (3 instead of 2 waves per
 //                 SIMD).  Both variants are launched over the same job groups; a group runs in the
 //                 variant its geometry selects and exits at once in the other.
+// Small calls -- fewer jobs (rows x images) than fill the chip once at 5 x 5 offset blocks: Bernoulli-sparse and strided
+// masks, one image of the reference's per-image loop -- run Geo<25,9,3,256>: 3 x 3 blocks, 81 lanes per job, 3 jobs per
+// 256-lane workgroup, every group in tile order.  17 % more lane-operations per job (121 LDS dwords feed 9 x 81 pairs
+// instead of 169 feeding 25 x 81) on 3.2 times the lanes: measured 0.105 -> 0.066 ms for 2 x 2,627 jobs (Bernoulli 1 %
+// of 4 x 256 x 256), neutral at 20 k jobs, slower above.
+constexpr int SMALL_CALL_JOBS = 8192;
+__device__ __forceinline__ bool small_call(int njobs) { return njobs <= SMALL_CALL_JOBS; }
+
 template <class G, bool MERGED>
 __device__ __forceinline__ bool fwd_tiled_group(const FwdParams &p, int grp) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
@@ -81,7 +89,12 @@ __device__ __forceinline__ bool fwd_tiled_group(const FwdParams &p, int grp) {
     if (k0 >= nrows) return false;                       // padding-only group
     mergeable = (p.order[k0] & ORDER_FLAG) != 0;         // one wave-uniform load decides the variant
   }
-  if (mergeable != MERGED) return false;
+  // p.small: 0 = this launch is the only set of variants; 1 = this variant takes every group whatever its flag (the
+  // small-call variant launched alone); 2 = regular and small-call variants were both launched and the device-side job
+  // count picks (small_call() below)
+  constexpr bool SMALLV = G::BS < 5 && G::KS == 25;
+  if (p.small == 2 && small_call(nrows * p.nimg) != SMALLV) return false;
+  if (!(SMALLV && p.small != 0) && mergeable != MERGED) return false;
 
   if (tid < JOBS) {
     int row = -1, which = 0;
@@ -471,6 +484,24 @@ static int launch_fwd_pair(FwdParams p, hipStream_t st) {
   // operator's plan path, ssg_api.hip; without an order the single variant walks the rows as they come)
   const bool can_merge = p.order && fwd_lds_bytes<G, true>(p.C) <= 160 * 1024;
   if (!can_merge) p.order = nullptr;
+  p.small = 0;
+  if constexpr (G::KS == 25 && G::KW == 9) {
+    // the small-call variant (SMALL_CALL_JOBS): alone when the host's bound on the jobs says so, together with the
+    // regular ones -- the device-side count picks -- while the bound is within 8x of it (a generous capacity), not at all
+    // beyond (C2's 155 k jobs: no third launch)
+    static int mode = -1;   // SSG_FWD_SMALL=0: never (A/B measurements)
+    if (mode < 0) {
+      const char *e = getenv("SSG_FWD_SMALL");
+      mode = e ? (atoi(e) != 0) : 1;
+    }
+    const long bound = (long)p.n_host * p.nimg;
+    if (mode && bound <= 8L * SMALL_CALL_JOBS) {
+      using GS3 = Geo<25, 9, 3, 256>;
+      p.small = bound <= SMALL_CALL_JOBS ? 1 : 2;
+      const int rc = launch_fwd_tiled<GS3, false>(p, st);
+      if (rc || p.small == 1) return rc;
+    }
+  }
   if (can_merge) {
     const int rc = launch_fwd_tiled<G, true>(p, st);
     if (rc) return rc;

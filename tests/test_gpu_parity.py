@@ -1985,3 +1985,5 @@ def test_reference_operator_plan_path_equals_direct_path(dev, ks, kw, H, W, dens
         assert maxerr(x.grad.cpu(), gref) <= 1e-5 * np.abs(gref).max()
     finally:
         L.ssg_set_operator_plan_threshold(prev)
+    torch.cuda.synchronize()
+    assert L.ssg_operator_pool_trim() == 0
