@@ -120,7 +120,10 @@ __device__ __forceinline__ void pin_block(float (&v)[R][N]) {
 // of 4) and the tile kernel skips them; every other consumer masks the bit off (dense_tile_id).
 constexpr int STRIP_ROWS = 36;
 constexpr int TILE_IN_STRIP = 1 << 30;
-__device__ __forceinline__ int dense_tile_id(int listed) { return listed & ~TILE_IN_STRIP; }
+// 8 x 32 tiles holding more than 128 edge pixels (three or four 64-slot chunks in the forward's edge stage): the dense
+// forward runs them in its four-chunk instantiation, every other tile in the two-chunk one (ssg_dense.hip)
+constexpr int TILE_HUGE = 1 << 29;
+__device__ __forceinline__ int dense_tile_id(int listed) { return listed & ~(TILE_IN_STRIP | TILE_HUGE); }
 __device__ __forceinline__ int dense_tile_count(const int *hdr) { return hdr[0] + hdr[2]; }
 __device__ __forceinline__ int dense_tile_at(const int *hdr, const int *tiles, int n_super, int tslot) {
   const int nh = hdr[0];

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void plan_count(const int *rank, int B, int H,
     }
     dflag[st] = dense;
     if (dense) {   // heavy tiles from the front, light ones from the back (dense_tile_at, ssg_common.hpp)
-      if (n > 64) dense_ids[atomicAdd(&plan[1], 1)] = st;
+      if (n > 64) dense_ids[atomicAdd(&plan[1], 1)] = st | (sty == OT && n > 128 ? TILE_HUGE : 0);
       else dense_ids[B * sy_n * sx_n - 1 - atomicAdd(&plan[3], 1)] = st;
     }
   }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void plan_from_tile_counts(int B, int H, int W
   const int dense = thr > 0 && n >= thr;
   dflag[st] = dense;
   if (dense) {   // heavy tiles from the front, light ones from the back (dense_tile_at, ssg_common.hpp)
-    if (n > 64) dense_ids[atomicAdd(&plan[1], 1)] = st;
+    if (n > 64) dense_ids[atomicAdd(&plan[1], 1)] = st | (n > 128 ? TILE_HUGE : 0);
     else dense_ids[B * sy_n * sx_n - 1 - atomicAdd(&plan[3], 1)] = st;
     for (int k = 0; k < nk; ++k) c[k] = 0;   // its rows belong to the dense kernels: not in the sparse order
   }
