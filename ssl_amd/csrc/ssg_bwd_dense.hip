@@ -151,9 +151,27 @@ struct DenseBwdGeo {
 // lanes keep the dense forward's fixed pixel map, read e_sr / e_gt of one offset as aligned 256-byte runs seven
 // steps ahead, and form G = -(s k)(g - dot) themselves (criteria_elem's g, bit for bit what ssg_rows_tm summed into
 // dot) instead of reading G rows that ssg_grad_rows would have had to write.
-template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 : 1, RG == 8 ? 2 : 1))) void ssg_bwd_dense(DenseBwdParams p) {
+// SPL (tile-major k_s 49 only): TWO waves per tile in one workgroup, the lane map unchanged, the work split by ROLE --
+//   role 0: channels 0 and 1 (the packed pair) of both ends of every pair, G formation (tile-major loads, field
+//           writes), the border sums swb;
+//   role 1: channel 2, the W stage (horizontal sums, vertical prefix, prefix rows to LDS).
+// Every LDS array stays what it was (the bands are per channel, so each role flushes and refills its own); the two
+// waves meet at ONE s_barrier per offset step: G[.,t] (role 0, end of step t-2) -> prefix rows (role 1, end of step
+// t-1) -> W (both, top of step t).  Each role's registers are its own (≈ 190 / ≈ 110 instead of 256 + 138 parked in
+// AGPRs), so a SIMD holds two waves.  ROLE 2 = one wave does everything (the other instantiations).
+template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM, bool SPL, int ROLE>
+__device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   using G = DenseBwdGeo<KS, KW, C, TY, RG>;
+  static_assert(SPL == (ROLE != 2) && (!SPL || (TM && RG == 4)), "roles: tile-major k_s 49 instantiation only");
+  constexpr bool DO_A = ROLE != 1, DO_B = ROLE != 0;   // channels (0,1) / channel 2
+  constexpr bool DO_G = ROLE != 1, DO_W = ROLE != 0;   // G formation + border sums / W stage
+  // LDS hand-over between the steps' stages: one wave = program order; two waves = LDS writes retired, then s_barrier
+  // (not __syncthreads(): it would also drain the tile-major loads that are seven steps ahead)
+  auto stage_sync = [] {
+    if constexpr (SPL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __builtin_amdgcn_wave_barrier();
+  };
+  auto chan_on = [](int c) { return c < 2 ? DO_A : DO_B; };
   constexpr int RR = G::RR, RMASK = RR - 1, BRS = G::BRS;
   constexpr int TX = G::TX, HP = G::HP, HK = G::HK, HALO = G::HALO, P = G::P;
   constexpr int UW = G::UW, NPX = G::NPX, NPXP = G::NPXP, RW = G::RW, RH = G::RH, RWS = G::RWS;
@@ -175,7 +193,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   int *elist = (int *)imgb;  // [NE_MAX][2] (field offset, row): prologue only, the image band is filled afterwards
   static_assert(2 * G::NE_MAX <= 2 * RR * BRS, "edge list aliases the bands");
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int tslot = blockIdx.x;
   if (tslot >= dense_tile_count(p.n_dense)) return;
   if (p.tm_slots > 0 && tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host)) != TM) return;
@@ -222,9 +240,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     n_e += __popcll(bal);
   }
   if (n_e <= 64 * NCH_LO || n_e > 64 * NCH) return;
-  for (int i = lane; i < 2 * FSZ + 4; i += 64) fld[i] = 0.f;  // fields (pads stay 0) and prefix rows 0
-  for (int i = lane; i < RR * BRS; i += 64) grb[i] = 0.f;
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (DO_G) for (int i = lane; i < 2 * FSZ + 4; i += 64) fld[i] = 0.f;  // fields (pads stay 0) and prefix rows 0
+  if constexpr (DO_W) for (int i = lane; i < RR * BRS; i += 64) grb[i] = 0.f;
+  stage_sync();
 
   int epos[NCH];
   const float *gp[NCH];
@@ -235,7 +253,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   float tdot[NCH];
 #pragma unroll
   for (int ck = 0; ck < NCH; ++ck) {
-    if constexpr (TM) {
+    if constexpr (!DO_G) {
+      epos[ck] = DUMMY;
+      erow[ck] = 0;
+      gp[ck] = nullptr;
+      tsa[ck] = tsb[ck] = TmScale{0.f, 0.f};
+      tdot[ck] = 0.f;
+    } else if constexpr (TM) {
       const int r = tm_row[ck];
       epos[ck] = tm_pos[ck];
       erow[ck] = r >= 0 ? r : 0;
@@ -378,8 +402,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     for (int i = 0; i < NPX; ++i) {
       int gx = reflect_idx(tx0 - HK + NPX * g + i, W);
       gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-      iuA[i] = f2{src[((size_t)0 * H + gy) * W + gx], src[((size_t)1 * H + gy) * W + gx]};
-      iuB[i] = src[((size_t)2 * H + gy) * W + gx];
+      iuA[i] = DO_A ? f2{src[((size_t)0 * H + gy) * W + gx], src[((size_t)1 * H + gy) * W + gx]} : f2{0.f, 0.f};
+      iuB[i] = DO_B ? src[((size_t)2 * H + gy) * W + gx] : 0.f;
     }
   }
   // image band rows: global -> registers -> LDS (lane = region column)
@@ -392,7 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       int gx = reflect_idx(tx0 - HALO + (col < RW ? col : 0), W);
       gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
 #pragma unroll
-      for (int c = 0; c < C; ++c) v[c][k] = src[((size_t)c * H + gy) * W + gx];
+      for (int c = 0; c < C; ++c) v[c][k] = chan_on(c) ? src[((size_t)c * H + gy) * W + gx] : 0.f;
     }
   };
   auto store_img_row = [&](int rho, const float (&v)[C][CPL]) {
@@ -402,7 +426,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       const int col = lane + 64 * k;
       if (col < RW) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) dst[c * RWS + col] = v[c][k];
+        for (int c = 0; c < C; ++c)
+          if (chan_on(c)) dst[c * RWS + col] = v[c][k];
       }
     }
   };
@@ -420,6 +445,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
         const bool ok = yok && gx >= 0 && gx < W;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
+          if (!chan_on(c)) continue;
           const float v = brow[c * RWS + col];
           brow[c * RWS + col] = 0.f;
           if (ok && v != 0.f && !SSG_DBG(p, 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
@@ -464,7 +490,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   float tea[TM ? TMD : 1][NCH], teb[TM ? TMD : 1][NCH];
   const float *tma = nullptr, *tmb = nullptr;
   float tw1 = 0.f, tw2 = 0.f, tkf = 0.f;
-  if constexpr (TM) {
+  if constexpr (TM && DO_G) {
     tma = p.tm[0] + (size_t)tslot * P * TM_PX;   // (wave-uniform: scalar base + lane offset addressing)
     tmb = p.tm[1] + (size_t)tslot * P * TM_PX;
     const float invM = 1.f / ((float)nrows * (float)P);
@@ -476,7 +502,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   }
   auto tm_load = [&](auto slot_c, int q) {   // offset q (linear) -> ring slot
     constexpr int sl = decltype(slot_c)::value;
-    if constexpr (TM) {
+    if constexpr (TM && DO_G) {
 #pragma unroll
       for (int ck = 0; ck < NCH; ++ck) {
         tea[sl][ck] = __builtin_nontemporal_load(tma + (size_t)q * TM_PX + ck * 64 + lane);
@@ -486,7 +512,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   };
   if constexpr (TM) {
     static_for(std::make_integer_sequence<int, TMD>{}, [&](auto sc) { tm_load(sc, qy0 * KS + decltype(sc)::value); });
-  } else {
+  } else if constexpr (DO_G) {
     load_group(qy0, 0, gbuf[0]);
     load_group(qy0, 1, gbuf[1]);
     load_last(qy0);
@@ -495,6 +521,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   // (tile-major rows: G is formed here; `q_refill` = the linear offset TMD steps ahead that refills the ring slot)
   auto x_put = [&](auto qx_c, int qyi, float *f, int q_refill = 0) {
     constexpr int qxi = decltype(qx_c)::value, grp = qxi / 4, gj = qxi % 4;
+    if constexpr (!DO_G) return;
 #pragma unroll
     for (int ck = 0; ck < NCH; ++ck) {
       float gv;
@@ -515,6 +542,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     }
     if constexpr (TM) tm_load(std::integral_constant<int, qxi % TMD>{}, q_refill);
   };
+  // Two waves (SPL): every hand-over crosses an s_barrier, and a read issued right behind the barrier would put its
+  // whole LDS round trip on the step's critical path.  The stages therefore run ONE offset further ahead (LAG): G[., t]
+  // at the end of step t-3, its prefix rows during step t-2, and both waves fetch W of offset t in the middle of step
+  // t-1 (behind the body, consumed a step later from registers): no step waits for data written in the step before.
+  // Two field copies still suffice (F_t: written end of t-3, read top of t-2; P_t: written end of t-2, read in t-1).
+  constexpr int LAG = SPL ? 1 : 0;
+  static_assert(!LAG || !REGW, "the lagged schedule reads W from LDS prefix rows");
+  float Wv[NPX];   // (LAG: W of the offset the next step consumes)
   // The work of one offset t is spread over three steps so that a step waits for LDS ONCE:
   //   end of step t-2 : G[., t] into field copy t&1                       (x_put)
   //   step t-1        : top: read the field; horizontal sums + prefix; end: prefix rows to copy t&1   (x_stage)
@@ -525,9 +560,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     float *f0 = fld + ((qy0 * KS) & 1) * FSZ, *f1 = fld + (((qy0 * KS) & 1) ^ 1) * FSZ;
     x_put(std::integral_constant<int, 0>{}, qy0, f0, qy0 * KS + TMD);
     x_put(std::integral_constant<int, 1>{}, qy0, f1, qy0 * KS + TMD + 1);
-    __builtin_amdgcn_wave_barrier();
-    x_stage(std::integral_constant<int, (-HK > 0 ? -HK : 0)>{}, std::integral_constant<int, HK>{}, f0);
+    stage_sync();
+    if constexpr (DO_W) x_stage(std::integral_constant<int, (-HK > 0 ? -HK : 0)>{}, std::integral_constant<int, HK>{}, f0);
+    if constexpr (LAG) {   // one offset more in flight (see the step schedule below): P(1), F(2), and W of offset 0
+      if constexpr (DO_W) x_stage(std::integral_constant<int, (-HK > -1 ? -HK : -1)>{}, std::integral_constant<int, HK>{}, f1);
+      stage_sync();
+      x_put(std::integral_constant<int, 2>{}, qy0, f0, qy0 * KS + TMD + 2);
+      const int ylo0 = (-HK > -qy0) ? -HK : -qy0, yhi0 = (HK < KS - 1 - qy0) ? HK : KS - 1 - qy0;
+      int pa0, pb0;
+      prefix_rows(ylo0, yhi0, pa0, pb0);
+      y_read(f0, pa0, pb0, Wv);
+    }
     step_fence();
+    if constexpr (SPL) stage_sync();
   }
 
 #pragma unroll 1
@@ -547,6 +592,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     const bool rowfull = ylo == -HK && yhi == HK;
     if constexpr (REGW) cut_rows(ylo, yhi, lpos, lneg, mpos, mneg);
     else prefix_rows(ylo, yhi, pa, pb);
+    int pan = 0, pbn = 0;   // LAG: the row's last step fetches W of the next row's first offset
+    if constexpr (LAG) prefix_rows((-HK > -qyn) ? -HK : -qyn, (HK < KS - 1 - qyn) ? HK : KS - 1 - qyn, pan, pbn);
     float *fe = fld + (qyi & 1) * FSZ, *fo = fld + ((qyi & 1) ^ 1) * FSZ;  // copies of the even / odd q_x of this row
     const int slr = (r + qyi) & RMASK;
     const float *ib = imgb + slr * BRS + NPX * g;
@@ -555,8 +602,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
     float wB[NPX], grB[NPX];
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
-      wA[i] = f2{ib[i], ib[RWS + i]};
-      wB[i] = ib[2 * RWS + i];
+      wA[i] = DO_A ? f2{ib[i], ib[RWS + i]} : f2{0.f, 0.f};
+      wB[i] = DO_B ? ib[2 * RWS + i] : 0.f;
       grA[i] = f2{0.f, 0.f};
       grB[i] = 0.f;
     }
@@ -564,10 +611,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       constexpr int qxi = decltype(qc)::value;
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
       constexpr int grp = qxi / 4, gj = qxi % 4;
-      constexpr int qxn = (qxi + 1) % KS, qx2 = (qxi + 2) % KS;  // offsets prepared during this step
+      constexpr int qxn = (qxi + 1 + LAG) % KS, qx2 = (qxi + 2 + LAG) % KS;  // offsets prepared during this step (P stage, G)
       constexpr int nlo = (-HK > -qxn) ? -HK : -qxn, nhi = (HK < KS - 1 - qxn) ? HK : KS - 1 - qxn;
       constexpr int M0 = HK - nhi, M1 = HOUT - 1 + HK - nlo;
       float *fc = (qxi & 1) ? fo : fe, *fn = (qxi & 1) ? fe : fo;  // (k_s odd: the next row's offsets continue the alternation)
+      float *fP = LAG ? fc : fn, *fG = LAG ? fn : fc;              // copies of the offsets qxn / qx2
       // G prefetch, two groups ahead: group grp+2 (of the next row past the end) replaces group grp, whose last
       // value went to LDS a step ago; the row's last offset on its own
       if constexpr (gj == 2 && grp < NG) {
@@ -576,32 +624,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       }
       if constexpr (qxi == KS - 2) load_last(qyn);
       // ---- top: every LDS read of the step ----
-      float Wv[NPX], v[HOUT + 2 * HK], fl[C], wn[C];
-      if constexpr (REGW) {
+      float v[HOUT + 2 * HK], fl[C], wn[C];
+      if constexpr (LAG) {
+      } else if constexpr (REGW) {
         w_regs(rowfull, lpos, lneg, mpos, mneg, Wv);
       } else {
 #pragma unroll
         for (int i = 0; i < NPX; ++i) Wv[i] = fc[pb + i] - fc[pa + i];
       }
+      if constexpr (DO_W) {
 #pragma unroll
-      for (int m = M0; m <= M1; ++m) v[m] = fn[hsrc + m];
+        for (int m = M0; m <= M1; ++m) v[m] = fP[hsrc + m];
+      }
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        fl[c] = gb[c * RWS + qxi];
-        wn[c] = (qxi + 1 < KS) ? ib[c * RWS + qxi + NPX] : 0.f;
+        fl[c] = chan_on(c) ? gb[c * RWS + qxi] : 0.f;
+        wn[c] = (qxi + 1 < KS && chan_on(c)) ? ib[c * RWS + qxi + NPX] : 0.f;
       }
       // ---- both ends of every pair (u, u+q) ----
       constexpr bool xborder = xlo > -HK || xhi < HK;
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
         const float Wi = Wv[i];
-        if constexpr (xborder) swb[i] += Wi;
-        else swb[i] = __builtin_fmaf(Wi, ymask, swb[i]);
+        if constexpr (DO_G) {
+          if constexpr (xborder) swb[i] += Wi;
+          else swb[i] = __builtin_fmaf(Wi, ymask, swb[i]);
+        }
         const int sl = (i + qxi) % NPX;
-        const float dB = iuB[i] - wB[sl];
-        guB[i] = __builtin_fmaf(Wi, dB, guB[i]);
-        grB[sl] = __builtin_fmaf(-Wi, dB, grB[sl]);
-        if constexpr (RG == 4) {   // measured: packed 2.27 -> 2.06 ms for (49,13); 0.31 -> 0.33 ms for (25,9), which stays scalar
+        if constexpr (DO_B) {
+          const float dB = iuB[i] - wB[sl];
+          guB[i] = __builtin_fmaf(Wi, dB, guB[i]);
+          grB[sl] = __builtin_fmaf(-Wi, dB, grB[sl]);
+        }
+        if constexpr (!DO_A) {
+        } else if constexpr (RG == 4) {   // measured: packed 2.27 -> 2.06 ms for (49,13); 0.31 -> 0.33 ms for (25,9), which stays scalar
           const f2 Wi2 = f2{Wi, Wi};
           const f2 dA = iuA[i] - wA[sl];
           guA[i] = __builtin_elementwise_fma(Wi2, dA, guA[i]);
@@ -614,60 +670,82 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
           grA[sl].y = __builtin_fmaf(-Wi, d1, grA[sl].y);
         }
       }
+      // ---- LAG: W of the next offset, fetched behind the body and subtracted at the end of the step ----
+      float wra[NPX], wrb[NPX];
+      if constexpr (LAG) {
+        const int pa1 = qxi + 1 < KS ? pa : pan, pb1 = qxi + 1 < KS ? pb : pbn;
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+          wrb[i] = fn[pb1 + i];
+          wra[i] = fn[pa1 + i];
+        }
+      }
       // ---- next offset: horizontal sums over its column taps, vertical prefix ----
       float out[HOUT];
-      window_sums<HOUT, HK - nhi, HK - nlo>(v, out);
-      if constexpr (REGW && HOUT == 5) {
-        dpp_prefix8x5(out);
-      } else {
+      if constexpr (DO_W) {
+        window_sums<HOUT, HK - nhi, HK - nlo>(v, out);
+        if constexpr (REGW && HOUT == 5) {
+          dpp_prefix8x5(out);
+        } else {
 #pragma unroll
-        for (int i = 0; i < HOUT; ++i) {
-          out[i] = __builtin_fmaf(dpp_row_shr<1>(out[i]), m1, out[i]);
-          if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
-          if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
+          for (int i = 0; i < HOUT; ++i) {
+            out[i] = __builtin_fmaf(dpp_row_shr<1>(out[i]), m1, out[i]);
+            if constexpr (TY > 2) out[i] = __builtin_fmaf(dpp_row_shr<2>(out[i]), m2, out[i]);
+            if constexpr (TY > 4) out[i] = __builtin_fmaf(dpp_row_shr<4>(out[i]), m4, out[i]);
+          }
         }
       }
       // ---- end: every LDS write of the step ----
-      if constexpr (REGW) {
+      if constexpr (!DO_W) {
+      } else if constexpr (REGW) {
 #pragma unroll
         for (int i = 0; i < HOUT; ++i) wout[i] = out[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < HOUT; ++i) fn[hdst[i]] = out[i];
+        for (int i = 0; i < HOUT; ++i) fP[hdst[i]] = out[i];
       }
       // region column NPX*g + qxi of this band row is complete: to the band; the window moves on
       {
         constexpr int s0 = qxi % NPX;
-        gb[qxi] = fl[0] + grA[s0].x;
-        gb[RWS + qxi] = fl[1] + grA[s0].y;
-        gb[2 * RWS + qxi] = fl[2] + grB[s0];
-        grA[s0] = f2{0.f, 0.f};
-        grB[s0] = 0.f;
-        if constexpr (qxi + 1 < KS) {
-          wA[s0] = f2{wn[0], wn[1]};
-          wB[s0] = wn[2];
+        if constexpr (DO_A) {
+          gb[qxi] = fl[0] + grA[s0].x;
+          gb[RWS + qxi] = fl[1] + grA[s0].y;
+          grA[s0] = f2{0.f, 0.f};
+          if constexpr (qxi + 1 < KS) wA[s0] = f2{wn[0], wn[1]};
+        }
+        if constexpr (DO_B) {
+          gb[2 * RWS + qxi] = fl[2] + grB[s0];
+          grB[s0] = 0.f;
+          if constexpr (qxi + 1 < KS) wB[s0] = wn[2];
         }
       }
-      x_put(std::integral_constant<int, qx2>{}, qxi + 2 < KS ? qyi : qyn, fc,
-            (qxi + 2 < KS && qx2 + TMD < KS) ? rq0 + qx2 + TMD : (qxi + 2 < KS ? rq1 + qx2 + TMD - KS : rq1 + qx2 + TMD));
+      x_put(std::integral_constant<int, qx2>{}, qxi + 2 + LAG < KS ? qyi : qyn, fG,
+            (qxi + 2 + LAG < KS && qx2 + TMD < KS) ? rq0 + qx2 + TMD : (qxi + 2 + LAG < KS ? rq1 + qx2 + TMD - KS : rq1 + qx2 + TMD));
+      if constexpr (LAG) {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) Wv[i] = wrb[i] - wra[i];
+      }
       // (the accumulators of the lane's own pixels pass through an empty asm: they are not read again before
       // the end of the sweep, and hipcc otherwise sinks their FMAs below all k_s steps, keeping every step's
       // W and differences alive: 1,000 spilled registers)
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
-        asm volatile("" : "+v"(guA[i]));
-        asm volatile("" : "+v"(guB[i]));
+        if constexpr (DO_A) asm volatile("" : "+v"(guA[i]));
+        if constexpr (DO_B) asm volatile("" : "+v"(guB[i]));
       }
-      pin_row<NPX>(swb);
+      if constexpr (DO_G) pin_row<NPX>(swb);
       step_fence();
+      if constexpr (SPL) stage_sync();
     });
     // the row's last NPX-1 columns
 #pragma unroll
     for (int i = 1; i < NPX; ++i)
     {
-      gb[KS - 1 + i] += grA[(i + KS - 1) % NPX].x;
-      gb[RWS + KS - 1 + i] += grA[(i + KS - 1) % NPX].y;
-      gb[2 * RWS + KS - 1 + i] += grB[(i + KS - 1) % NPX];
+      if constexpr (DO_A) {
+        gb[KS - 1 + i] += grA[(i + KS - 1) % NPX].x;
+        gb[RWS + KS - 1 + i] += grA[(i + KS - 1) % NPX].y;
+      }
+      if constexpr (DO_B) gb[2 * RWS + KS - 1 + i] += grB[(i + KS - 1) % NPX];
     }
     __builtin_amdgcn_wave_barrier();
     flush_row(r0 + qyi);
@@ -679,11 +757,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
   // ---- the lane's own pixels: + I * sum_q V_q (Box(sum_b) - sum of the border W_q), then to HBM ----
   float vbox[NPX];
   {
+    if constexpr (DO_G) {
 #pragma unroll
-    for (int ck = 0; ck < NCH; ++ck) fld[epos[ck]] = (blockIdx.y == 0) ? p.sum_b[erow[ck]] : 0.f;
-    __builtin_amdgcn_wave_barrier();
-    x_stage(std::integral_constant<int, -HK>{}, std::integral_constant<int, HK>{}, fld);
-    __builtin_amdgcn_wave_barrier();
+      for (int ck = 0; ck < NCH; ++ck) fld[epos[ck]] = (blockIdx.y == 0) ? p.sum_b[erow[ck]] : 0.f;
+    }
+    stage_sync();
+    if constexpr (DO_W) x_stage(std::integral_constant<int, -HK>{}, std::integral_constant<int, HK>{}, fld);
+    if constexpr (SPL && DO_G) {   // the border sums for the other role (the gradient band is flushed: scratch)
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) grb[64 * i + lane] = swb[i];
+    }
+    stage_sync();
+    if constexpr (SPL && !DO_G) {
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) swb[i] = grb[64 * i + lane];
+    }
     if constexpr (REGW) {
       w_regs(true, 0, 0, 0.f, 0.f, vbox);
     } else {
@@ -705,11 +793,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG == 8 ? 2 
       const float vt = vbox[i] - swb[i];
 #pragma unroll
       for (int c = 0; c < C; ++c) {
+        if (!chan_on(c)) continue;
         const float iuc = c == 0 ? iuA[i].x : c == 1 ? iuA[i].y : iuB[i], guc = c == 0 ? guA[i].x : c == 1 ? guA[i].y : guB[i];
         const float v = __builtin_fmaf(iuc, vt, guc);
         if (ok && v != 0.f && !SSG_DBG(p, 8)) grad_add(p.grad, p.gfix, (((size_t)b * C + c) * H + gy) * W + gx, 2.f * v, gsc);
       }
     }
+  }
+}
+
+template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM = false, bool SPL = false>
+__global__ __launch_bounds__(SPL ? 128 : 64)
+__attribute__((amdgpu_waves_per_eu((RG == 8 || SPL) ? 2 : 1, (RG == 8 || SPL) ? 2 : 1))) void ssg_bwd_dense(DenseBwdParams p) {
+  if constexpr (!SPL) {
+    bwd_dense_body<KS, KW, C, TY, NCH, RG, TM, false, 2>(p);
+  } else if (threadIdx.x < 64) {
+    bwd_dense_body<KS, KW, C, TY, NCH, RG, TM, true, 0>(p);
+  } else {
+    bwd_dense_body<KS, KW, C, TY, NCH, RG, TM, true, 1>(p);
   }
 }
 
@@ -719,14 +820,14 @@ bool dense_bwd_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 &&
 // qsplit 0: the grid carries this many offset-row parts per tile, the device uses 1 .. QSPLIT_AUTO_MAX of them
 constexpr int QSPLIT_AUTO_MAX = 5;
 
-template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM = false>
+template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM = false, bool SPL = false>
 static int launch_one(const DenseBwdParams &p, int n_tiles, hipStream_t st) {
   using G = DenseBwdGeo<KS, KW, C, TY, RG>;
   if (n_tiles <= 0) return 0;
   static std::atomic<unsigned long long> lds_set{0};
-  if (const int rc = ensure_dynamic_lds(ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM>, (int)G::lds_bytes(), lds_set)) return rc;
-  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM>),
-                     dim3((unsigned)n_tiles, (unsigned)(p.qsplit > 0 ? p.qsplit : QSPLIT_AUTO_MAX), G::NHALF), dim3(64),
+  if (const int rc = ensure_dynamic_lds(ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM, SPL>, (int)G::lds_bytes(), lds_set)) return rc;
+  hipLaunchKernelGGL((ssg_bwd_dense<KS, KW, C, TY, NCH, RG, TM, SPL>),
+                     dim3((unsigned)n_tiles, (unsigned)(p.qsplit > 0 ? p.qsplit : QSPLIT_AUTO_MAX), G::NHALF), dim3(SPL ? 128 : 64),
                      G::lds_bytes(), st, p);
   return (int)hipGetLastError();
 }
@@ -754,7 +855,8 @@ int launch_bwd_dense(const DenseBwdParams &p0, int ks, int kw, int C, hipStream_
   const bool tm = ks == 49 && p.tm[0] && p.tm[1] && p.row_scale && p.dot && p.tm_slots > 0;
   if (!tm) p.tm_slots = 0;
   if (ks == 49) {
-    int rc = tm ? launch_one<49, 13, 3, 4, 2, 4, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st) : 0;
+    static const bool split = !(getenv("SSG_BWD_TM_SPLIT") && atoi(getenv("SSG_BWD_TM_SPLIT")) == 0);
+    int rc = !tm ? 0 : split ? launch_one<49, 13, 3, 4, 2, 4, true, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st) : launch_one<49, 13, 3, 4, 2, 4, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st);
     if (!rc) rc = launch_one<49, 13, 3, 4, 2, 4, false>(p, p.max_tiles, st);
     return rc;
   }
