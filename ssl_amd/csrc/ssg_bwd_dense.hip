@@ -117,7 +117,10 @@ struct DenseBwdGeo {
   static constexpr int NPXP = RG == 8 ? NPX : ((NPX + 1) & ~1);
   static constexpr int RR = 64 / RG, NHALF = UH / RR;         // U-rows per wave, waves per tile
   static constexpr int RW = UWP + KS - 1, RH = UH + KS - 1;   // gradient / image region
-  static constexpr int RWS = RW | 1;                          // channel stride inside a band row
+  // channel stride inside a band row.  RG = 4 (k_s 49): RWS = 92, BRS = 276 = 20 (mod 32) -- the band accesses of a
+  // step (lane (r, g): row slot (r + q_y) & 15, column 11 g + q_x) then fall on 32 different banks per half-wave; with
+  // the odd stride 93 (BRS = 23 mod 32) every one of them was a two-way conflict (27 % of the kernel's LDS cycles).
+  static constexpr int RWS = (RG == 4 && (3 * RW) % 32 == 20) ? RW : (RW | 1);
   // band row stride: RG = 4: C odd strides; RG = 8: = 4 (mod 32), the 8 slots x 4 groups (5 floats apart) of a
   // half-wave (lane = 8 * group + row) on 32 different banks
   static constexpr int BRS = REGW ? ((C * RWS - 4 + 31) / 32 * 32 + 4) : (RG == 8 ? ((C * RWS - 8 + 15) / 16 * 16 + 8) : C * RWS);
@@ -129,10 +132,15 @@ struct DenseBwdGeo {
   static constexpr int GQS_MIN = (HG * HOUT > UW ? HG * HOUT : UW) + 2 * HK;
   static constexpr int GQS_RES = TY == 8 ? 20 : 8;
   static constexpr int GQS = GQS_MIN + ((GQS_RES - GQS_MIN % 32) + 32) % 32;
-  static constexpr int PS = RG * NPXP;                        // prefix row
+  static constexpr int PS = RG * NPXP;                        // W row
+  // RG = 4: the rows a lane can need -- the vertical window of a U-row covers tile rows [a, bb] with a = 0 or bb = TY-1
+  // (k_w - 1 >= 2 TY: it is at least TY rows long even when cut), so W is a prefix P_1 .. P_TY (rows 0 .. TY-1) or a
+  // suffix S_a = P_TY - P_a (rows TY .. 2TY-2): ONE row per lane instead of the difference of two prefix rows
+  // (round 4: -22 of a step's 73 LDS dwords per lane pair, -11 subtractions per role)
+  static constexpr int WROWS = 2 * TY - 1;
   // one field + its prefix rows (two copies: steps alternate); RG = 8 keeps the prefix in registers: no rows
   // (+4: the copy's last word is a dummy that absorbs the writes of lanes without an edge pixel / past U)
-  static constexpr int FSZ = TY * GQS + (REGW ? 0 : (TY + 1) * PS) + 4;
+  static constexpr int FSZ = TY * GQS + (REGW ? 0 : WROWS * PS) + 4;
   static constexpr int NE_MAX = TY * TX, NCHUNK = NE_MAX / 64;
   static constexpr int NG = KS / 4;                           // full groups of 4 offsets per offset row
   static constexpr int CPL = (RW + 63) / 64;                  // region columns per lane (row loads / flushes)
@@ -162,13 +170,25 @@ struct DenseBwdGeo {
 template <int KS, int KW, int C, int TY, int NCH, int RG, bool TM, bool SPL, int ROLE>
 __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   using G = DenseBwdGeo<KS, KW, C, TY, RG>;
+#ifndef SSG_SWB_SKIP
+#define SSG_SWB_SKIP 0
+#endif
+  constexpr int SWB_SKIP = SSG_SWB_SKIP;   // 1: role 0 carries the border sums, 0: role 1
   static_assert(SPL == (ROLE != 2) && (!SPL || (TM && RG == 4)), "roles: tile-major k_s 49 instantiation only");
   constexpr bool DO_A = ROLE != 1, DO_B = ROLE != 0;   // channels (0,1) / channel 2
-  constexpr bool DO_G = ROLE != 1, DO_W = ROLE != 0;   // G formation + border sums / W stage
+  constexpr bool DO_G = ROLE != 1, DO_W = ROLE != 0;   // G formation / W stage
+  constexpr bool DO_S = ROLE != SWB_SKIP;               // border sums swb (experiment knob: which role carries them)
   // LDS hand-over between the steps' stages: one wave = program order; two waves = LDS writes retired, then s_barrier
   // (not __syncthreads(): it would also drain the tile-major loads that are seven steps ahead)
   auto stage_sync = [] {
+#ifdef SSG_TIMING_NO_BARRIER   // (timing experiment, wrong results: what the s_barrier itself costs)
+    if constexpr (SPL) asm volatile("" ::: "memory");
+#else
     if constexpr (SPL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    // (nothing is scheduled across: without this the next step's body -- register operands only -- moves up in front of
+    // the s_barrier, behind a wait for ALL of the step's LDS reads, and no longer covers their latency)
+    if constexpr (SPL) __builtin_amdgcn_sched_barrier(0);
     else __builtin_amdgcn_wave_barrier();
   };
   auto chan_on = [](int c) { return c < 2 ? DO_A : DO_B; };
@@ -296,12 +316,21 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   const int hty = REGW ? jrow : lane % TY, hg = REGW ? g : lane / TY;
   const float m1 = hty >= 1 ? 1.f : 0.f, m2 = hty >= 2 ? 1.f : 0.f, m4 = hty >= 4 ? 1.f : 0.f;
   const int hsrc = (REGW && half ? TY - 1 - hty : hty) * GQS + HOUT * hg;  // (offsets relative to a copy's base)
-  int hdst[HOUT];
+  int hdst[HOUT], hdst2[HOUT];   // prefix row hty, suffix row TY-1+hty (hty >= 1)
 #pragma unroll
   for (int i = 0; i < HOUT; ++i) {
     const int uc = HOUT * hg + i;
-    hdst[i] = uc < UW ? TY * GQS + (hty + 1) * PS + (uc / NPX) * NPXP + uc % NPX : DUMMY;  // (columns past U: the dummy word)
+    hdst[i] = uc < UW ? TY * GQS + hty * PS + (uc / NPX) * NPXP + uc % NPX : DUMMY;  // (columns past U: the dummy word)
+    // (tile row 0 has no suffix row of its own: S_0 = P_TY, written once more into the last prefix row -- 16 lanes on
+    // the dummy word would be a 16-way bank conflict per store)
+    hdst2[i] = uc < UW ? TY * GQS + (TY - 1 + hty) * PS + (uc / NPX) * NPXP + uc % NPX : DUMMY;
   }
+  // suffix S_hty = P_TY (the group's last tile row: quad lane 3 / lane TY-1 of the prefix group) - P_hty (the lane below)
+  auto suffix_of = [&](float pfx) {
+    static_assert(REGW || TY == 4, "suffix rows: the TY = 4 tile rows of a group are one DPP quad");
+    const float tot = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pfx), 0xff, 0xf, 0xf, true));  // quad_perm [3,3,3,3]
+    return __builtin_fmaf(-m1, dpp_row_shr<1>(pfx), tot);   // (m1 = 0 for tile row 0; exact product: the same rounding as tot - P)
+  };
 
   float wout[HOUT];  // RG = 8: the prefix of the offset prepared last (consumed by the next step)
   // The box sum W of the field in copy `f` on the lane's NPX pixels comes in two halves, so that consecutive
@@ -330,24 +359,52 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     }
     if constexpr (!REGW) {
 #pragma unroll
-      for (int i = 0; i < HOUT; ++i) f[hdst[i]] = out[i];
+      for (int i = 0; i < HOUT; ++i) {
+        f[hdst[i]] = out[i];
+        f[hdst2[i]] = suffix_of(out[i]);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < HOUT; ++i) wout[i] = out[i];
     }
   };
-  auto y_read = [&](const float *f, int pa, int pb, float (&Wv)[NPX]) {
+  // (a lane's W row segment is NPXP = 12 floats on a 16-byte boundary -- so are the 12 zeros: three ds_read_b128)
+  auto y_read = [&](const float *f, int pw, float (&Wv)[NPX]) {
+    if constexpr (!REGW && NPXP % 4 == 0 && NPXP >= NPX) {
+      // (the pad word is not loaded -- ds_read_b96 for the last three: a dead destination register would be reused at
+      // once and make its next writer wait for the whole read)
+      typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+      typedef float f3a __attribute__((ext_vector_type(3), aligned(16)));
+      const float *q = (const float *)__builtin_assume_aligned(f + pw, 16);
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) Wv[i] = f[pb + i] - f[pa + i];
+      for (int k = 0; k < NPXP / 4; ++k) {
+        if (4 * k + 4 <= NPX) {
+          const f4a t = *(const f4a *)(q + 4 * k);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Wv[4 * k + j] = t[j];
+        } else if (4 * k + 3 == NPX) {
+          const f3a t = *(const f3a *)(q + 4 * k);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Wv[4 * k + j] = t[j];
+        } else {
+#pragma unroll
+          for (int j = 0; 4 * k + j < NPX; ++j) Wv[4 * k + j] = q[4 * k + j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) Wv[i] = f[pw + i];
+    }
   };
   // prefix rows of U-row r for row taps [ylo, yhi]: tile rows [r-HK-yhi, r-HK-ylo] clipped to the tile
-  auto prefix_rows = [&](int ylo, int yhi, int &pa, int &pb) {
+  // (no tile row in the window: the 2 HK zeros left of the field's first row)
+  static_assert(REGW || (KW - 1 >= 2 * TY && 2 * HK >= NPX), "W rows: prefix or suffix; the zero pad serves a whole lane");
+  auto prefix_rows = [&](int ylo, int yhi) {
     int a = r - HK - yhi, bb = r - HK - ylo;
     a = a < 0 ? 0 : a;
     bb = bb > TY - 1 ? TY - 1 : bb;
     const bool none = a > bb;
-    pa = TY * GQS + (none ? 0 : a * PS) + NPXP * g;
-    pb = TY * GQS + (none ? 0 : (bb + 1) * PS) + NPXP * g;
+    return none ? 0 : TY * GQS + (a == 0 ? bb : TY - 1 + a) * PS + NPXP * g;
   };
 
   // RG = 8, offset rows with a vertically cut window [ylo, yhi]: W = (prefix of lane `lpos`) - (prefix of lane
@@ -491,8 +548,9 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   const float *tma = nullptr, *tmb = nullptr;
   float tw1 = 0.f, tw2 = 0.f, tkf = 0.f;
   if constexpr (TM && DO_G) {
-    tma = p.tm[0] + (size_t)tslot * P * TM_PX;   // (wave-uniform: scalar base + lane offset addressing)
-    tmb = p.tm[1] + (size_t)tslot * P * TM_PX;
+    // (wave-uniform: scalar base + lane offset addressing; profiling bit 4: every tile streams slot 0 -- L2 hits)
+    tma = p.tm[0] + (size_t)(SSG_DBG(p, 16) ? 0 : tslot) * P * TM_PX;
+    tmb = p.tm[1] + (size_t)(SSG_DBG(p, 16) ? 0 : tslot) * P * TM_PX;
     const float invM = 1.f / ((float)nrows * (float)P);
     tkf = 1.f / (p.sigma * (float)(C * KW * KW));
     tw1 = -tkf * (p.w_l1 * invM * (p.upstream ? p.upstream[0] : 1.f));
@@ -567,9 +625,7 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       stage_sync();
       x_put(std::integral_constant<int, 2>{}, qy0, f0, qy0 * KS + TMD + 2);
       const int ylo0 = (-HK > -qy0) ? -HK : -qy0, yhi0 = (HK < KS - 1 - qy0) ? HK : KS - 1 - qy0;
-      int pa0, pb0;
-      prefix_rows(ylo0, yhi0, pa0, pb0);
-      y_read(f0, pa0, pb0, Wv);
+      y_read(f0, prefix_rows(ylo0, yhi0), Wv);
     }
     step_fence();
     if constexpr (SPL) stage_sync();
@@ -587,13 +643,13 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     load_img_row(r0 + qyi + RR < RH ? r0 + qyi + RR : RH - 1, nrow);
     const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
     const float ymask = (ylo > -HK || yhi < HK) ? 1.f : 0.f;
-    int pa = 0, pb = 0, lpos = 0, lneg = 0;
+    int pw = 0, lpos = 0, lneg = 0;
     float mpos = 0.f, mneg = 0.f;
     const bool rowfull = ylo == -HK && yhi == HK;
     if constexpr (REGW) cut_rows(ylo, yhi, lpos, lneg, mpos, mneg);
-    else prefix_rows(ylo, yhi, pa, pb);
-    int pan = 0, pbn = 0;   // LAG: the row's last step fetches W of the next row's first offset
-    if constexpr (LAG) prefix_rows((-HK > -qyn) ? -HK : -qyn, (HK < KS - 1 - qyn) ? HK : KS - 1 - qyn, pan, pbn);
+    else pw = prefix_rows(ylo, yhi);
+    int pwn = 0;   // LAG: the row's last step fetches W of the next row's first offset
+    if constexpr (LAG) pwn = prefix_rows((-HK > -qyn) ? -HK : -qyn, (HK < KS - 1 - qyn) ? HK : KS - 1 - qyn);
     float *fe = fld + (qyi & 1) * FSZ, *fo = fld + ((qyi & 1) ^ 1) * FSZ;  // copies of the even / odd q_x of this row
     const int slr = (r + qyi) & RMASK;
     const float *ib = imgb + slr * BRS + NPX * g;
@@ -629,8 +685,7 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       } else if constexpr (REGW) {
         w_regs(rowfull, lpos, lneg, mpos, mneg, Wv);
       } else {
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) Wv[i] = fc[pb + i] - fc[pa + i];
+        y_read(fc, pw, Wv);
       }
       if constexpr (DO_W) {
 #pragma unroll
@@ -641,12 +696,18 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
         fl[c] = chan_on(c) ? gb[c * RWS + qxi] : 0.f;
         wn[c] = (qxi + 1 < KS && chan_on(c)) ? ib[c * RWS + qxi + NPX] : 0.f;
       }
+      // LAG: W of the next offset (its rows were written a step ago), into registers of its own
+      float Wn[NPX];
+      if constexpr (LAG) y_read(fn, qxi + 1 < KS ? pw : pwn, Wn);
+      // (two waves: the reads stay here, in front of the body that covers their latency -- the scheduler otherwise
+      // sinks them to their first use behind it)
+      if constexpr (SPL) __builtin_amdgcn_sched_barrier(0);
       // ---- both ends of every pair (u, u+q) ----
       constexpr bool xborder = xlo > -HK || xhi < HK;
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
         const float Wi = Wv[i];
-        if constexpr (DO_G) {
+        if constexpr (DO_S) {
           if constexpr (xborder) swb[i] += Wi;
           else swb[i] = __builtin_fmaf(Wi, ymask, swb[i]);
         }
@@ -668,16 +729,6 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
           guA[i].y = __builtin_fmaf(Wi, d1, guA[i].y);
           grA[sl].x = __builtin_fmaf(-Wi, d0, grA[sl].x);
           grA[sl].y = __builtin_fmaf(-Wi, d1, grA[sl].y);
-        }
-      }
-      // ---- LAG: W of the next offset, fetched behind the body and subtracted at the end of the step ----
-      float wra[NPX], wrb[NPX];
-      if constexpr (LAG) {
-        const int pa1 = qxi + 1 < KS ? pa : pan, pb1 = qxi + 1 < KS ? pb : pbn;
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) {
-          wrb[i] = fn[pb1 + i];
-          wra[i] = fn[pa1 + i];
         }
       }
       // ---- next offset: horizontal sums over its column taps, vertical prefix ----
@@ -702,7 +753,10 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
         for (int i = 0; i < HOUT; ++i) wout[i] = out[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < HOUT; ++i) fP[hdst[i]] = out[i];
+        for (int i = 0; i < HOUT; ++i) {
+          fP[hdst[i]] = out[i];
+          fP[hdst2[i]] = suffix_of(out[i]);
+        }
       }
       // region column NPX*g + qxi of this band row is complete: to the band; the window moves on
       {
@@ -721,10 +775,6 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       }
       x_put(std::integral_constant<int, qx2>{}, qxi + 2 + LAG < KS ? qyi : qyn, fG,
             (qxi + 2 + LAG < KS && qx2 + TMD < KS) ? rq0 + qx2 + TMD : (qxi + 2 + LAG < KS ? rq1 + qx2 + TMD - KS : rq1 + qx2 + TMD));
-      if constexpr (LAG) {
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) Wv[i] = wrb[i] - wra[i];
-      }
       // (the accumulators of the lane's own pixels pass through an empty asm: they are not read again before
       // the end of the sweep, and hipcc otherwise sinks their FMAs below all k_s steps, keeping every step's
       // W and differences alive: 1,000 spilled registers)
@@ -733,7 +783,11 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
         if constexpr (DO_A) asm volatile("" : "+v"(guA[i]));
         if constexpr (DO_B) asm volatile("" : "+v"(guB[i]));
       }
-      if constexpr (DO_G) pin_row<NPX>(swb);
+      if constexpr (DO_S) pin_row<NPX>(swb);
+      if constexpr (LAG) {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) Wv[i] = Wn[i];
+      }
       step_fence();
       if constexpr (SPL) stage_sync();
     });
@@ -763,21 +817,19 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     }
     stage_sync();
     if constexpr (DO_W) x_stage(std::integral_constant<int, -HK>{}, std::integral_constant<int, HK>{}, fld);
-    if constexpr (SPL && DO_G) {   // the border sums for the other role (the gradient band is flushed: scratch)
+    if constexpr (SPL && DO_S) {   // the border sums for the other role (the gradient band is flushed: scratch)
 #pragma unroll
       for (int i = 0; i < NPX; ++i) grb[64 * i + lane] = swb[i];
     }
     stage_sync();
-    if constexpr (SPL && !DO_G) {
+    if constexpr (SPL && !DO_S) {
 #pragma unroll
       for (int i = 0; i < NPX; ++i) swb[i] = grb[64 * i + lane];
     }
     if constexpr (REGW) {
       w_regs(true, 0, 0, 0.f, 0.f, vbox);
     } else {
-      int pa, pb;
-      prefix_rows(-HK, HK, pa, pb);
-      y_read(fld, pa, pb, vbox);
+      y_read(fld, prefix_rows(-HK, HK), vbox);
     }
     step_fence();
   }

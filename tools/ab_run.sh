@@ -9,7 +9,7 @@ for rep in 1 2 3; do
     cp gpurun_ab/$t/libssg_hip.so gpurun_ab/$t/libssg_hip_prof.so ssl_amd/csrc/
     python bench.py --no-cpu-baseline --no-module --no-extra "$@" 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); k = d['roofline']['kernel_ms']
+d = json.loads(sys.stdin.read()); k = d['roofline'].get('kernel_ms', {})
 print('$t', 'step %.4f' % d['ms_per_step'], ' '.join('%s %.3f' % (n.split('<')[0].replace('ssg_', '') + ('+' if 'merged' in n else ''), v) for n, v in k.items() if n.startswith('ssg_') or n.startswith('edge') or 'all' in n))"
   done
 done
