@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void tile_count_sparse(const int *rank, int B,
 // and across the 16 wave totals (two barriers per round), and the offsets leave as four 16-byte stores.
 constexpr int SCAN_RUN = 16, SCAN_ROUND = 1024 * SCAN_RUN;
 
-__global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int n, int *total_out) {
-  __shared__ int wtot[16], wincl[16];
+// (block of 1024 lanes; wtot / wincl: 16 ints of LDS each; returns the total, identical in every lane)
+__device__ __forceinline__ int block_scan_1024(const int *cnt, int *off, int n, int *wtot, int *wincl) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int carry = 0;  // kept identical in every lane
   for (int base = 0; base < n; base += SCAN_ROUND) {
@@ -395,7 +395,13 @@ __global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int 
     }
     __syncthreads();  // wtot / wincl are rewritten by the next round
   }
-  if (total_out && tid == 0) *total_out = carry;
+  return carry;
+}
+
+__global__ __launch_bounds__(1024) void tile_scan(const int *cnt, int *off, int n, int *total_out) {
+  __shared__ int wtot[16], wincl[16];
+  const int total = block_scan_1024(cnt, off, n, wtot, wincl);
+  if (total_out && threadIdx.x == 0) *total_out = total;
 }
 
 __global__ __launch_bounds__(256) void tile_scatter(const int *rank, int B, int H, int W, int ntiles, const int *off,
@@ -445,6 +451,199 @@ __global__ __launch_bounds__(256) void tile_group_flags(int *order_a, const int 
   }
   ok = ok && (y1 - y0) <= MERGE_ROWS - 1 && (x1 - x0) <= MERGE_COLS - 1;
   order[k0] = first | (ok ? ORDER_FLAG : 0);
+}
+
+// ---- banded builder (round 4): edge list, rank map, dense list and sparse order in FOUR launches instead of seven -----
+// A workgroup owns a band of 8 image rows x 256 columns: 32 strips of 8 pixels per row, one lane per strip.  Such a block
+// is a run of whole 8 x 8 order tiles (a strip IS a tile row) and of whole 8 x 32 super-tiles, and each of its row
+// segments is a contiguous piece of the reference's row-major edge order -- so one pass over the mask yields the
+// row-segment counts (the edge order's scan input) AND the tile counts (the plan's input), which the seven-launch
+// builder only had after its scatter pass (atomics into the order tiles' counters):
+//   band_count    bits of every strip, edge pixels per row segment, edge pixels per order tile (+ the caller's ZeroRanges)
+//   band_scan     one workgroup: row-segment offsets and `counts`; tile counts corrected when N exceeds the capacity
+//                 (rows from `capacity` on do not exist for the plan: same lists as the seven-launch builder); dense
+//                 list and flags from the tile counts; offsets of the sparse order; the plan's header
+//   band_scatter  edges, rank map and the tile-major order of the rows left to the direct kernels
+//   tile_group_flags as before
+constexpr int BAND_COLS = 256;
+
+__device__ __forceinline__ unsigned strip_bits(const EdgeParams &p, int b, int y, int x0) {
+  unsigned bits = 0;
+  if (p.kind == 0 && x0 + 8 <= p.W) {
+    const float *m = (const float *)p.mask + (size_t)b * p.mask_channels * p.H * p.W + (size_t)y * p.W + x0;
+    float v[8];
+    if (((size_t)m & 15) == 0) {
+      const float4 a = *(const float4 *)m, c = *(const float4 *)(m + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = m[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (v[k] == 1.0f && (p.stride <= 1 || (y % p.stride) == ((x0 + k) % p.stride))) bits |= 1u << k;
+    return bits;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (x0 + k < p.W && edge_pred(p, b, y, x0 + k)) bits |= 1u << k;
+  return bits;
+}
+
+__global__ __launch_bounds__(256) void band_count(EdgeParams p, int nseg, int *segcnt, int *tcnt, uint8_t *bits_out,
+                                                  ZeroRanges z) {
+  __shared__ int s_c[8][33];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    uint4 *q = (uint4 *)z.ptr[k];
+    const size_t n = z.bytes[k] / 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) q[i] = make_uint4(0, 0, 0, 0);
+  }
+  const int tx_n = (p.W + OT - 1) / OT, ty_n = (p.H + OT - 1) / OT;
+  const int seg = blockIdx.x % nseg, band = (blockIdx.x / nseg) % ty_n, b = blockIdx.x / (nseg * ty_n);
+  const int r = threadIdx.x >> 5, g = threadIdx.x & 31;
+  const int y = band * OT + r, sx = seg * 32 + g;
+  const bool in = y < p.H && sx < tx_n;
+  const unsigned bits = in ? strip_bits(p, b, y, sx * 8) : 0u;
+  if (in) bits_out[((size_t)b * p.H + y) * tx_n + sx] = (uint8_t)bits;
+  const int c = __popc(bits);
+  int rc = c;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) rc += __shfl_xor(rc, o, 64);   // (offsets < 32: the sum of the row's 32 lanes)
+  if (g == 0 && y < p.H) segcnt[((size_t)b * p.H + y) * nseg + seg] = rc;
+  s_c[r][g] = c;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int tx = seg * 32 + threadIdx.x;
+    if (tx < tx_n) {
+      int n = 0;
+#pragma unroll
+      for (int k = 0; k < OT; ++k) n += s_c[k][threadIdx.x];
+      tcnt[((size_t)b * ty_n + band) * tx_n + tx] = n;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void band_scan(int B, int H, int W, int nseg, const int *segcnt, int *segoff, int *counts,
+                                                  int capacity, const uint8_t *bits, int *tcnt, int *toff, int thr,
+                                                  int *dflag, int *plan) {
+  __shared__ int wtot[16], wincl[16];
+  __shared__ int s_heavy, s_light;
+  const int tid = threadIdx.x;
+  const int tx_n = (W + OT - 1) / OT, ty_n = (H + OT - 1) / OT;
+  const int nrow = B * H * nseg, nt = B * ty_n * tx_n;
+  if (tid == 0) s_heavy = s_light = 0;
+  const int N = block_scan_1024(segcnt, segoff, nrow, wtot, wincl);   // (ends with a barrier: segoff is visible)
+  for (int b = tid; b < B; b += 1024) counts[1 + b] = segoff[(size_t)b * H * nseg];
+  if (tid == 0) counts[0] = counts[1 + B] = N;
+  if (N > capacity) {
+    // rows from `capacity` on are not listed: the tiles count what is left of them.  A row segment lies before the cut,
+    // behind it, or -- exactly one in the batch -- across it (its first capacity - offset edge pixels count)
+    for (int t = tid; t < nt; t += 1024) {
+      const int b = t / (ty_n * tx_n), rem = t - b * ty_n * tx_n, band = rem / tx_n, tx = rem - band * tx_n;
+      const int seg = tx / 32;
+      int n = 0;
+      for (int r = 0; r < OT; ++r) {
+        const int y = band * OT + r;
+        if (y >= H) break;
+        const size_t rs = ((size_t)b * H + y) * nseg + seg;
+        const int so = segoff[rs];
+        if (so >= capacity) continue;
+        const uint8_t *row = bits + ((size_t)b * H + y) * tx_n;
+        int c = __popc((unsigned)row[tx]);
+        if (so + segcnt[rs] > capacity) {
+          int before = so;
+          for (int k = seg * 32; k < tx; ++k) before += __popc((unsigned)row[k]);
+          const int left = capacity - before;
+          c = left < 0 ? 0 : (left < c ? left : c);
+        }
+        n += c;
+      }
+      tcnt[t] = n;
+    }
+  }
+  __syncthreads();
+  if (plan) {
+    const int sx_n = (W + 31) / 32, ns = B * ty_n * sx_n;
+    for (int st = tid; st < ns; st += 1024) {
+      const int b = st / (ty_n * sx_n), rem = st - b * ty_n * sx_n, sy = rem / sx_n, sx = rem - sy * sx_n;
+      int *c = tcnt + ((size_t)b * ty_n + sy) * tx_n + 4 * sx;
+      const int nk = tx_n - 4 * sx < 4 ? tx_n - 4 * sx : 4;
+      int n = 0;
+      for (int k = 0; k < nk; ++k) n += c[k];
+      const int dense = thr > 0 && n >= thr;
+      dflag[st] = dense;
+      if (dense) {   // heavy tiles from the front, light ones from the back (dense_tile_at, ssg_common.hpp)
+        if (n > 64) plan[4 + atomicAdd(&s_heavy, 1)] = st | (n > 128 ? TILE_HUGE : 0);
+        else plan[4 + ns - 1 - atomicAdd(&s_light, 1)] = st;
+        for (int k = 0; k < nk; ++k) c[k] = 0;   // its rows belong to the dense kernels: not in the sparse order
+      }
+    }
+    __syncthreads();
+  }
+  const int n_sparse = block_scan_1024(tcnt, toff, nt, wtot, wincl);
+  if (plan && tid == 0) {
+    plan[0] = n_sparse;
+    plan[1] = s_heavy;
+    plan[2] = OT;
+    plan[3] = s_light;
+  }
+}
+
+__global__ __launch_bounds__(256) void band_scatter(EdgeParams p, int nseg, const int *segoff, const uint8_t *bits_in,
+                                                    int *edges, int capacity, int *rank, const int *toff,
+                                                    const int *dflag, int *order_out) {
+  __shared__ int s_v[8][33];
+  const int tx_n = (p.W + OT - 1) / OT, ty_n = (p.H + OT - 1) / OT;
+  const int seg = blockIdx.x % nseg, band = (blockIdx.x / nseg) % ty_n, b = blockIdx.x / (nseg * ty_n);
+  const int r = threadIdx.x >> 5, g = threadIdx.x & 31;
+  const int y = band * OT + r, sx = seg * 32 + g, x0 = sx * 8;
+  const bool in = y < p.H && sx < tx_n;
+  const unsigned bits = in ? bits_in[((size_t)b * p.H + y) * tx_n + sx] : 0u;
+  const int c = __popc(bits);
+  int incl = c;   // inclusive scan over the row's 32 lanes (a half-wave: lanes g >= o take from their own half)
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (g >= o) incl += t;
+  }
+  const int pos0 = (y < p.H ? segoff[((size_t)b * p.H + y) * nseg + seg] : 0) + incl - c;
+  int valid = capacity - pos0;
+  valid = valid < 0 ? 0 : (valid < c ? valid : c);
+  s_v[r][g] = valid;
+  __syncthreads();
+  if (!in) return;
+  int rk[8];
+  int pos = pos0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bool on = bits & (1u << k);
+    const bool ok = on && pos < capacity;
+    if (ok) {
+      edges[3 * (size_t)pos + 0] = b;
+      edges[3 * (size_t)pos + 1] = y;
+      edges[3 * (size_t)pos + 2] = x0 + k;
+    }
+    rk[k] = ok ? pos : -1;   // rank map: row index of every pixel (-1: not an edge pixel / beyond capacity)
+    if (on) ++pos;
+  }
+  int *rrow = rank + ((size_t)b * p.H + y) * p.W + x0;
+  if (x0 + 8 <= p.W && ((size_t)rrow & 15) == 0) {
+    *(int4 *)rrow = make_int4(rk[0], rk[1], rk[2], rk[3]);
+    *(int4 *)(rrow + 4) = make_int4(rk[4], rk[5], rk[6], rk[7]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (x0 + k < p.W) rrow[k] = rk[k];
+  }
+  if (order_out && valid > 0) {
+    const int sx_n = (p.W + 31) / 32;
+    if (dflag && dflag[((size_t)b * ty_n + band) * sx_n + sx / 4]) return;   // rows of a dense super-tile
+    int idx = toff[((size_t)b * ty_n + band) * tx_n + sx];
+    for (int k = 0; k < r; ++k) idx += s_v[k][g];
+    for (int j = 0; j < valid; ++j)
+      if (idx + j < capacity) order_out[idx + j] = pos0 + j;   // (a strip's rows are consecutive in the edge order)
+  }
 }
 
 // ---- the reference operator's position list -> the engine's plan (ssg_compute_similarity[_backward] with many positions,
@@ -515,10 +714,21 @@ static size_t n_order_tiles(int B, int H, int W) { return (size_t)B * ((H + OT -
 // (sized for the smallest super-tile height, 4 rows)
 static size_t n_super_tiles(int B, int H, int W) { return (size_t)B * ((H + 3) / 4) * ((W + 31) / 32); }
 
+static size_t n_row_segments(int B, int H, int W) { return (size_t)B * H * ((W + BAND_COLS - 1) / BAND_COLS); }
+
 size_t edge_scratch_bytes(int B, int H, int W) {
   const size_t nblk = (size_t)B * (((size_t)H * W + CHUNK - 1) / CHUNK);
   // (+ one predicate byte per lane of edge_count, behind the int arrays)
-  return (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64 + nblk * 256;
+  const size_t chunked = (2 * nblk + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64 + nblk * 256;
+  // banded builder: row-segment counts and offsets instead of the chunks', one predicate byte per 8-pixel strip
+  const size_t banded = (2 * n_row_segments(B, H, W) + 2 * n_order_tiles(B, H, W) + n_super_tiles(B, H, W)) * sizeof(int) + 64 +
+                        (size_t)B * H * ((W + OT - 1) / OT);
+  return chunked > banded ? chunked : banded;
+}
+
+static bool banded_enabled() {
+  static const bool on = !(getenv("SSG_EDGE_BANDED") && atoi(getenv("SSG_EDGE_BANDED")) == 0);
+  return on;
 }
 
 static size_t n_strips(int B, int H, int W) { return (size_t)B * ((H + STRIP_ROWS - 1) / STRIP_ROWS) * ((W + 31) / 32); }
@@ -551,6 +761,25 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   EdgeParams p{mask, kind, mask_channels, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
   const int nblk = B * p.nblk_img;
   const int nt = (int)n_order_tiles(B, H, W);
+  if (rank && banded_enabled() && ((plan && plan_tile_rows == OT && !order) || (order && !plan))) {
+    const int nseg = (W + BAND_COLS - 1) / BAND_COLS, ty_n = (H + OT - 1) / OT;
+    const size_t nrow = n_row_segments(B, H, W);
+    int *segcnt = (int *)scratch, *segoff = segcnt + nrow, *tcnt = segoff + nrow, *toff = tcnt + nt, *dflag = toff + nt;
+    uint8_t *bits = (uint8_t *)(dflag + n_super_tiles(B, H, W)) + 64;
+    const ZeroRanges z{{zero_a, zero_b, zero_c}, {zero_a ? zero_a_bytes : 0, zero_b ? zero_b_bytes : 0, zero_c ? zero_c_bytes : 0}};
+    const unsigned grid = (unsigned)(B * ty_n * nseg);
+    int *order_out = plan ? plan + fwd_plan_order_offset(B, H, W) : order;
+    hipLaunchKernelGGL(band_count, dim3(grid), dim3(256), 0, st, p, nseg, segcnt, tcnt, bits, z);
+    hipLaunchKernelGGL(band_scan, dim3(1), dim3(1024), 0, st, B, H, W, nseg, segcnt, segoff, counts, capacity, bits, tcnt, toff,
+                       dense_thr, plan ? dflag : nullptr, plan);
+    hipLaunchKernelGGL(band_scatter, dim3(grid), dim3(256), 0, st, p, nseg, segoff, bits, edges, capacity, rank, toff,
+                       plan ? dflag : nullptr, order_out);
+    const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
+    if (ngroups > 0)
+      hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256, 1), dim3(256), 0, st, order_out, plan ? plan : counts,
+                         nullptr, nullptr, edges, capacity);
+    return (int)hipGetLastError();
+  }
   int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;
   int *tcnt = blockoff + nblk, *toff = tcnt + nt;
   const bool need_tiles = order || plan;  // rows per 8x8 order tile, counted while the edges are scattered

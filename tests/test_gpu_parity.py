@@ -1987,3 +1987,111 @@ def test_reference_operator_plan_path_equals_direct_path(dev, ks, kw, H, W, dens
         L.ssg_set_operator_plan_threshold(prev)
     torch.cuda.synchronize()
     assert L.ssg_operator_pool_trim() == 0
+
+
+# ------------------------------------------------------------------ banded edge-list builder (round 4)
+def _plan_reference(mask_bool, cap, thr, with_plan):
+    """numpy restatement of what ssg_edge_list leaves behind for 8-row tiles: edges in torch.where order, rank map,
+    dense super-tiles (>= thr edge pixels per 8 x 32 tile, rows below `cap` only), the tile-major order (8 x 8 tiles in
+    image / row-major order, row-major inside a tile) of the rows not in a dense tile, and the groups-of-5 merge flags."""
+    B, H, W = mask_bool.shape
+    bs, ys, xs = np.nonzero(mask_bool)
+    N = len(bs)
+    n_ok = min(N, cap)
+    rank = -np.ones((B, H, W), np.int64)
+    rank[bs[:n_ok], ys[:n_ok], xs[:n_ok]] = np.arange(n_ok)
+    ty_n, tx_n, sx_n = -(-H // 8), -(-W // 8), -(-W // 32)
+    heavy, light, dense = set(), set(), np.zeros((B, ty_n, sx_n), bool)
+    if with_plan:
+        for b in range(B):
+            for sy in range(ty_n):
+                for sx in range(sx_n):
+                    n = int((rank[b, sy * 8:sy * 8 + 8, sx * 32:sx * 32 + 32] >= 0).sum())
+                    if thr > 0 and n >= thr:
+                        dense[b, sy, sx] = True
+                        st = (b * ty_n + sy) * sx_n + sx
+                        (heavy if n > 64 else light).add(st | ((1 << 29) if n > 128 else 0))
+    order = []
+    for b in range(B):
+        for ty in range(ty_n):
+            for tx in range(tx_n):
+                if dense[b, ty, tx // 4]:
+                    continue
+                r = rank[b, ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8].ravel()
+                order.extend(r[r >= 0].tolist())
+    order = np.array(order, np.int64)
+    flags = np.zeros(len(order), bool)
+    for k0 in range(0, len(order), 5):
+        rows = order[k0:k0 + 5]
+        flags[k0] = (len(set(bs[rows])) == 1 and ys[rows].max() - ys[rows].min() <= 7 and xs[rows].max() - xs[rows].min() <= 15)
+    return dict(N=N, edges=np.stack([bs, ys, xs], 1)[:n_ok], rank=rank, heavy=heavy, light=light, order=order, flags=flags,
+                first=np.searchsorted(bs, np.arange(B)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,dens,stride,cap_frac,kind", [
+    (2, 64, 96, 0.10, 0, None, "f32"),        # whole tiles, one segment
+    (3, 61, 83, 0.30, 0, None, "u8"),         # ragged bands / strips / super-tiles
+    (1, 40, 600, 0.08, 0, None, "f32"),       # three 256-column segments, the last one ragged
+    (2, 72, 300, 0.50, 3, None, "f32"),       # stride pattern, unaligned rows (W % 4 != 0 -> scalar loads)
+    (2, 64, 288, 0.25, 0, 0.55, "f32"),       # capacity overflow: the cut falls inside a row of the second segment
+    (2, 57, 70, 0.90, 0, 0.30, "u8"),         # overflow with dense tiles on both sides of the cut
+    (1, 33, 40, 0.0, 0, None, "f32"),         # empty mask
+])
+def test_banded_edge_list_builder_vs_numpy(dev, B, H, W, dens, stride, cap_frac, kind):
+    """The four-launch banded builder (ssg_edges.hip: band_count / band_scan / band_scatter / tile_group_flags): edges,
+    counts, rank map, the plan's header and dense lists, sparse order and merge flags against a numpy restatement, with
+    a plan ((25,9) sizes) and without one ((11,5) sizes: the full tile-major order), with blobs so that tiles of every
+    class (sparse, light, heavy, huge) occur."""
+    from ssl_amd import engine
+    rng = np.random.default_rng(B * 1000 + H * 10 + W)
+    m = rng.random((B, H, W)) < dens
+    if dens > 0:   # blobs: dense super-tiles of the light, heavy and huge classes
+        m[0, 8:16, 32:64] |= rng.random((8, 32)) < 0.2
+        m[-1, 16:24, 0:32] |= rng.random((8, 32)) < 0.45
+        m[0, 24:32, 32:64] = True
+    eff = m.copy()
+    if stride > 1:
+        yy, xx = np.mgrid[0:H, 0:W]
+        eff &= ((yy % stride) == (xx % stride))[None]
+    N = int(eff.sum())
+    cap = B * H * W if cap_frac is None else max(1, int(N * cap_frac))
+    mk = torch.as_tensor(m[:, None].astype(np.uint8 if kind == "u8" else np.float32), device=dev)
+    thr = engine.set_dense_threshold(20)
+    try:
+        for ks, with_plan in ((25, True), (11, False)):
+            el = engine.edge_list(mask=mk, mask_stride=stride, capacity=cap, ks=ks, order=not with_plan, plan=with_plan)
+            torch.cuda.synchronize()
+            ref = _plan_reference(eff, cap, 20, with_plan)
+            c = el.counts.cpu().numpy()
+            assert c[0] == ref["N"] == c[-1] and np.array_equal(c[1:B + 1], ref["first"])
+            n_ok = min(N, cap)
+            assert np.array_equal(el.edges[:n_ok].cpu().numpy(), ref["edges"])
+            assert np.array_equal(el.rank.cpu().numpy(), ref["rank"])
+            if with_plan:
+                L = engine._lib.lib()
+                plan = el.plan.cpu().numpy()
+                ns = B * (-(-H // 8)) * (-(-W // 32))
+                assert plan[2] == 8 and plan[1] == len(ref["heavy"]) and plan[3] == len(ref["light"])
+                assert set(plan[4:4 + plan[1]].tolist()) == ref["heavy"]
+                assert set(plan[4 + ns - plan[3]:4 + ns].tolist()) == ref["light"]
+                off = L.ssg_forward_plan_bytes(B, H, W, cap) // 4 - max(cap, 1)
+                n_sp, od = int(plan[0]), plan[off:]
+            else:
+                n_sp, od = n_ok, el.order.cpu().numpy()
+            assert n_sp == len(ref["order"])
+            assert np.array_equal(od[:n_sp] & ((1 << 30) - 1), ref["order"])
+            assert np.array_equal((od[:n_sp] >> 30) & 1, ref["flags"].astype(od.dtype))
+        # the seven-launch builder (taken when a caller wants the full order AND a plan) leaves the same lists
+        el = engine.edge_list(mask=mk, mask_stride=stride, capacity=cap, ks=25, order=True, plan=True)
+        ref, full = _plan_reference(eff, cap, 20, True), _plan_reference(eff, cap, 20, False)
+        plan, od = el.plan.cpu().numpy(), el.order.cpu().numpy()
+        ns = B * (-(-H // 8)) * (-(-W // 32))
+        assert np.array_equal(el.rank.cpu().numpy(), ref["rank"]) and int(el.counts[0]) == N
+        assert set(plan[4:4 + plan[1]].tolist()) == ref["heavy"] and set(plan[4 + ns - plan[3]:4 + ns].tolist()) == ref["light"]
+        off = engine._lib.lib().ssg_forward_plan_bytes(B, H, W, cap) // 4 - max(cap, 1)
+        assert plan[0] == len(ref["order"]) and np.array_equal(plan[off:off + plan[0]] & ((1 << 30) - 1), ref["order"])
+        assert np.array_equal((plan[off:off + plan[0]] >> 30) & 1, ref["flags"].astype(plan.dtype))
+        assert np.array_equal(od[:min(N, cap)] & ((1 << 30) - 1), full["order"])
+    finally:
+        engine.set_dense_threshold(thr)
