@@ -5,8 +5,10 @@
 // reference's offline Laplacian edge mask on the fly (generate_mask.py:22-31)
 // and applying the mask_stride eye pattern (realesrganssl_model.py:64-72).
 //
-// Three small HBM-bound kernels: per-1024-pixel chunk counts, an exclusive scan
-// of the chunk counts (one workgroup), and an order-preserving scatter.
+// Two builders.  The chunked one: per-1024-pixel chunk counts, an exclusive scan of the chunk counts (one workgroup), an
+// order-preserving scatter, then the tile order / plan kernels on the rank map (7-12 launches; k_s 49 plans with their
+// strips, callers that want the full order AND a plan).  The BANDED one (further down; every other call): 8-row x
+// 256-column blocks give the row-segment counts and the tile counts in one pass -- four launches.
 #include "ssg_common.hpp"
 
 namespace ssg {
