@@ -193,7 +193,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   int *misc = elist + NE_MAX * 3;          // [16 + 64 NW]: wave counts, n_e (misc[NW]); then the census' (wave, bank) counts and starts
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int which = blockIdx.x / p.grid_tiles, tslot = blockIdx.x - which * p.grid_tiles;
+  // tile-major launch order: (slot 0, image 0), (slot 0, image 1), (slot 1, image 0) ... -- the heavy tiles of BOTH images
+  // start first (longest jobs first across the whole grid) and the slots behind the list's end drain last
+  const int tslot = blockIdx.x / p.nimg, which = blockIdx.x - tslot * p.nimg;
   if (tslot >= dense_tile_count(p.n_dense)) return;
   // (both variants are launched over the whole tile list when the call has a tile-major region; one of them leaves)
   if (p.tm_slots > 0 && tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host)) != TM) return;
