@@ -506,7 +506,48 @@ __global__ __launch_bounds__(256) void band_count(EdgeParams p, int nseg, int *s
   const int r = threadIdx.x >> 5, g = threadIdx.x & 31;
   const int y = band * OT + r, sx = seg * 32 + g;
   const bool in = y < p.H && sx < tx_n;
-  const unsigned bits = in ? strip_bits(p, b, y, sx * 8) : 0u;
+  unsigned bits = 0u;
+  if (p.kind == 2) {
+    // Laplacian of GT on the fly (generate_mask.py:22-31): the block's 'L' values once -- its 8 rows x 256 columns and a
+    // one-pixel frame, BORDER_REFLECT_101 -- into LDS (10 per lane), then the 5-point stencil from there: a quarter of
+    // the gathers and gray conversions of evaluating edge_pred per pixel (C2 step with mask=None: +0.045 -> +0.02 ms)
+    __shared__ uint8_t s_l[OT + 2][BAND_COLS + 2];
+    const float *img = (const float *)p.mask + (size_t)b * 3 * p.H * p.W;
+    const size_t plane = (size_t)p.H * p.W;
+    constexpr int NL = (OT + 2) * (BAND_COLS + 2), NIT = (NL + 255) / 256;
+    float px[NIT][3];
+    // (all loads of the lane first -- unconditional, from clamped coordinates -- then the conversions: one round of
+    //  memory latency per workgroup instead of one per value)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + 256 * it < NL ? threadIdx.x + 256 * it : NL - 1;
+      const int rr = i / (BAND_COLS + 2), cc = i - rr * (BAND_COLS + 2);
+      int yy = band * OT + rr - 1, xx = seg * BAND_COLS + cc - 1;
+      yy = yy > p.H ? p.H : yy;
+      xx = xx > p.W ? p.W : xx;
+      const size_t off = (size_t)reflect101_idx(yy, p.H) * p.W + reflect101_idx(xx, p.W);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[it][c] = img[off + c * plane];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + 256 * it;
+      if (i < NL) ((uint8_t *)s_l)[i] = (uint8_t)gray_l(px[it], 1, 0);
+    }
+    __syncthreads();
+    if (in) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int x = sx * 8 + k, cx = g * 8 + k + 1;
+        if (x >= p.W || (p.stride > 1 && (y % p.stride) != (x % p.stride))) continue;
+        int v = (int)s_l[r][cx] + (int)s_l[r + 2][cx] + (int)s_l[r + 1][cx - 1] + (int)s_l[r + 1][cx + 1] - 4 * (int)s_l[r + 1][cx];
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        if ((float)v > p.thr) bits |= 1u << k;
+      }
+    }
+  } else if (in) {
+    bits = strip_bits(p, b, y, sx * 8);
+  }
   if (in) bits_out[((size_t)b * p.H + y) * tx_n + sx] = (uint8_t)bits;
   const int c = __popc(bits);
   int rc = c;

@@ -2095,3 +2095,24 @@ def test_banded_edge_list_builder_vs_numpy(dev, B, H, W, dens, stride, cap_frac,
         assert np.array_equal(od[:min(N, cap)] & ((1 << 30) - 1), full["order"])
     finally:
         engine.set_dense_threshold(thr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,stride", [(2, 61, 83, 0), (1, 40, 600, 0), (2, 72, 300, 3), (1, 256, 256, 0)])
+def test_banded_builder_laplacian_mask_on_the_fly(dev, B, H, W, stride):
+    """mask_kind 2 through the banded builder (the block's 'L' values staged in LDS with a reflected one-pixel frame,
+    5-point stencil from there): the edge list equals torch.where of the oracle's PIL-'L' + cv2.Laplacian restatement
+    (generate_mask.py:22-31), ragged bands, several 256-column segments and the stride pattern included; with a plan
+    and without one."""
+    from ssl_amd import engine, synth
+    gt = np.stack([synth.natural_like(4100 + 7 * i + H, H, W, 0.10, 0.03) for i in range(B)])
+    ref = np.stack([orc.mask_stride(orc.edge_mask_chw(gt[i]), stride) for i in range(B)])
+    bs, ys, xs = np.nonzero(ref)
+    for ks, with_plan in ((25, True), (11, False)):
+        el = engine.edge_list(gt=T(gt, dev), mask_stride=stride, ks=ks, order=not with_plan, plan=with_plan)
+        c = el.counts.cpu().numpy()
+        assert c[0] == len(bs) and np.array_equal(c[1:B + 1], np.searchsorted(bs, np.arange(B)))
+        assert np.array_equal(el.edges[:c[0]].cpu().numpy(), np.stack([bs, ys, xs], 1))
+        want = -np.ones((B, H, W), np.int64)
+        want[bs, ys, xs] = np.arange(len(bs))
+        assert np.array_equal(el.rank.cpu().numpy(), want)
