@@ -188,7 +188,10 @@ int ssg_edge_mask_laplacian(const float *gt, int B, int H, int W,
  * k_s*k_s) fp32, row n <-> edges[n].  If img2/ssg2 are non-null the same
  * edge list is evaluated on a second batch in the same launch (SR and GT).
  * tile_order (from ssg_edge_list) only changes which workgroup computes which
- * row: neighbouring edge pixels then share one LDS search region. */
+ * row: neighbouring edge pixels then share one LDS search region.
+ * With a fwd_plan, n_rows must cover the rows the plan was cut for: n_rows >= min(counts[0], capacity of the
+ * ssg_edge_list call) -- the launches over the plan's heavy tiles are sized from n_rows (a heavy tile holds more than
+ * 64 rows).  The same holds for ssg_map_backward / ssg_loss_backward. */
 int ssg_map_forward(const float *img, const float *img2, int B, int C, int H,
                     int W, const int *edges, const int *tile_order /* nullable */,
                     const int *rank_map /* nullable */,

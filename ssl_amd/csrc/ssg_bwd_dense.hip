@@ -913,7 +913,9 @@ int launch_bwd_dense(const DenseBwdParams &p0, int ks, int kw, int C, hipStream_
     return rc;
   }
   int rc = launch_one<25, 9, 3, 8, 2, 8>(p, p.max_tiles, st);
-  if (!rc) rc = launch_one<25, 9, 3, 8, 4, 8>(p, p.max_tiles, st);
+  // (TILE_HUGE tiles are heavy ones -- more than 64 rows each, at the front of the list: see launch_fwd_dense_25)
+  const int heavy_max = p.n_host / 65 + 1;
+  if (!rc) rc = launch_one<25, 9, 3, 8, 4, 8>(p, heavy_max < p.max_tiles ? heavy_max : p.max_tiles, st);
   return rc;
 }
 

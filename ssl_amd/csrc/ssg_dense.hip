@@ -1131,7 +1131,11 @@ static int launch_fwd_dense_t(DenseParams p, int n_tiles, hipStream_t st) {
 template <bool RAW>
 static int launch_fwd_dense_25(const DenseParams &p, hipStream_t st) {
   int rc = launch_fwd_dense_t<25, 9, 3, 4, false, RAW, 2>(p, p.max_tiles, st);
-  if (!rc) rc = launch_fwd_dense_t<25, 9, 3, 4, false, RAW, 4>(p, p.max_tiles, st);
+  // TILE_HUGE tiles sit among the HEAVY ones, at the front of the list, and a heavy tile holds more than 64 of the call's
+  // rows: slots from n_host / 65 on cannot be theirs (with a tight row capacity the launch -- empty at C2 / C4 -- shrinks
+  // from 8,192 to 2,400 workgroups)
+  const int heavy_max = p.n_host / 65 + 1;
+  if (!rc) rc = launch_fwd_dense_t<25, 9, 3, 4, false, RAW, 4>(p, heavy_max < p.max_tiles ? heavy_max : p.max_tiles, st);
   return rc;
 }
 
