@@ -384,16 +384,29 @@ def extra_line(cfg_key, fused, dev, steps, warmup, maskgen=False):
     B = sr_np.shape[0]
     sr, gt, mask = (torch.as_tensor(a, device=dev) for a in (sr_np, gt_np, mask_np))
     step = make_step(cfg, B, dev, n + 1024, materialise=not fused)
+    def timed(m):
+        for _ in range(warmup):
+            step(sr, gt, m)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(sr, gt, m)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    same_harness = None
     if maskgen:
-        mask = None          # mask_kind 2: the reference's offline Laplacian mask generated from GT inside the edge-list kernels
-    for _ in range(warmup):
-        step(sr, gt, mask)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step(sr, gt, mask)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+        # mask_kind 2: the reference's offline Laplacian mask generated from GT inside the edge-list kernels.  The same
+        # step object with the fp32 mask is timed right before and right after (this harness, this point of the process):
+        # the difference of the two modes is what the on-device mask costs, whatever the box's clocks do meanwhile
+        before = timed(mask)
+        ms = timed(None)
+        after = timed(mask)
+        same_harness = {"fp32_mask_ms_before": before, "fp32_mask_ms_after": after,
+                        "delta_ms": ms - 0.5 * (before + after)}
+        mask = None
+    else:
+        ms = timed(mask)
     assert int(step.counts[0]) == n
     loss = step.loss.cpu().numpy()
     b_alg = alg_bytes_per_edge_px(cfg, n, B) - (8.0 * cfg["ks"] ** 2 if fused else 0.0)
@@ -408,6 +421,7 @@ def extra_line(cfg_key, fused, dev, steps, warmup, maskgen=False):
                         (" [mask=None: Laplacian edge mask of GT generated on the device, generate_mask.py:22-31]" if maskgen else ""),
             "ms_per_step": ms, "value": n / (ms * 1e-3), "unit": "edge-px/s", "steps": steps, "warmup": warmup,
             "edge_px": n, "l1": float(loss[0]), "kl": float(loss[1]),
+            **({"same_harness": same_harness} if same_harness else {}),
             "roofline": {"step": {"alg_bytes_per_edge_px": b_alg, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": ach / HBM_PEAK_GBS, "traffic": moved,
                                   "traffic_GBps": None if not moved else moved / (ms * 1e-3) / 1e9,
