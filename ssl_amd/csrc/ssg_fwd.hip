@@ -168,7 +168,36 @@ __device__ __forceinline__ bool fwd_tiled_group(const FwdParams &p, int grp) {
   }
   // ---- single variant: the jobs' k_s x k_s tiles of ONE channel, reflect by index mirroring.  All global loads (JOBS x
   // EPT per thread) are issued before the first LDS store (a plain loop pays the full L2 latency per element) ----
+  // Thread -> tile elements.  With whole tile rows per pass (thread = (row in pass, column): WG / k_s rows per pass) the
+  // column's mirrored x is one value per job and a row's mirrored y one per (job, pass) -- no division and a third of the
+  // index arithmetic of the linear map e = tid + k WG (20 VALU per load there: a fifth of the single variant's
+  // instructions at (25,9)); taken when it needs no more passes than the linear map.
+  constexpr int RPT = WG / KS, NPASS = (KS + RPT - 1) / RPT;
+  constexpr bool ROWMAP = RPT > 0 && NPASS <= (P + WG - 1) / WG;
+  const int f_row = tid / KS, f_col = tid - f_row * KS;
   auto fill_channel = [&](int c) {
+    if constexpr (ROWMAP) {
+      float v[JOBS][NPASS];
+      const bool t_on = f_row < RPT;
+#pragma unroll
+      for (int j = 0; j < JOBS; ++j) {
+        const int b = sh_edge[j * 6 + 0], y = sh_edge[j * 6 + 1], x = sh_edge[j * 6 + 2];
+        const float *src = p.img[sh_edge[j * 6 + 4]] + ((size_t)b * C + c) * H * W + reflect_idx(x - HP + f_col, W);
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+          const int ry = f_row + k * RPT;
+          v[j][k] = src[(size_t)reflect_idx(y - HP + (ry < KS ? ry : KS - 1), H) * W];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < JOBS; ++j)
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+          const int ry = f_row + k * RPT;
+          if (t_on && ry < KS) tiles[j * CH + ry * S + f_col] = v[j][k];
+        }
+      return;
+    }
     constexpr int EPT = (P + WG - 1) / WG;  // tile elements per thread
     float v[JOBS][EPT];
 #pragma unroll
