@@ -397,13 +397,13 @@ def extra_line(cfg_key, fused, dev, steps, warmup, maskgen=False):
     same_harness = None
     if maskgen:
         # mask_kind 2: the reference's offline Laplacian mask generated from GT inside the edge-list kernels.  The same
-        # step object with the fp32 mask is timed right before and right after (this harness, this point of the process):
-        # the difference of the two modes is what the on-device mask costs, whatever the box's clocks do meanwhile
-        before = timed(mask)
-        ms = timed(None)
-        after = timed(mask)
-        same_harness = {"fp32_mask_ms_before": before, "fp32_mask_ms_after": after,
-                        "delta_ms": ms - 0.5 * (before + after)}
+        # step object alternates between mask=None and the fp32 mask (this harness, this point of the process): the
+        # difference of the two modes is what the on-device mask costs, whatever the box's clocks do meanwhile
+        timed(mask)                      # (discarded: the clocks settle during the first block of a new workload)
+        runs = [timed(m) for m in (None, mask, None, mask)]
+        ms = 0.5 * (runs[0] + runs[2])
+        same_harness = {"mask_none_ms": [runs[0], runs[2]], "fp32_mask_ms": [runs[1], runs[3]],
+                        "delta_ms": ms - 0.5 * (runs[1] + runs[3])}
         mask = None
     else:
         ms = timed(mask)
