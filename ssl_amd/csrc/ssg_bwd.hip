@@ -515,8 +515,9 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
               const float g = red[j * SL * LPJ + (in ? ty * KS + tx : 0)];
               v += in ? g : 0.f;
             }
-            if (v != 0.f)
+            if (v != 0.f && !SSG_DBG(p, 32))   // (profiling ablation 32: the gather without its atomics)
               grad_add(p.grad, p.gfix, cb0 + (size_t)reflect_idx(my0 - HP + ry, H) * W + reflect_idx(mx0 - HP + rx, W), v, gsc);
+            if (SSG_DBG(p, 32) && v == 123456.f) red2[0] = v;   // (keeps the sums alive)
           }
         }
         lds_barrier();
