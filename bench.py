@@ -183,7 +183,7 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     p = engine._ptr
 
     # (the edge list as the fused step builds it: sizes with shared-term kernels take every job order from the plan,
-    #  the others have no plan -- four launches either way since round 4's banded builder)
+    #  the others have no plan -- three launches either way since the banded builder of round 4)
     dense_sizes = (KS, KW, C) in ((25, 9, 3), (49, 13, 3))
 
     def o_arg():

@@ -8,7 +8,7 @@
 // Two builders.  The chunked one: per-1024-pixel chunk counts, an exclusive scan of the chunk counts (one workgroup), an
 // order-preserving scatter, then the tile order / plan kernels on the rank map (7-12 launches; k_s 49 plans with their
 // strips, callers that want the full order AND a plan).  The BANDED one (further down; every other call): 8-row x
-// 256-column blocks give the row-segment counts and the tile counts in one pass -- four launches.
+// 256-column blocks give the row-segment counts and the tile counts in one pass -- three launches.
 #include "ssg_common.hpp"
 
 namespace ssg {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void tile_group_flags(int *order_a, const int 
   order[k0] = first | (ok ? ORDER_FLAG : 0);
 }
 
-// ---- banded builder (round 4): edge list, rank map, dense list and sparse order in FOUR launches instead of seven -----
+// ---- banded builder (round 4): edge list, rank map, dense list and sparse order in THREE launches instead of seven ----
 // A workgroup owns a band of 8 image rows x 256 columns: 32 strips of 8 pixels per row, one lane per strip.  Such a block
 // is a run of whole 8 x 8 order tiles (a strip IS a tile row) and of whole 8 x 32 super-tiles, and each of its row
 // segments is a contiguous piece of the reference's row-major edge order -- so one pass over the mask yields the
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void tile_group_flags(int *order_a, const int 
 //                 (rows from `capacity` on do not exist for the plan: same lists as the seven-launch builder); dense
 //                 list and flags from the tile counts; offsets of the sparse order; the plan's header
 //   band_scatter  edges, rank map and the tile-major order of the rows left to the direct kernels
-//   tile_group_flags as before
+//                 (+ the merge flags of the groups of ORDER_GROUP entries that lie inside the block)
 constexpr int BAND_COLS = 256;
 
 __device__ __forceinline__ unsigned strip_bits(const EdgeParams &p, int b, int y, int x0) {
@@ -736,15 +736,24 @@ __global__ __launch_bounds__(1024) void band_scan(int B, int H, int W, int nseg,
 }
 
 __global__ __launch_bounds__(256) void band_scatter(EdgeParams p, int nseg, const int *segoff, const uint8_t *bits_in,
-                                                    int *edges, int capacity, int *rank, const int *toff,
-                                                    const int *dflag, int *order_out) {
+                                                    int *edges, int capacity, int *rank, const int *toff, const int *tcnt,
+                                                    const int *dflag, int *order_out, const int *n_order) {
   __shared__ int s_v[8][33];
+  __shared__ unsigned short s_x[OT * BAND_COLS];   // column of every listed row of the block, by its place in the order
   const int tx_n = (p.W + OT - 1) / OT, ty_n = (p.H + OT - 1) / OT;
   const int seg = blockIdx.x % nseg, band = (blockIdx.x / nseg) % ty_n, b = blockIdx.x / (nseg * ty_n);
   const int r = threadIdx.x >> 5, g = threadIdx.x & 31;
   const int y = band * OT + r, sx = seg * 32 + g, x0 = sx * 8;
   const bool in = y < p.H && sx < tx_n;
   const unsigned bits = in ? bits_in[((size_t)b * p.H + y) * tx_n + sx] : 0u;
+  // (issued with the loads above: the order's offsets)
+  const size_t tile0 = ((size_t)b * ty_n + band) * tx_n;
+  const int sx_n = (p.W + 31) / 32;
+  const bool listed = in && order_out && !(dflag && dflag[((size_t)b * ty_n + band) * sx_n + sx / 4]);   // not a dense super-tile's
+  const int t_off = listed ? toff[tile0 + sx] : 0;
+  const int sx_last = seg * 32 + 31 < tx_n ? seg * 32 + 31 : tx_n - 1;
+  const int blk_first = order_out ? toff[tile0 + seg * 32] : 0;
+  const int blk_end = order_out ? toff[tile0 + sx_last] + tcnt[tile0 + sx_last] : 0;   // (dense tiles: count 0)
   const int c = __popc(bits);
   int incl = c;   // inclusive scan over the row's 32 lanes (a half-wave: lanes g >= o take from their own half)
 #pragma unroll
@@ -757,37 +766,61 @@ __global__ __launch_bounds__(256) void band_scatter(EdgeParams p, int nseg, cons
   valid = valid < 0 ? 0 : (valid < c ? valid : c);
   s_v[r][g] = valid;
   __syncthreads();
-  if (!in) return;
-  int rk[8];
-  int pos = pos0;
+  int idx = t_off;
+  for (int k = 0; k < r; ++k) idx += s_v[k][g];
+  if (in) {
+    int rk[8];
+    int pos = pos0, li = idx - blk_first;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const bool on = bits & (1u << k);
-    const bool ok = on && pos < capacity;
-    if (ok) {
-      edges[3 * (size_t)pos + 0] = b;
-      edges[3 * (size_t)pos + 1] = y;
-      edges[3 * (size_t)pos + 2] = x0 + k;
+    for (int k = 0; k < 8; ++k) {
+      const bool on = bits & (1u << k);
+      const bool ok = on && pos < capacity;
+      if (ok) {
+        edges[3 * (size_t)pos + 0] = b;
+        edges[3 * (size_t)pos + 1] = y;
+        edges[3 * (size_t)pos + 2] = x0 + k;
+        if (listed) s_x[li++] = (unsigned short)(x0 + k);   // (the block's listed rows: fewer than its 2,048 pixels)
+      }
+      rk[k] = ok ? pos : -1;   // rank map: row index of every pixel (-1: not an edge pixel / beyond capacity)
+      if (on) ++pos;
     }
-    rk[k] = ok ? pos : -1;   // rank map: row index of every pixel (-1: not an edge pixel / beyond capacity)
-    if (on) ++pos;
-  }
-  int *rrow = rank + ((size_t)b * p.H + y) * p.W + x0;
-  if (x0 + 8 <= p.W && ((size_t)rrow & 15) == 0) {
-    *(int4 *)rrow = make_int4(rk[0], rk[1], rk[2], rk[3]);
-    *(int4 *)(rrow + 4) = make_int4(rk[4], rk[5], rk[6], rk[7]);
-  } else {
+    int *rrow = rank + ((size_t)b * p.H + y) * p.W + x0;
+    if (x0 + 8 <= p.W && ((size_t)rrow & 15) == 0) {
+      *(int4 *)rrow = make_int4(rk[0], rk[1], rk[2], rk[3]);
+      *(int4 *)(rrow + 4) = make_int4(rk[4], rk[5], rk[6], rk[7]);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (x0 + k < p.W) rrow[k] = rk[k];
+      for (int k = 0; k < 8; ++k)
+        if (x0 + k < p.W) rrow[k] = rk[k];
+    }
   }
-  if (order_out && valid > 0) {
-    const int sx_n = (p.W + 31) / 32;
-    if (dflag && dflag[((size_t)b * ty_n + band) * sx_n + sx / 4]) return;   // rows of a dense super-tile
-    int idx = toff[((size_t)b * ty_n + band) * tx_n + sx];
-    for (int k = 0; k < r; ++k) idx += s_v[k][g];
-    for (int j = 0; j < valid; ++j)
-      if (idx + j < capacity) order_out[idx + j] = pos0 + j;   // (a strip's rows are consecutive in the edge order)
+  if (!order_out) return;
+  __syncthreads();
+  // The order's entries with the merge flag of tile_group_flags on the first entry of every group of ORDER_GROUP that lies
+  // inside this block: one image and 8 rows by construction, so the flag is "within MERGE_COLS columns".  A group that
+  // runs across two blocks stays unflagged (the single variants take it: same values) -- across band rows it could
+  // only qualify in an image of <= MERGE_COLS columns.
+  if (listed && valid > 0) {
+    int n = n_order[0];
+    n = n < capacity ? n : capacity;
+    for (int j = 0; j < valid; ++j) {
+      const int k0 = idx + j;
+      if (k0 >= capacity) break;
+      int e = pos0 + j;   // (a strip's rows are consecutive in the edge order)
+      if (k0 % ORDER_GROUP == 0) {
+        const int gend = k0 + ORDER_GROUP < n ? k0 + ORDER_GROUP : n;
+        if (gend <= blk_end) {
+          int lo = 1 << 30, hi = -1;
+          for (int q = k0 - blk_first; q < gend - blk_first; ++q) {
+            const int x = s_x[q];
+            lo = x < lo ? x : lo;
+            hi = x > hi ? x : hi;
+          }
+          if (hi - lo <= MERGE_COLS - 1) e |= ORDER_FLAG;
+        }
+      }
+      order_out[k0] = e;
+    }
   }
 }
 
@@ -917,12 +950,9 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
     hipLaunchKernelGGL(band_count, dim3(grid), dim3(256), 0, st, p, nseg, segcnt, tcnt, bits, z);
     hipLaunchKernelGGL(band_scan, dim3(1), dim3(1024), 0, st, B, H, W, nseg, segcnt, segoff, counts, capacity, bits, tcnt, toff,
                        dense_thr, plan ? dflag : nullptr, plan);
-    hipLaunchKernelGGL(band_scatter, dim3(grid), dim3(256), 0, st, p, nseg, segoff, bits, edges, capacity, rank, toff,
-                       plan ? dflag : nullptr, order_out);
-    const int ngroups = (capacity + ORDER_GROUP - 1) / ORDER_GROUP;
-    if (ngroups > 0)
-      hipLaunchKernelGGL(tile_group_flags, dim3((ngroups + 255) / 256, 1), dim3(256), 0, st, order_out, plan ? plan : counts,
-                         nullptr, nullptr, edges, capacity);
+    // (the merge flags of the groups are set by the scatter pass itself: three launches)
+    hipLaunchKernelGGL(band_scatter, dim3(grid), dim3(256), 0, st, p, nseg, segoff, bits, edges, capacity, rank, toff, tcnt,
+                       plan ? dflag : nullptr, order_out, plan ? plan : counts);
     return (int)hipGetLastError();
   }
   int *blockcnt = (int *)scratch, *blockoff = blockcnt + nblk;

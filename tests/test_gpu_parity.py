@@ -2021,11 +2021,13 @@ def _plan_reference(mask_bool, cap, thr, with_plan):
                 order.extend(r[r >= 0].tolist())
     order = np.array(order, np.int64)
     flags = np.zeros(len(order), bool)
+    banded = np.zeros(len(order), bool)   # the banded builder flags the groups that lie inside one 8-row x 256-column block
     for k0 in range(0, len(order), 5):
         rows = order[k0:k0 + 5]
         flags[k0] = (len(set(bs[rows])) == 1 and ys[rows].max() - ys[rows].min() <= 7 and xs[rows].max() - xs[rows].min() <= 15)
+        banded[k0] = flags[k0] and len(set(zip(bs[rows], ys[rows] // 8, xs[rows] // 256))) == 1
     return dict(N=N, edges=np.stack([bs, ys, xs], 1)[:n_ok], rank=rank, heavy=heavy, light=light, order=order, flags=flags,
-                first=np.searchsorted(bs, np.arange(B)))
+                flags_banded=banded, first=np.searchsorted(bs, np.arange(B)))
 
 
 @pytest.mark.gpu
@@ -2039,7 +2041,7 @@ def _plan_reference(mask_bool, cap, thr, with_plan):
     (1, 33, 40, 0.0, 0, None, "f32"),         # empty mask
 ])
 def test_banded_edge_list_builder_vs_numpy(dev, B, H, W, dens, stride, cap_frac, kind):
-    """The four-launch banded builder (ssg_edges.hip: band_count / band_scan / band_scatter / tile_group_flags): edges,
+    """The banded builder (ssg_edges.hip: band_count / band_scan / band_scatter, three launches): edges,
     counts, rank map, the plan's header and dense lists, sparse order and merge flags against a numpy restatement, with
     a plan ((25,9) sizes) and without one ((11,5) sizes: the full tile-major order), with blobs so that tiles of every
     class (sparse, light, heavy, huge) occur."""
@@ -2081,7 +2083,7 @@ def test_banded_edge_list_builder_vs_numpy(dev, B, H, W, dens, stride, cap_frac,
                 n_sp, od = n_ok, el.order.cpu().numpy()
             assert n_sp == len(ref["order"])
             assert np.array_equal(od[:n_sp] & ((1 << 30) - 1), ref["order"])
-            assert np.array_equal((od[:n_sp] >> 30) & 1, ref["flags"].astype(od.dtype))
+            assert np.array_equal((od[:n_sp] >> 30) & 1, ref["flags_banded"].astype(od.dtype))
         # the seven-launch builder (taken when a caller wants the full order AND a plan) leaves the same lists
         el = engine.edge_list(mask=mk, mask_stride=stride, capacity=cap, ks=25, order=True, plan=True)
         ref, full = _plan_reference(eff, cap, 20, True), _plan_reference(eff, cap, 20, False)
