@@ -12,7 +12,7 @@ f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # one step = from an edge_count launch to the next one; take the 6th (inside the timed loop)
-idx = [i for i, r in enumerate(rows) if 'edge_count' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'band_count' in r['Kernel_Name'] or 'edge_count' in r['Kernel_Name']]
 a, b = idx[5], idx[6]
 t0 = int(rows[a]['Start_Timestamp']); prev_end = t0
 print("step span %.1f us, %d kernels" % ((int(rows[b]['Start_Timestamp']) - t0) / 1e3, b - a))
