@@ -22,7 +22,7 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
                 libssg_hip_prof.so -- the product library has no such switch);
                 `kernel_ms` lists every kernel of the step measured that way (each ALONE on the chip: inside the
                 step the direct kernel of a pass runs on a side stream beside the dense one for k_s <= 25, so the
-                step is shorter than their sum; profiles/*_kernel_stats.csv is taken with SSG_OVERLAP=0 for the
+                step is shorter than their sum; profiles/*_kernel_stats.csv is taken with --no-overlap for the
                 same reason), `step` repeats the figure over the whole step's GPU time, `valu` prices the same
                 time against the fp32 vector peak.
   extra         (N = 1, default config only) the other lines a reader wants next to the headline, measured in the same
@@ -46,6 +46,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
+    # BASELINE configs[0]: the reference's own CPU-runnable case (uniform-noise pair, fixed 5 % mask incl. corners)
+    "c1": dict(ks=11, kw=5, sigma=1.0, batch=1, H=64, W=64, dense_mask=False, uniform=True,
+               name="C1: 1 x 3x64x64, fixed 5 % mask (209 px), k_s=11 k_w=5 sigma=1.0, L1+KL w=1e3, SSGs materialised"),
     "c2": dict(ks=25, kw=9, sigma=1.0, batch=16, H=256, W=256, dense_mask=False,
                name="C2: batch 16 x 3x256x256 per GPU, Laplacian mask, k_s=25 k_w=9 sigma=1.0, L1+KL w=1e3, SSGs materialised"),
     "c5": dict(ks=49, kw=13, sigma=1.0, batch=1, H=512, W=512, dense_mask=True,
@@ -576,11 +579,27 @@ def operator_line(cfg, sr, mask):
     return res
 
 
+def step_share_lines(dev):
+    """SURVEY 8d's reporting grid for BASELINE configs[2] / [3]: a training step with the SSL engine vs with SSL disabled
+    (stand-in generator / decoder of the published shapes on stock PyTorch-ROCm, tools/train_step_bench.py -- context for
+    the measurement, not product code; call sites realesrganssl_model.py:379-430, ddpmssl.py:438-513)."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("train_step_bench", os.path.join(ROOT, "tools", "train_step_bench.py"))
+    tsb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tsb)
+    out = {"c3_step_share": tsb.c3_step_share(dev), "c4_step_share": tsb.c4_step_share(dev)}
+    torch.cuda.empty_cache()
+    return out
+
+
 def make_inputs(cfg, rank, world, scaling):
     """Synthetic batch of this rank (numpy): weak = `batch` images per rank, strong = the rank's share of ONE batch."""
     import numpy as np
     from ssl_amd import synth
     B, H, W = cfg["batch"], cfg["H"], cfg["W"]
+    if cfg.get("uniform"):
+        return synth.uniform_case(H, W)
     if cfg["dense_mask"]:
         gt = np.stack([synth.natural_like(300 + rank * B + i, H, W) for i in range(B)])
         sr = np.stack([synth.degrade(gt[i], 7 + rank * B + i) for i in range(B)])
@@ -602,11 +621,15 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 16 images per GPU; strong: the 16 images split over the GPUs (SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the timed pre-warm before the W warm-up steps")
     ap.add_argument("--no-module", action="store_true", help="skip the SSGLoss (nn.Module) timing")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` block (C5 and the fused steps)")
     ap.add_argument("--no-kernel-table", action="store_true",
                     help="skip the per-kernel table (it launches the kernels one at a time through the separate entry "
                          "points): a rocprofv3 run of the fused step then shows that step's own kernels only")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="ssg_set_overlap(0): every launch on the caller's stream -- for rocprofv3 --kernel-trace runs, whose "
+                         "per-kernel durations otherwise include the time a kernel shares the chip with its side-stream twin")
     ap.add_argument("--no-ssg-output", action="store_true",
                     help="the fused step of the C ABI (ssg_sr = ssg_gt = NULL): a SEPARATE metric with SURVEY 8d's "
                          "B_alg' = (12C+4)HW/N -- not comparable with the default line")
@@ -641,6 +664,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ssl_amd import synth
+    if args.no_overlap and not args.dry_run:
+        from ssl_amd import engine
+        engine.set_overlap(False)
     sr_np, gt_np, mask_np = make_inputs(cfg, rank, world, args.scaling)
     B = sr_np.shape[0]
     n_edges = int(effective_mask(cfg, mask_np).sum())
@@ -667,6 +693,24 @@ def main():
             if step is not None:
                 step(sr, gt, mask)
 
+    # Pre-warm BY TIME before the counted warm-up (disclosure, not tuning: a fresh box ramps its shader clock over the
+    # first tens of milliseconds of work, and `--warmup 10` is 13 ms of GPU time at C2): 10-step blocks until two
+    # consecutive ones agree to 1 % or 0.5 s have passed.  Reported as config.prewarm_steps / prewarm_ms; the W warm-up
+    # steps and the K timed steps below are exactly the ones asked for.
+    prewarm_steps, prewarm_t0, last_blk = 0, time.perf_counter(), None
+    if not args.dry_run and not args.no_prewarm and step is not None:
+        torch.cuda.synchronize()
+        while time.perf_counter() - prewarm_t0 < 0.5:
+            tb = time.perf_counter()
+            for _ in range(10):
+                run_step()
+            torch.cuda.synchronize()
+            blk = time.perf_counter() - tb
+            prewarm_steps += 10
+            if last_blk is not None and abs(blk - last_blk) <= 0.01 * last_blk:
+                break
+            last_blk = blk
+    prewarm_ms = (time.perf_counter() - prewarm_t0) * 1e3 if prewarm_steps else 0.0
     for _ in range(args.warmup):
         run_step()
     sync_all()
@@ -690,18 +734,22 @@ def main():
 
     tot_edges = torch.tensor([float(n_edges)], device=dev, dtype=torch.float64)
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    tmin = tmax.clone()
     ranks_seen = 1
     if use_dist:
         dist.all_reduce(tot_edges, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         ranks_seen = dist.get_world_size()
+    rank_ms_min, rank_ms_max = float(tmin) / max(args.steps, 1) * 1e3, float(tmax) / max(args.steps, 1) * 1e3
     elapsed = float(tmax)
     total_edges = float(tot_edges)
 
     if rank == 0:
         value = total_edges * args.steps / elapsed
         res = {
-            "metric": {"c2": "SSG-loss edge-pixels/sec (fwd+bwd) 3x256x256 k_s=25 k_w=9",
+            "metric": {"c1": "SSG-loss edge-pixels/sec (fwd+bwd) 3x64x64 k_s=11 k_w=5",
+                       "c2": "SSG-loss edge-pixels/sec (fwd+bwd) 3x256x256 k_s=25 k_w=9",
                        "c4": "SSG-loss edge-pixels/sec (fwd+bwd) 3x512x512 k_s=25 k_w=9 mask_stride=3 eps=1e-20",
                        "c5": "SSG-loss edge-pixels/sec (fwd+bwd) 3x512x512 k_s=49 k_w=13 dense mask"}[args.config] +
                       (" [fused step, no SSG output: B_alg' = (12C+4)HW/N]" if args.no_ssg_output else ""),
@@ -711,12 +759,17 @@ def main():
             "config": {"workload": (cfg["name"].replace("SSGs materialised", "fused step: no SSG output")
                                     if args.no_ssg_output else cfg["name"]) +
                                    (" (16 images split over the GPUs)" if args.scaling == "strong" else ""),
-                       "launch": "HIP graph replay" if args.graph else "per-kernel", "ranks_seen": ranks_seen,
+                       "launch": ("HIP graph replay" if args.graph else "per-kernel") + (", no side stream" if args.no_overlap else ""), "ranks_seen": ranks_seen,
+                       "rank_ms_per_step_min": rank_ms_min, "rank_ms_per_step_max": rank_ms_max,
                        "edge_px_rank0": n_edges, "edge_px_total": total_edges, "images_rank0": B,
                        "mask_density": n_edges / max(B * cfg["H"] * cfg["W"], 1),
                        "input_checksum": synth.checksum(sr_np, gt_np, mask_np),
                        "gradient_accumulation": "fixed-point integer atomics (bit-reproducible, the shipped default)",
-                       "ms_per_step_blocks": blocks, "sclk_after_timed_region": gpu_clock(),
+                       "prewarm_steps": prewarm_steps, "prewarm_ms": prewarm_ms,
+                       "ms_per_step_blocks": blocks,
+                       "ms_per_step_block2": blocks[1] if len(blocks) > 1 else None,
+                       "ms_per_step_block3": blocks[2] if len(blocks) > 2 else None,
+                       "sclk_after_timed_region": gpu_clock(),
                        "parallelism": f"images sharded x{world}, no data-path collective"},
         }
         if args.dry_run:
@@ -733,13 +786,13 @@ def main():
             # tile-major rows (ssg_fwd_strip, ssg_rows_tm[_mat], ssg_bwd_dense<..., TM>) while the separate entry points
             # run the row-major kernels: that step's per-kernel figures are the committed rocprofv3 stats.
             key = ("c5f" if args.no_ssg_output else "c5") if args.config == "c5" else (None if args.no_ssg_output else args.config)
-            if args.no_kernel_table or cfg["ks"] == 49:
+            if args.no_kernel_table or cfg["ks"] == 49 or args.config == "c1":
                 step_gpu_ms = event_time_ms(lambda: step(sr, gt, mask), it)
                 ach_step = b_alg * n_edges / (step_gpu_ms * 1e-3) / 1e9
                 moved = pmc_step_bytes(key)
                 res["roofline"] = {"bound": "hbm", "alg_bytes_per_edge_px": b_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS, "traffic": moved,
-                                   "kernel": "whole step (per-kernel durations: profiles/r4_bench_%s_kernel_stats.csv)" % (key or "c2"),
+                                   "kernel": "whole step (per-kernel durations: profiles/r5_bench_%s_kernel_stats.csv)" % (key or "c2"),
                                    "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS,
                                             "traffic": moved,
                                             "traffic_GBps": None if not moved else moved / (step_gpu_ms * 1e-3) / 1e9,
@@ -784,14 +837,16 @@ def main():
                                  "ms_per_step": mm, "value": n_edges / (mm * 1e-3), "unit": "edge-px/s"}
             if world == 1 and not args.no_extra and args.config == "c2" and not args.no_ssg_output:
                 # the other configuration / mode lines, driver-visible (about 2 s of GPU time in all)
-                res["extra"] = {"c5": extra_line("c5", False, dev, 10, 3),
+                res["extra"] = {"c1": extra_line("c1", False, dev, 200, 50),
+                                "c5": extra_line("c5", False, dev, 10, 3),
                                 "c2_fused": extra_line("c2", True, dev, 30, 5),
                                 "c5_fused": extra_line("c5", True, dev, 10, 3),
                                 "c4": extra_line("c4", False, dev, 50, 10),
                                 "c2_maskgen": extra_line("c2", False, dev, 30, 5, maskgen=True),
                                 "ref_api": ref_api_lines(cfg, sr, gt, mask, n_edges, elapsed / args.steps * 1e3),
                                 "ref_api_dm": ref_api_dm_line(dev),
-                                "operator": operator_line(cfg, sr, mask)}
+                                "operator": operator_line(cfg, sr, mask),
+                                **step_share_lines(dev)}
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg, sr_np, gt_np, mask_np)
                 res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]

@@ -57,6 +57,9 @@ typedef void *ssg_stream_t; /* hipStream_t */
 
 /* 4 (round 4): + ssg_device_status, ssg_criteria_sums / _grad / _scratch_bytes, SSG_E_ALIGN, SSG_E_PLAN; a fused step
  * whose edge count exceeds its capacity returns NaN losses; a plan of the wrong tile height no longer traps. */
+/* 5 (round 5): + ssg_set_overlap; the product library no longer reads ANY environment variable (SSG_DENSE_THR,
+ * SSG_OVERLAP, SSG_OP_PLAN_FROM ... are honoured by the profiling build only); the one-wave tile-major dense backward
+ * is gone. */
 int ssg_abi_version(void);
 const char *ssg_status_string(int status);
 /* Device-side refusals that no return value can carry (everything is asynchronous): waits for `stream`, then returns
@@ -152,12 +155,17 @@ int ssg_compute_similarity_backward(const float *image, const float *grads,
 size_t ssg_edge_scratch_bytes(int B, int H, int W);
 size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
 /* Threshold (edge pixels per 8x32 tile) from which the forward routes a tile to the
- * shared-term kernel; 0 = never.  Default 18 (initial value overridable with the
- * environment variable SSG_DENSE_THR).  Results are the same either way (parity-tested
+ * shared-term kernel; 0 = never.  Default 18.  Results are the same either way (parity-tested
  * with every tile routed through it and with none).  Process-wide; takes effect at the
  * next ssg_edge_list().  Returns the previous value.  No reference counterpart: the
  * reference has one code path. */
 int ssg_set_dense_threshold(int edge_pixels_per_tile);
+/* on = 0: every launch of a call goes to the caller's stream; on != 0 (default): for k_s <= 25 the direct kernel of a
+ * pass runs on a library-owned side stream beside the dense-tile kernel (event fork / join on the caller's stream;
+ * capturable).  Same results either way (the two work on disjoint rows).  Process-wide; returns the previous setting.
+ * Used to take per-kernel rocprofv3 durations.  No reference counterpart (the reference launches on the legacy stream,
+ * similarity.cu:69,147). */
+int ssg_set_overlap(int on);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int H, int W, int mask_stride, float lap_threshold,
                   int plan_ks /* k_s the fwd_plan is built for (tile rows: 8, or 4 for k_s = 49); 0 = 25.

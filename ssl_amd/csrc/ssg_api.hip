@@ -59,6 +59,7 @@ bool grow_supported(int ks, int kw);
 unsigned grow_grid(int n_host);
 int launch_grad_rows(const GrowParams &p, int ks, int kw, hipStream_t st);
 int launch_rows_tm(const TmRowsParams &p, int ks, int kw, hipStream_t st);
+int rows_tm_parts(int n_tiles);
 int launch_pos_to_mask(const int *pos, int mc, int Hp, int Wp, uint8_t *mask, hipStream_t st);
 int launch_pos_relabel(const int *pos, int mc, int Hp, int Wp, int *rank, int *perm, int *dup, int *ndup, int *plan,
                        int *order2, hipStream_t st);
@@ -91,14 +92,13 @@ using namespace ssg;
 // round, after the direct forward had lost 9 % of its instructions (profiles/r4_dense_threshold_18_vs_20.txt, three
 // alternations): 18 against 20: C2 1.2771 vs 1.2849, fused 1.2225 vs 1.2309, C4 0.5024 vs 0.5196, Bernoulli 4 % 0.4925
 // vs 0.4868, 1 % equal (16 costs the Bernoulli masks 3 %, 24 and above cost C4 4 %).
-// ssg_set_dense_threshold(n) or the environment variable SSG_DENSE_THR (read at first use) override it.
+// ssg_set_dense_threshold(n) overrides it (profiling build: also the environment variable SSG_DENSE_THR at first use).
 constexpr int DENSE_THR_DEFAULT = 18;
 static std::atomic<int> g_dense_thr{-1};   // (atomic: the ABI may be called from several host threads)
 static int dense_threshold() {
   int v = g_dense_thr.load(std::memory_order_relaxed);
   if (v < 0) {
-    const char *e = getenv("SSG_DENSE_THR");
-    v = e ? atoi(e) : DENSE_THR_DEFAULT;
+    v = env_int("SSG_DENSE_THR", DENSE_THR_DEFAULT);
     if (v < 0) v = 0;
     g_dense_thr.store(v, std::memory_order_relaxed);
   }
@@ -122,8 +122,7 @@ static std::atomic<int> g_dbg{-1};
 static int dbg_mask() {
   int v = g_dbg.load(std::memory_order_relaxed);
   if (v < 0) {
-    const char *e = getenv("SSG_DEBUG_SKIP");
-    v = e ? atoi(e) : 0;
+    v = env_int("SSG_DEBUG_SKIP", 0);
     if (v < 0) v = 0;
     g_dbg.store(v, std::memory_order_relaxed);
   }
@@ -142,20 +141,28 @@ static constexpr int dbg_mask() { return 0; }
 // atomics), so the direct one runs on a side stream beside the dense one: fork = side waits for an event on the
 // caller's stream, join = the caller's stream waits for the side's event.  Both are plain event edges, so a stream
 // capture of the caller's stream (hipGraph) records the fork as two parallel branches.  One side stream and two
-// events per (host thread, device); SSG_OVERLAP=0 keeps every launch on the caller's stream.  Measured on MI355X:
+// events per (host thread, device); ssg_set_overlap(0) keeps every launch on the caller's stream.  Measured on MI355X:
 // C2 (k_s 25) 1.541 -> 1.510 ms per step; C5 (k_s 49, every kernel already fills the chip for its whole run)
 // 9.15 -> 9.64 ms -- so the fork is taken for k_s <= 25 only.
 struct SideStream {
   hipStream_t side = nullptr;
   hipEvent_t forked = nullptr, joined = nullptr;
 };
+static std::atomic<int> g_overlap{-1};
 static bool overlap_enabled() {
-  static int v = -1;
+  int v = g_overlap.load(std::memory_order_relaxed);
   if (v < 0) {
-    const char *e = getenv("SSG_OVERLAP");
-    v = e ? (atoi(e) != 0) : 1;
+    v = env_int("SSG_OVERLAP", 1) != 0;
+    g_overlap.store(v, std::memory_order_relaxed);
   }
   return v != 0;
+}
+// ssg_set_overlap(0): every launch on the caller's stream (per-kernel rocprofv3 durations: profiles/*_kernel_stats.csv
+// are taken that way; same results -- the two branches work on disjoint rows).  Returns the previous setting.
+extern "C" int ssg_set_overlap(int on) {
+  const int prev = overlap_enabled() ? 1 : 0;
+  g_overlap.store(on ? 1 : 0, std::memory_order_relaxed);
+  return prev;
 }
 static SideStream *side_stream() {
   constexpr int MAXDEV = 64;
@@ -217,12 +224,11 @@ static bool sizes_ok(int ks, int kw) { return ks > 0 && kw > 0 && (ks & 1) && (k
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Waves per tile of the dense-tile backward (each takes a contiguous range of offset rows): by default chosen on the
-// device so that the launch fills the chip about once; SSG_BWD_QSPLIT fixes it for experiments.
+// device so that the launch fills the chip about once; SSG_BWD_QSPLIT fixes it in the profiling build (experiments).
 static int bwd_qsplit() {   // 0 = chosen on the device from the number of dense tiles (DenseBwdParams::qsplit)
   static int v = -1;
   if (v < 0) {
-    const char *e = getenv("SSG_BWD_QSPLIT");
-    v = e ? atoi(e) : 0;
+    v = env_int("SSG_BWD_QSPLIT", 0);
     if (v < 0) v = 0;
     if (v > 25) v = 25;
   }
@@ -237,7 +243,9 @@ static size_t split_scratch_bytes(int n_rows, int ks) {
 
 // Tile-major scratch rows of the fused step at k_s = 49 (TmRowsParams, ssg_common.hpp): the dense tiles in the first
 // `slots` places of the plan keep their e rows in a second rows region, tile by tile, and the three kernels that touch
-// them move whole 256-byte runs.  SSG_TILE_MAJOR=0 keeps every row row-major (A/B measurements).
+// them move whole 256-byte runs.  (Profiling build: SSG_TILE_MAJOR=0 keeps every row row-major, SSG_STRIPS=0 leaves
+// every tile-major tile to the tile kernel -- A/B measurements; a product caller gets the row-major step by not giving
+// the workspace the tile-major bytes, LossStep(tile_major=False).)
 struct TileMajor {
   float *rows[2] = {nullptr, nullptr};
   int slots = 0;
@@ -245,16 +253,14 @@ struct TileMajor {
 static bool strips_enabled() {   // SSG_STRIPS=0: the tile kernel computes every tile-major tile (A/B measurements)
   static int v = -1;
   if (v < 0) {
-    const char *e = getenv("SSG_STRIPS");
-    v = e ? (atoi(e) != 0) : 1;
+    v = env_int("SSG_STRIPS", 1) != 0;
   }
   return v != 0;
 }
 static bool tile_major_enabled() {
   static int v = -1;
   if (v < 0) {
-    const char *e = getenv("SSG_TILE_MAJOR");
-    v = e ? (atoi(e) != 0) : 1;
+    v = env_int("SSG_TILE_MAJOR", 1) != 0;
   }
   return v != 0;
 }
@@ -346,7 +352,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   }
   if (rc || !p.grad) return rc;
   if (p.gfix) {
-    rc = launch_grad_fix_reduce(gmax_part, (int)grow_grid(p.n_host) + n_tm, p.gfix, (size_t)p.B * p.C * p.H * p.W, st);
+    rc = launch_grad_fix_reduce(gmax_part, (int)grow_grid(p.n_host) + rows_tm_parts(n_tm), p.gfix, (size_t)p.B * p.C * p.H * p.W, st);
     if (rc) return rc;
   }
   const float *grows = p.mode == GRAD_D ? p.gin : G;
@@ -422,13 +428,12 @@ static int det_end(const BwdParams &p, hipStream_t st, bool assign = false) {
 // ms forward at 4,820) and lose above (0.251 vs 0.197 ms at 18,417; forward + backward 0.733 vs 0.454).
 constexpr int OP_PLAN_FROM_DEFAULT = 8192;
 static std::atomic<int> g_op_plan_from{-1};
-// positions from which a call takes the plan path (0x7fffffff = never); SSG_OP_PLAN_FROM / ssg_set_operator_plan_threshold
+// positions from which a call takes the plan path (0x7fffffff = never); ssg_set_operator_plan_threshold
 // (n <= 0: never)
 static int op_plan_from() {
   int v = g_op_plan_from.load(std::memory_order_relaxed);
   if (v < 0) {
-    const char *e = getenv("SSG_OP_PLAN_FROM");
-    v = e ? atoi(e) : OP_PLAN_FROM_DEFAULT;
+    v = env_int("SSG_OP_PLAN_FROM", OP_PLAN_FROM_DEFAULT);
     if (v <= 0) v = 0x7fffffff;
     g_op_plan_from.store(v, std::memory_order_relaxed);
   }
@@ -539,7 +544,7 @@ static bool split_ok(int ks, int kw, int C, const int *rank, const int *plan, co
 
 extern "C" {
 
-int ssg_abi_version(void) { return 4; }
+int ssg_abi_version(void) { return 5; }
 
 const char *ssg_status_string(int status) {
   switch (status) {
@@ -875,7 +880,7 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   int nparts;
   bool fin_done = false;
   if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
-    nparts = (int)grow_grid(n_rows) + split_tm_tiles(p, tm);
+    nparts = (int)grow_grid(n_rows) + rows_tm_parts(split_tm_tiles(p, tm));
     const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0};
     rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done, tm);
   } else {

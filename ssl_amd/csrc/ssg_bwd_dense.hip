@@ -907,8 +907,9 @@ int launch_bwd_dense(const DenseBwdParams &p0, int ks, int kw, int C, hipStream_
   const bool tm = ks == 49 && p.tm[0] && p.tm[1] && p.row_scale && p.dot && p.tm_slots > 0;
   if (!tm) p.tm_slots = 0;
   if (ks == 49) {
-    static const bool split = !(getenv("SSG_BWD_TM_SPLIT") && atoi(getenv("SSG_BWD_TM_SPLIT")) == 0);
-    int rc = !tm ? 0 : split ? launch_one<49, 13, 3, 4, 2, 4, true, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st) : launch_one<49, 13, 3, 4, 2, 4, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st);
+    // (tile-major rows: the role-split two-wave instantiation; round 3's one-wave kernel -- 256 VGPR + 136 AGPR, 2.50 ms
+    // against 1.98 at C5 -- is no longer instantiated)
+    int rc = !tm ? 0 : launch_one<49, 13, 3, 4, 2, 4, true, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st);
     if (!rc) rc = launch_one<49, 13, 3, 4, 2, 4, false>(p, p.max_tiles, st);
     return rc;
   }

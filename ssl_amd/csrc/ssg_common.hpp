@@ -219,8 +219,35 @@ __device__ __forceinline__ float criteria_elem(float a, float b, float w1m, floa
   const float ratio = __builtin_fmaf(__builtin_fmaf(-r0, ac, bc), rc, r0);
   kl += bc * (0.69314718056f * __builtin_amdgcn_logf(ratio));
   float g = a > b ? w1m : (a < b ? -w1m : 0.f);
-  if (a >= cl) g -= w2m * ratio;
+  if (a >= cl && w2m != 0.f) g -= w2m * ratio;   // (an L1-only gradient never sees the ratio: it may overflow on foreign tensors)
   return g;
+}
+
+// The same on tensors the engine did not produce (L1Loss / KLDistanceLoss on arbitrary fp32 GPU tensors, basic_loss.py):
+// a NaN in either operand reaches both sums and the gradient, as it does through torch.clamp / F.kl_div / sign
+// (v_max_f32 would drop it: fmaxf(NaN, 1e-10) = 1e-10).
+__device__ __forceinline__ float criteria_elem_any(float a, float b, float w1m, float w2m, float &l1, float &kl) {
+  float g = criteria_elem(a, b, w1m, w2m, l1, kl);
+  if (a != a || b != b) {
+    const float qnan = __builtin_nanf("");
+    kl = qnan;
+    g = qnan;
+  }
+  return g;
+}
+
+// Environment switches exist in the PROFILING build only (libssg_hip_prof.so, -DSSG_PROFILE: the A/B measurements of
+// tools/).  The product library never reads the environment: what it does is set through the C ABI
+// (ssg_set_dense_threshold, ssg_set_operator_plan_threshold, ssg_set_overlap) or not at all, so that every path it can
+// take is one a test can reach (tests/test_cpu_host.py checks the binary for "SSG_" strings).
+inline int env_int(const char *name, int dflt) {
+#ifdef SSG_PROFILE
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel,

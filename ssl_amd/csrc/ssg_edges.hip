@@ -905,7 +905,7 @@ size_t edge_scratch_bytes(int B, int H, int W) {
 }
 
 static bool banded_enabled() {
-  static const bool on = !(getenv("SSG_EDGE_BANDED") && atoi(getenv("SSG_EDGE_BANDED")) == 0);
+  static const bool on = env_int("SSG_EDGE_BANDED", 1) != 0;   // (profiling build only: the chunked builder for every call)
   return on;
 }
 

@@ -518,11 +518,7 @@ static int launch_fwd_pair(FwdParams p, hipStream_t st) {
     // the small-call variant (SMALL_CALL_JOBS): alone when the host's bound on the jobs says so, together with the
     // regular ones -- the device-side count picks -- while the bound is within 8x of it (a generous capacity), not at all
     // beyond (C2's 155 k jobs: no third launch)
-    static int mode = -1;   // SSG_FWD_SMALL=0: never (A/B measurements)
-    if (mode < 0) {
-      const char *e = getenv("SSG_FWD_SMALL");
-      mode = e ? (atoi(e) != 0) : 1;
-    }
+    static const int mode = env_int("SSG_FWD_SMALL", 1) != 0;   // (profiling build: SSG_FWD_SMALL=0 = never, A/B measurements)
     const long bound = (long)p.n_host * p.nimg;
     if (mode && bound <= 8L * SMALL_CALL_JOBS) {
       using GS3 = Geo<25, 9, 3, 256>;

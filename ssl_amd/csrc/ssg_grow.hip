@@ -171,10 +171,10 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
   const int tslot = blockIdx.x;
   if (tslot >= dense_tile_count(p.n_dense) || p.n_dense[1] != TY ||
       !tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host))) {
-    if (threadIdx.x == 0) {
-      p.partials[2 * tslot] = 0.f;
-      p.partials[2 * tslot + 1] = 0.f;
-      if (p.gmax_part) p.gmax_part[tslot] = 0.f;
+    if (threadIdx.x < 2) {   // (two partial slots per tile: rows_tm_parts)
+      p.partials[2 * (2 * tslot + threadIdx.x)] = 0.f;
+      p.partials[2 * (2 * tslot + threadIdx.x) + 1] = 0.f;
+      if (p.gmax_part) p.gmax_part[2 * tslot + threadIdx.x] = 0.f;
     }
     return;
   }
@@ -295,39 +295,47 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm(TmRowsParams p) {
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    p.partials[2 * tslot] = wred[0][0] + wred[0][1];
-    p.partials[2 * tslot + 1] = wred[1][0] + wred[1][1];
-    if (p.gmax_part) p.gmax_part[tslot] = fmaxf(wred[2][0], wred[2][1]);
+  if (threadIdx.x < 2) {   // one partial slot per chunk, as the materialising kernel leaves them
+    p.partials[2 * (2 * tslot + threadIdx.x)] = wred[0][threadIdx.x];
+    p.partials[2 * (2 * tslot + threadIdx.x) + 1] = wred[1][threadIdx.x];
+    if (p.gmax_part) p.gmax_part[2 * tslot + threadIdx.x] = wred[2][threadIdx.x];
   }
 }
 
 // The same pass when the call MATERIALISES its SSG tensors (ssg_sr / ssg_gt are the caller's (n, k_s^2) row-major rows):
-// besides the sums above it writes the normalised rows.  The eight parts of a chunk split the 49 offsets of ONE offset
-// row here (6-7 columns each) instead of the offset rows, so that the whole workgroup finishes an offset row together:
-// the values of two offset rows go through an LDS tile ([image][pixel][2 x 49]; two barriers per hand-over) and leave
-// as 392-byte runs -- a pixel's two adjacent offset rows -- with consecutive lanes on consecutive floats (one row at a
-// time, 196-byte runs: 2.52 ms at C5 against 2.2 -- the partial 32-byte sectors at the ends of a run are written twice).
-// The next offset row's loads are issued before the current one is worked on.
+// besides the sums above it writes the normalised rows -- a transpose from [offset][pixel] to [pixel][offset] through LDS.
+// Round 5 layout (C5: 3.0 -> see profiles/EXPERIMENTS.md):
+//   * one workgroup of 8 waves per 64-pixel CHUNK of a tile (two per tile, ~68 KB of LDS each: two workgroups per CU, so
+//     that one's store phase runs beside the other's loads -- round 4's 1,024-thread workgroup held 140 KB and the CU alone);
+//   * wave = one eighth of the 49 offsets of an offset row (6-7 columns), lane = pixel: every load is an aligned 256-byte
+//     run, the next hand-over's loads are in flight while the current one is worked on;
+//   * per (pixel, image) the LDS holds a RING of 128 floats indexed by the offset q (+ a per-row rotation that gives ring
+//     and SSG tensor the same 16-byte phase).  After every NR = 2 offset rows the workgroup writes out, per pixel, every
+//     64-byte-ALIGNED segment of the pixel's SSG row that is complete; the <= 15 floats behind it stay in the ring for the
+//     next hand-over.  Every store is a whole aligned dwordx4, eight lanes = 128 contiguous bytes, and no 64-byte sector
+//     of the tensors is written twice (round 4 wrote 392-byte runs at 4-byte alignment with scalar dword stores: both
+//     ends of every run were partial sectors written twice; the first and last segment of a ROW still are -- 2 of 151).
 template <int KS, int KW>
-__global__ __launch_bounds__(1024) void ssg_rows_tm_mat(TmRowsParams p) {
+__global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(4, 4))) void ssg_rows_tm_mat(TmRowsParams p) {
   constexpr int P = KS * KS, HP = KS / 2, HK = KW / 2, NQ = 8, TY = 4, TX = 32, QMAX = (KS + NQ - 1) / NQ;
+  constexpr int CPX = 64, NR = 2, RING = 128, PITCH = RING + 4, SEG = 16, NIT = (KS + NR - 1) / NR;
   static_assert(TY * TX == TM_PX && QMAX == 7, "4 x 32 tiles; at most 7 offsets of a row per part");
+  static_assert(NR * KS + SEG - 1 <= RING, "a hand-over's new offsets + the carried ones fit the ring");
+  typedef float f4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int NR = 2, RUN = NR * KS;                  // offset rows per hand-over: a pixel's run is RUN floats
-  float *stage = lds;                                   // [2 images][TM_PX][RUN]
-  float *red = stage + 2 * TM_PX * RUN;                 // [8][NQ][TM_PX]
-  double *redk = (double *)(red + 8 * NQ * TM_PX);      // [NQ][TM_PX]
-  float *wred = (float *)(redk + NQ * TM_PX);           // [3][16]
-  int *prow = (int *)(wred + 48);                       // [TM_PX] row of every pixel of the tile (-1: hole)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ck = wv & 1, part = wv >> 1;
-  const int tslot = blockIdx.x;
+  float *stage = lds;                                   // [2 images][CPX][PITCH]
+  int *prow = (int *)(stage + 2 * CPX * PITCH);         // [CPX] row of every pixel of the chunk (-1: hole)
+  float *red = lds;                                     // after the main loop, over the stage: [8][NQ][CPX]
+  double *redk = (double *)(red + 8 * NQ * CPX);        // [NQ][CPX]
+  float *wred = (float *)(redk + NQ * CPX);             // [3]
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int tslot = blockIdx.x >> 1, ck = blockIdx.x & 1, slot = blockIdx.x;
   if (tslot >= dense_tile_count(p.n_dense) || p.n_dense[1] != TY ||
       !tm_active(p.n_dense, p.tm_slots, rows_to_do(p.n_dev, p.n_host))) {
     if (threadIdx.x == 0) {
-      p.partials[2 * tslot] = 0.f;
-      p.partials[2 * tslot + 1] = 0.f;
-      if (p.gmax_part) p.gmax_part[tslot] = 0.f;
+      p.partials[2 * slot] = 0.f;
+      p.partials[2 * slot + 1] = 0.f;
+      if (p.gmax_part) p.gmax_part[slot] = 0.f;
     }
     return;
   }
@@ -340,119 +348,161 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm_mat(TmRowsParams p) {
   const int y = ty0 + tm_pixel_row(ck, lane), x = tx0 + tm_pixel_col(lane);
   int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
   if (r >= nrows) r = -1;
-  if (part == 0) prow[ck * 64 + lane] = r;
+  if (part == 0) prow[lane] = r;
   const TmScale sa = tm_scale(r >= 0 ? p.row_scale[r] : 0.0), sb = tm_scale(r >= 0 ? p.row_scale[(size_t)p.n_host + r] : 0.0);
   const float invM = 1.f / ((float)nrows * (float)P);
   const float u1 = p.upstream ? p.upstream[0] : 1.f, u2 = p.upstream ? p.upstream[1] : 1.f;
   const float w1m = p.w_l1 * invM * u1, w2m = p.w_kl * invM * u2;
   const float cl = 1e-10f;
+  // the tensors' own phase: out = aligned-down pointer + goff floats (a caller's pointer need not be 64-byte aligned)
+  float *out_a = const_cast<float *>(p.out[0]), *out_b = const_cast<float *>(p.out[1]);
+  const int goff_a = (int)(((uintptr_t)out_a >> 2) & (SEG - 1)), goff_b = (int)(((uintptr_t)out_b >> 2) & (SEG - 1));
+  out_a -= goff_a;
+  out_b -= goff_b;
   const int qx0 = (KS * part) / NQ, qn = (KS * (part + 1)) / NQ - qx0;   // this part's columns of every offset row
   const float *pa = p.tm[0] + (size_t)tslot * P * TM_PX + (size_t)qx0 * TM_PX + ck * 64 + lane;
   const float *pb = p.tm[1] + (size_t)tslot * P * TM_PX + (size_t)qx0 * TM_PX + ck * 64 + lane;
+  // ring position of offset q of this lane's pixel: (q + rot) & 127 -- rot = the 16-byte phase of the pixel's row in the
+  // tensor, so that a 4-float group aligned in the tensor is aligned (and unbroken by the wrap) in the ring
+  const int rot_a = (goff_a + (r > 0 ? r : 0) * (P & 3)) & 3, rot_b = (goff_b + (r > 0 ? r : 0) * (P & 3)) & 3;
+  float *ring_a = stage + lane * PITCH, *ring_b = ring_a + CPX * PITCH;
   float l1 = 0.f, d1 = 0.f, d2 = 0.f, bs = 0.f, bg = 0.f, m1 = 0.f, m2 = 0.f;
   double kld = 0.0;
-  float na[QMAX], nb[QMAX];   // the next offset row's values, in flight while the current row is worked on
+  float na[NR][QMAX], nb[NR][QMAX];   // the next hand-over's values, in flight while the current one is worked on
 #pragma unroll
-  for (int j = 0; j < QMAX; ++j) {
-    const int jj = j < qn ? j : 0;
-    na[j] = __builtin_nontemporal_load(pa + (size_t)jj * TM_PX);
-    nb[j] = __builtin_nontemporal_load(pb + (size_t)jj * TM_PX);
-  }
-  float *out_a = const_cast<float *>(p.out[0]), *out_b = const_cast<float *>(p.out[1]);
+  for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+      const int jj = j < qn ? j : 0;
+      na[rr][j] = __builtin_nontemporal_load(pa + (size_t)(rr * KS + jj) * TM_PX);
+      nb[rr][j] = __builtin_nontemporal_load(pb + (size_t)(rr * KS + jj) * TM_PX);
+    }
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   lds_barrier();   // (prow)
+  // the store phase's identity: eight lanes per pixel, each a 16-byte quarter of two consecutive 64-byte segments
+  const int spx = threadIdx.x >> 3, sj = threadIdx.x & 7;
+  const int srow = prow[spx];
+  const int sbase_a = goff_a + (srow > 0 ? srow : 0) * P, sbase_b = goff_b + (srow > 0 ? srow : 0) * P;   // row start, in floats from the aligned pointer
+  int kc_a = sbase_a / SEG, kc_b = sbase_b / SEG;                  // next segment to write
+  const float *sring_a = stage + spx * PITCH, *sring_b = sring_a + CPX * PITCH;
 #pragma unroll 1
-  for (int qy = 0; qy < KS; ++qy) {
-    float ea[QMAX], eb[QMAX];
+  for (int it = 0; it < NIT; ++it) {
 #pragma unroll
-    for (int j = 0; j < QMAX; ++j) {
-      ea[j] = na[j];
-      eb[j] = nb[j];
-    }
-    if (qy + 1 < KS) {
+    for (int rr = 0; rr < NR; ++rr) {
+      const int qy = NR * it + rr;
+      if (qy < KS) {
+        const bool yb = qy < HK || qy > KS - 1 - HK, yc = qy == HP;
+        const int q0 = qy * KS + qx0;
+        float kl = 0.f;
+        // normalise first, then re-issue this offset row's registers for the same row of the NEXT hand-over: the loads
+        // are a whole hand-over ahead of their use and only NR x 14 values are ever in flight per lane
+        float av[QMAX], tv[QMAX];
 #pragma unroll
-      for (int j = 0; j < QMAX; ++j) {
-        const int jj = j < qn ? j : 0;
-        na[j] = __builtin_nontemporal_load(pa + (size_t)((qy + 1) * KS + jj) * TM_PX);
-        nb[j] = __builtin_nontemporal_load(pb + (size_t)((qy + 1) * KS + jj) * TM_PX);
+        for (int j = 0; j < QMAX; ++j) {
+          av[j] = tm_apply(na[rr][j], sa);
+          tv[j] = tm_apply(nb[rr][j], sb);
+        }
+        if (qy + NR < KS) {
+#pragma unroll
+          for (int j = 0; j < QMAX; ++j) {
+            const int jj = j < qn ? j : 0;
+            na[rr][j] = __builtin_nontemporal_load(pa + (size_t)((qy + NR) * KS + jj) * TM_PX);
+            nb[rr][j] = __builtin_nontemporal_load(pb + (size_t)((qy + NR) * KS + jj) * TM_PX);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) {
+          if (j < qn) {   // (wave-uniform: parts 0..6 have six columns, part 7 seven)
+            const int qx = qx0 + j;
+            const float a = av[j], t = tv[j];
+            ring_a[(q0 + j + rot_a) & (RING - 1)] = a;
+            ring_b[(q0 + j + rot_b) & (RING - 1)] = t;
+            const float ac = fmaxf(a, cl), bc = fmaxf(t, cl);
+            l1 += fabsf(a - t);
+            const float rc = __builtin_amdgcn_rcpf(ac);
+            const float r0 = bc * rc;
+            const float ratio = __builtin_fmaf(__builtin_fmaf(-r0, ac, bc), rc, r0);
+            kl += bc * (0.69314718056f * __builtin_amdgcn_logf(ratio));
+            const float sg = __builtin_amdgcn_fmed3f((a - t) * 0x1p126f, -1.f, 1.f);
+            const float bz = a >= cl ? bc : 0.f;
+            d1 = __builtin_fmaf(sg, a, d1);
+            d2 += bz;
+            const float gs = __builtin_fmaf(w1m * sg, a, -w2m * bz);
+            const float bm = (yb || qx < HK || qx > KS - 1 - HK) ? 1.f : 0.f, cm = (qx == HP && yc) ? 0.f : 1.f;
+            bs = __builtin_fmaf(a, bm, bs);
+            bg = __builtin_fmaf(gs, bm, bg);
+            m1 = fmaxf(m1, a * cm);
+            m2 = fmaxf(m2, fabsf(a - bz) * cm);
+          }
+        }
+        kld += (double)kl;
       }
     }
-    const bool yb = qy < HK || qy > KS - 1 - HK, yc = qy == HP;
-    const int rr = qy % NR;
-    float *sta = stage + (ck * 64 + lane) * RUN + rr * KS + qx0, *stb = sta + TM_PX * RUN;
-    float kl = 0.f;
+    // (barriers for the LDS hand-over only: a __syncthreads() would also drain the stores of the last hand-over and
+    // the next hand-over's loads -- two memory round trips per hand-over)
+    lds_barrier();   // offsets < qa of every pixel of the chunk are in the rings
+    {
+      const int qa = NR * KS * (it + 1) < P ? NR * KS * (it + 1) : P;
 #pragma unroll
-    for (int j = 0; j < QMAX; ++j) {
-      if (j < qn) {   // (wave-uniform: parts 0..6 have six columns, part 7 seven)
-        const int qx = qx0 + j;
-        const float a = tm_apply(ea[j], sa), t = tm_apply(eb[j], sb);
-        sta[j] = a;
-        stb[j] = t;
-        const float ac = fmaxf(a, cl), bc = fmaxf(t, cl);
-        l1 += fabsf(a - t);
-        const float rc = __builtin_amdgcn_rcpf(ac);
-        const float r0 = bc * rc;
-        const float ratio = __builtin_fmaf(__builtin_fmaf(-r0, ac, bc), rc, r0);
-        kl += bc * (0.69314718056f * __builtin_amdgcn_logf(ratio));
-        const float sg = __builtin_amdgcn_fmed3f((a - t) * 0x1p126f, -1.f, 1.f);
-        const float bz = a >= cl ? bc : 0.f;
-        d1 = __builtin_fmaf(sg, a, d1);
-        d2 += bz;
-        const float gs = __builtin_fmaf(w1m * sg, a, -w2m * bz);
-        const float bm = (yb || qx < HK || qx > KS - 1 - HK) ? 1.f : 0.f, cm = (qx == HP && yc) ? 0.f : 1.f;
-        bs = __builtin_fmaf(a, bm, bs);
-        bg = __builtin_fmaf(gs, bm, bg);
-        m1 = fmaxf(m1, a * cm);
-        m2 = fmaxf(m2, fabsf(a - bz) * cm);
+      for (int img = 0; img < 2; ++img) {
+        const int sbase = img ? sbase_b : sbase_a;
+        int &kc = img ? kc_b : kc_a;
+        const float *sring = img ? sring_b : sring_a;
+        float *outp = img ? out_b : out_a;
+        // complete segments: below the first float not yet in the ring; the row's last hand-over takes its partial tail
+        const int kend = qa == P ? (sbase + P + SEG - 1) / SEG : (sbase + qa) / SEG;
+        if (srow >= 0) {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {   // (at most 7 segments per hand-over)
+            const int seg = kc + 2 * s2 + (sj >> 2);
+            if (seg < kend) {
+              const int gi = seg * SEG + 4 * (sj & 3), q = gi - sbase;
+              const f4 v = *(const f4 *)(sring + ((q + (sbase & 3)) & (RING - 1)));
+              if (q >= 0 && q + 3 < P) {
+                __builtin_nontemporal_store(v, (f4 *)(outp + (size_t)gi));
+              } else {   // the row's first / last segment: the floats that belong to this row only
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (q + i >= 0 && q + i < P) outp[(size_t)gi + i] = v[i];
+              }
+            }
+          }
+        }
+        kc = kend;
       }
     }
-    kld += (double)kl;
-    if (rr == NR - 1 || qy == KS - 1) {
-      // (barriers for the LDS hand-over only: a __syncthreads() would also drain the stores of the last hand-over and
-      // the next row's loads -- two memory round trips per hand-over)
-      lds_barrier();   // NR offset rows (the last hand-over: one) are complete in the tile
-      // the tile's 2 x 128 runs: a pixel's NR offset rows are adjacent in its SSG row; element (image, pixel, i)
-      const int len = (rr + 1) * KS, qbase = (qy - rr) * KS;
-      for (int e = threadIdx.x; e < 2 * TM_PX * RUN; e += 1024) {
-        const int img = e >= TM_PX * RUN, e1 = e - img * TM_PX * RUN, px = e1 / RUN, i = e1 - px * RUN;
-        const int row = prow[px];
-        if (row >= 0 && i < len) (img ? out_b : out_a)[(size_t)row * P + qbase + i] = stage[e];
-      }
-      lds_barrier();   // (the tile is free for the next NR rows)
-    }
+    lds_barrier();   // (the rings are free for the next hand-over)
   }
-  red[(0 * NQ + part) * TM_PX + ck * 64 + lane] = l1;
-  redk[part * TM_PX + ck * 64 + lane] = kld;
-  red[(2 * NQ + part) * TM_PX + ck * 64 + lane] = d1;
-  red[(3 * NQ + part) * TM_PX + ck * 64 + lane] = d2;
-  red[(4 * NQ + part) * TM_PX + ck * 64 + lane] = bs;
-  red[(5 * NQ + part) * TM_PX + ck * 64 + lane] = bg;
-  red[(6 * NQ + part) * TM_PX + ck * 64 + lane] = m1;
-  red[(7 * NQ + part) * TM_PX + ck * 64 + lane] = m2;
+  red[(0 * NQ + part) * CPX + lane] = l1;
+  redk[part * CPX + lane] = kld;
+  red[(2 * NQ + part) * CPX + lane] = d1;
+  red[(3 * NQ + part) * CPX + lane] = d2;
+  red[(4 * NQ + part) * CPX + lane] = bs;
+  red[(5 * NQ + part) * CPX + lane] = bg;
+  red[(6 * NQ + part) * CPX + lane] = m1;
+  red[(7 * NQ + part) * CPX + lane] = m2;
   __syncthreads();
-  float l1w = 0.f, klw = 0.f, gb = 0.f;
-  if (part == 0) {   // waves 0 and 1: one lane per pixel, the eight parts in a fixed order
-    const int px = ck * 64 + lane;
+  if (part == 0) {   // wave 0: one lane per pixel, the eight parts in a fixed order
     float v[8];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (k == 1) continue;
-      float t = red[(k * NQ) * TM_PX + px];
+      float t = red[(k * NQ) * CPX + lane];
 #pragma unroll
-      for (int j = 1; j < NQ; ++j) t += red[(k * NQ + j) * TM_PX + px];
+      for (int j = 1; j < NQ; ++j) t += red[(k * NQ + j) * CPX + lane];
       v[k] = t;
     }
     {
-      double t = redk[px];
+      double t = redk[lane];
 #pragma unroll
-      for (int j = 1; j < NQ; ++j) t += redk[j * TM_PX + px];
+      for (int j = 1; j < NQ; ++j) t += redk[j * CPX + lane];
       v[1] = (float)t;
     }
 #pragma unroll
     for (int k = 6; k < 8; ++k) {
-      float t = red[(k * NQ) * TM_PX + px];
+      float t = red[(k * NQ) * CPX + lane];
 #pragma unroll
-      for (int j = 1; j < NQ; ++j) t = fmaxf(t, red[(k * NQ + j) * TM_PX + px]);
+      for (int j = 1; j < NQ; ++j) t = fmaxf(t, red[(k * NQ + j) * CPX + lane]);
       v[k] = t;
     }
     const float kfac = 1.f / (p.sigma * (float)(p.C * KW * KW));
@@ -463,35 +513,30 @@ __global__ __launch_bounds__(1024) void ssg_rows_tm_mat(TmRowsParams p) {
       p.dot[r] = dot;
       p.sum_b[r] = -kfac * (v[5] - dot * v[4]);
     }
-    gb = kfac * (v[6] * (fabsf(w1m) + fabsf(v[2]) + fabsf(v[3] + w2m)) + fabsf(w2m) * v[7]) * 1.0001f;
-    l1w = wave_sum(v[0]);
-    klw = wave_sum(v[1]);
+    float gb = kfac * (v[6] * (fabsf(w1m) + fabsf(v[2]) + fabsf(v[3] + w2m)) + fabsf(w2m) * v[7]) * 1.0001f;
+    const float l1w = wave_sum(v[0]), klw = wave_sum(v[1]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) gb = fmaxf(gb, __shfl_xor(gb, o, 64));
     if (lane == 0) {
-      wred[0 * 16 + ck] = l1w;
-      wred[1 * 16 + ck] = klw;
-      wred[2 * 16 + ck] = gb;
+      p.partials[2 * slot] = l1w;
+      p.partials[2 * slot + 1] = klw;
+      if (p.gmax_part) p.gmax_part[slot] = gb;
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    p.partials[2 * tslot] = wred[0] + wred[1];
-    p.partials[2 * tslot + 1] = wred[16] + wred[17];
-    if (p.gmax_part) p.gmax_part[tslot] = fmaxf(wred[32], wred[33]);
-  }
+  (void)wred;
 }
+
+// Both kernels leave TWO partial slots per tile (the materialising kernel runs one workgroup per 64-pixel chunk).
+int rows_tm_parts(int n_tiles) { return 2 * n_tiles; }
 
 int launch_rows_tm(const TmRowsParams &p, int ks, int kw, hipStream_t st) {
   if (p.n_tiles <= 0) return 0;
   if (ks != 49 || kw != 13) return -1;
   if (p.out[0] && p.out[1]) {
-    constexpr int KS = 49, NQ = 8;
-    const size_t lds = sizeof(float) * (size_t)(2 * TM_PX * 2 * KS + 8 * NQ * TM_PX + 48) + sizeof(double) * NQ * TM_PX +
-                       sizeof(int) * TM_PX;
+    const size_t lds = sizeof(float) * (size_t)(2 * 64 * 132) + sizeof(int) * 64;
     static std::atomic<unsigned long long> lds_set{0};
     if (const int rc = ensure_dynamic_lds(ssg_rows_tm_mat<49, 13>, (int)lds, lds_set)) return rc;
-    hipLaunchKernelGGL((ssg_rows_tm_mat<49, 13>), dim3((unsigned)p.n_tiles), dim3(1024), lds, st, p);
+    hipLaunchKernelGGL((ssg_rows_tm_mat<49, 13>), dim3(2u * (unsigned)p.n_tiles), dim3(512), lds, st, p);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL((ssg_rows_tm<49, 13>), dim3((unsigned)p.n_tiles), dim3(1024), 0, st, p);
@@ -515,19 +560,19 @@ __global__ __launch_bounds__(256) void criteria_sums_kernel(const float *a, cons
     int run = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
       const float4 x = a4[i], y = b4[i];
-      criteria_elem(x.x, y.x, 0.f, 0.f, l1, kl);
-      criteria_elem(x.y, y.y, 0.f, 0.f, l1, kl);
-      criteria_elem(x.z, y.z, 0.f, 0.f, l1, kl);
-      criteria_elem(x.w, y.w, 0.f, 0.f, l1, kl);
+      criteria_elem_any(x.x, y.x, 0.f, 0.f, l1, kl);
+      criteria_elem_any(x.y, y.y, 0.f, 0.f, l1, kl);
+      criteria_elem_any(x.z, y.z, 0.f, 0.f, l1, kl);
+      criteria_elem_any(x.w, y.w, 0.f, 0.f, l1, kl);
       if (++run == 32) {   // (128 elements per fp32 partial sum)
         L1 += (double)l1; KL += (double)kl; l1 = kl = 0.f; run = 0;
       }
     }
-    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) criteria_elem(a[i], b[i], 0.f, 0.f, l1, kl);
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) criteria_elem_any(a[i], b[i], 0.f, 0.f, l1, kl);
   } else {
     int run = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-      criteria_elem(a[i], b[i], 0.f, 0.f, l1, kl);
+      criteria_elem_any(a[i], b[i], 0.f, 0.f, l1, kl);
       if (++run == 128) {
         L1 += (double)l1; KL += (double)kl; l1 = kl = 0.f; run = 0;
       }
@@ -585,15 +630,15 @@ __global__ __launch_bounds__(256) void criteria_grad_kernel(const float *a, cons
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
       const float4 x = a4[i], y = b4[i];
       float4 r;
-      r.x = criteria_elem(x.x, y.x, c1, c2, d1, d2);
-      r.y = criteria_elem(x.y, y.y, c1, c2, d1, d2);
-      r.z = criteria_elem(x.z, y.z, c1, c2, d1, d2);
-      r.w = criteria_elem(x.w, y.w, c1, c2, d1, d2);
+      r.x = criteria_elem_any(x.x, y.x, c1, c2, d1, d2);
+      r.y = criteria_elem_any(x.y, y.y, c1, c2, d1, d2);
+      r.z = criteria_elem_any(x.z, y.z, c1, c2, d1, d2);
+      r.w = criteria_elem_any(x.w, y.w, c1, c2, d1, d2);
       g4[i] = r;
     }
-    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = criteria_elem(a[i], b[i], c1, c2, d1, d2);
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = criteria_elem_any(a[i], b[i], c1, c2, d1, d2);
   } else {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = criteria_elem(a[i], b[i], c1, c2, d1, d2);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = criteria_elem_any(a[i], b[i], c1, c2, d1, d2);
   }
 }
 

@@ -131,6 +131,12 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
     return EdgeList(edges, counts, rank, order, plan, ks)
 
 
+def set_overlap(on):
+    """Side-stream overlap of the dense-tile and direct kernels of a pass (k_s <= 25; default on).  Off = every launch on
+    the caller's stream (per-kernel profiling).  Same results either way.  Returns the previous setting."""
+    return bool(_lib.lib().ssg_set_overlap(1 if on else 0))
+
+
 def set_dense_threshold(edge_pixels_per_tile):
     """Route 8x32-pixel tiles holding at least this many edge pixels through the shared-term ("dense") forward
     kernel (0 = never; default 18).  Same results either way.  Returns the previous value."""

@@ -23,11 +23,27 @@ from .. import engine
 _reduction_modes = ['none', 'mean', 'sum']
 
 
+_NATIVE_CRITERIA = True
+
+
+def set_native_criteria(on):
+    """Route L1Loss / KLDistanceLoss on materialised fp32 GPU tensors through the engine's streaming criteria kernels
+    (default) or through the reference's torch expressions (needed for a second derivative through the criterion:
+    the native autograd node is once-differentiable).  Returns the previous setting."""
+    global _NATIVE_CRITERIA
+    prev, _NATIVE_CRITERIA = _NATIVE_CRITERIA, bool(on)
+    return prev
+
+
 def _native_pair(pred, target):
     """Whether (pred, target) can go through the engine's streaming criteria kernels (ssg_criteria_sums / _grad): real
-    fp32 GPU tensors of one shape, no gradient wanted for the target.  Deferred handles (losses/lazy.py) are not
+    fp32 tensors of one shape on ONE GPU, no gradient wanted for the target.  (The native node is once-differentiable:
+    a caller that needs a second derivative through the criterion -- gradient penalties -- passes tensors under
+    `torch.autograd.graph`'s usual rules and gets an error from autograd, not a wrong value; `set_native_criteria(False)`
+    restores the reference's torch expressions.)  Deferred handles (losses/lazy.py) are not
     tensors: they take the torch calls below, which is where they are intercepted."""
-    return (isinstance(pred, torch.Tensor) and isinstance(target, torch.Tensor) and pred.is_cuda and target.is_cuda
+    return (_NATIVE_CRITERIA and isinstance(pred, torch.Tensor) and isinstance(target, torch.Tensor)
+            and pred.is_cuda and target.is_cuda and pred.device == target.device
             and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.shape == target.shape
             and pred.numel() > 0 and not target.requires_grad)
 

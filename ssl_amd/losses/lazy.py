@@ -29,6 +29,7 @@ reference's eager cost.  A pair whose two masks differ (the reference would fail
 broadcast) yields NaN losses.
 """
 import os
+import warnings
 
 import torch
 import torch.nn.functional as F
@@ -38,6 +39,8 @@ from .. import _lib, engine
 _ptr, _stream, _f32c = engine._ptr, engine._stream, engine._f32c
 
 _LAZY = os.environ.get("SSG_LAZY", "1") not in ("", "0")
+_handles_since_step = 0      # LazySSG handles created since the last batched step ran (the eager-cliff warning below)
+_warned_eager = False
 
 
 def set_lazy(on):
@@ -93,8 +96,24 @@ class _Lazy:
     def __repr__(self):
         return f"{type(self).__name__}({'materialised' if self._t is not None else 'deferred'})"
 
+    # dim 0 of everything deferred here -- SSG rows (1, sum N, k_s^2) and their element-wise images -- is 1: the
+    # reference's caller loop asks `len(b_sr_list) > 0` of the concatenated tensor before each criterion
+    # (realesrganssl_model.py:413,419); answering must not compute anything
+    _len0 = None
+
     def __len__(self):
-        return len(self.materialise())
+        return self._len0 if self._len0 is not None and self._t is None else len(self.materialise())
+
+    def __bool__(self):
+        return bool(self.materialise())
+
+    def __float__(self):
+        return float(self.materialise())
+
+    def __int__(self):
+        return int(self.materialise())
+
+    __hash__ = object.__hash__       # (__eq__ below is the tensor's element-wise comparison; handles are keyed by identity)
 
     def __getitem__(self, k):
         return self.materialise()[k]
@@ -119,7 +138,7 @@ def _binary(name):
 for _n in ("add", "sub", "mul", "truediv", "pow", "matmul", "floordiv", "mod"):
     setattr(_Lazy, f"__{_n}__", _binary(f"__{_n}__"))
     setattr(_Lazy, f"__r{_n}__", _binary(f"__r{_n}__"))
-for _n in ("lt", "le", "gt", "ge"):
+for _n in ("lt", "le", "gt", "ge", "eq", "ne"):
     setattr(_Lazy, f"__{_n}__", _binary(f"__{_n}__"))
 
 
@@ -130,13 +149,27 @@ class LazySSG(_Lazy):
     mask decides, loss_util.py:233) or 'all' (ssl_pytorch: torch.where over every mask channel, loss_util.py:195-198).
     cfg: (k_s, k_w, sigma, eps, generalization)."""
 
+    _len0 = 1
+
     def __init__(self, parts, cfg):
+        global _handles_since_step
         self.parts = list(parts)
         self.cfg = tuple(cfg)
         self._pairs = {}     # id(target handle) -> (target handle, (l1 mean, kl mean)) of the fused step
+        _handles_since_step += 1
 
     def _compute(self):
         from .loss_util import eager_rows
+        global _warned_eager
+        if _handles_since_step >= 2 and not _warned_eager:
+            # several handles were created and one of them is now used in a way the batched step does not cover: the
+            # rows of every image are computed one launch at a time from here on (C2: 7 ms instead of 2.9 per loop)
+            _warned_eager = True
+            warnings.warn("ssl_amd: a deferred SSG handle is being materialised inside a per-image loop (it was used in "
+                          "a way other than torch.cat / L1Loss / KLDistanceLoss on equal settings); the rows are computed "
+                          "eagerly per image from here on -- same values, several times the batched step's cost.  "
+                          "set_lazy(False) / SSG_LAZY=0 silences this by always returning tensors.", RuntimeWarning,
+                          stacklevel=3)
         rows = [eager_rows(img, mask, conv, *self.cfg) for img, mask, conv in self.parts]
         return rows[0] if len(rows) == 1 else torch.cat(rows, dim=1)
 
@@ -150,6 +183,7 @@ class LazySSG(_Lazy):
 
 class _L1Elem(_Lazy):
     """F.l1_loss(pred, target, reduction='none') of two handles: only ever reduced."""
+    _len0 = 1
 
     def __init__(self, pred, target):
         self.pred, self.target = pred, target
@@ -174,6 +208,7 @@ class _L1Elem(_Lazy):
 
 class _Clamped(_Lazy):
     """torch.clamp(input=handle, min=m), optionally .log() of it -- the operands of the reference's KL criterion."""
+    _len0 = 1
 
     def __init__(self, src, lo, logged=False):
         self.src, self.lo, self.logged = src, lo, logged
@@ -350,4 +385,6 @@ def fused_losses(pred, target, deterministic=None):
     nan = torch.full((), float("nan"), dtype=l1u.dtype, device=l1u.device)
     out = (torch.where(bad, nan, l1u), torch.where(bad, nan, klu), count * mult)
     pred._pairs[id(target)] = (target, out)
+    global _handles_since_step
+    _handles_since_step = 0
     return out

@@ -45,12 +45,18 @@ def gan_selfsim_block(similarity_map, cri_selfsim, cri_selfsim1, output, gt, gt_
         s_gt = similarity_map(img=gt[i, :].unsqueeze(0).clone(), mask=m.clone(), **kw).getitem()
         sr_rows.append(s_sr)
         gt_rows.append(s_gt)
-    if not sr_rows:
-        return None, None
-    sr_rows = torch.cat(sr_rows, dim=1)
-    gt_rows = torch.cat(gt_rows, dim=1)
-    l_selfsim = cri_selfsim(sr_rows, gt_rows) if cri_selfsim is not None else None
-    l_selfsim_kl = cri_selfsim1(sr_rows, gt_rows) if cri_selfsim1 is not None else None
+    # the reference's own tests, literally: `len()` of the two LISTS before the cat, then `len()` of the concatenated
+    # TENSORS (1, sum N, k_s^2) before each criterion (realesrganssl_model.py:409-411, 413, 419)
+    if len(sr_rows) > 0 and len(gt_rows) > 0:
+        sr_rows = torch.cat(sr_rows, dim=1)
+        gt_rows = torch.cat(gt_rows, dim=1)
+    l_selfsim = l_selfsim_kl = None
+    if cri_selfsim is not None:
+        if len(sr_rows) > 0 and len(gt_rows) > 0:
+            l_selfsim = cri_selfsim(sr_rows, gt_rows)
+    if cri_selfsim1 is not None:
+        if len(sr_rows) > 0 and len(gt_rows) > 0:
+            l_selfsim_kl = cri_selfsim1(sr_rows, gt_rows)
     return l_selfsim, l_selfsim_kl
 
 
@@ -78,7 +84,7 @@ def dm_issl(similarity_map, cri_selfsim, cri_selfsim1, sr, gt, mask, sslopt, mas
                               softmax=sslopt.get('softmax_gt', False), **common).getitem()
         sr_rows.append(s_sr)
         gt_rows.append(s_gt)
-    if not sr_rows:
+    if len(sr_rows) <= 0 or len(gt_rows) <= 0:          # (ddpmssl.py:492-493)
         return 0.0, 0.0
     sr_rows = torch.cat(sr_rows, dim=1)
     gt_rows = torch.cat(gt_rows, dim=1)

@@ -42,7 +42,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     # every prototype the Python binding uses is declared in the header
     assert set(_lib.PROTOTYPES) <= declared - profile_only
     lib = _lib.lib()
-    assert lib.ssg_abi_version() == 4
+    assert lib.ssg_abi_version() == 5
     assert lib.ssg_status_string(0) == b"ok"
     assert b"LDS" in lib.ssg_status_string(-2)
     assert lib.ssg_kernel_name(25, 9, 0).startswith(b"ssg_fwd_")
@@ -59,6 +59,11 @@ def test_product_library_has_no_profiling_switch():
     assert not hasattr(prod, "ssg_set_profile_mask")
     blob = open(_lib.SO_PATH, "rb").read()
     assert b"SSG_DEBUG_SKIP" not in blob
+    # ... nor any other environment switch (round 5: SSG_DENSE_THR, SSG_OVERLAP, SSG_BWD_QSPLIT, SSG_STRIPS, SSG_TILE_MAJOR,
+    # SSG_OP_PLAN_FROM, SSG_BWD_TM_SPLIT, SSG_EDGE_BANDED, SSG_FWD_SMALL are honoured by the profiling build only)
+    import re
+    assert not re.findall(rb"SSG_[A-Z_]{3,}\x00", blob), re.findall(rb"SSG_[A-Z_]{3,}\x00", blob)
+    assert b"getenv" not in blob
     prof = ctypes.CDLL(_lib.PROF_SO_PATH)
     assert hasattr(prof, "ssg_set_profile_mask")
     assert b"SSG_DEBUG_SKIP" in open(_lib.PROF_SO_PATH, "rb").read()

@@ -189,3 +189,67 @@ def test_reference_style_criteria_and_separate_upstream_gradients(lazy_on_cpu):
     ref = orc.ssg_loss(sr.numpy().astype(np.float64), gt.numpy().astype(np.float64), m, KS, KW, SIGMA, 3.0, 0.25)
     assert abs(float(l1) - ref["l1"]) <= 1e-6 * ref["l1"] and abs(float(kl) - ref["kl"]) <= 1e-6 * ref["kl"]
     assert float((x.grad - torch.as_tensor(ref["grad"], dtype=torch.float32)).abs().max()) <= 1e-6 * np.abs(ref["grad"]).max()
+
+
+def test_len_bool_and_comparisons_of_a_handle(lazy_on_cpu):
+    """What the reference's loop and other tensor-minded callers ask of the value `getitem()` returns: `len()` of the
+    concatenated rows (realesrganssl_model.py:413,419) answers 1 WITHOUT computing anything; `==` / `!=` are the tensor's
+    element-wise comparisons (not Python identity); `bool()` of a many-element handle raises like the tensor's."""
+    import warnings
+    from ssl_amd.losses import similarity_map
+    sr, gt, mask = batch(4)
+    mk = lambda img: similarity_map(img[:1], mask[:1], 'cuda', KS, True, KW, SIGMA).getitem()
+    a, b = mk(sr), mk(gt)
+    c = torch.cat([a, b], dim=1)
+    assert len(a) == 1 and len(c) == 1 and a._t is None and c._t is None
+    e = F.l1_loss(a, b, reduction='none')
+    assert len(e) == 1 and e._t is None and len(torch.clamp(input=a, min=1e-10)) == 1 and a._t is None
+    assert {a: 1}[a] == 1 and a._t is None                       # hashable by identity
+    lazy_on_cpu._warned_eager = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        eq = a == a.materialise()
+        assert any("materialised inside a per-image loop" in str(w.message) for w in rec)
+    assert isinstance(eq, torch.Tensor) and bool(eq.all()) and not bool((a != a.materialise()).any())
+    assert isinstance(a == 0, torch.Tensor)
+    with pytest.raises(RuntimeError):
+        bool(b)
+    with warnings.catch_warnings(record=True) as rec:             # (one warning per process)
+        warnings.simplefilter("always")
+        mk(sr).shape
+        assert not rec
+
+
+def test_literal_reference_loop_with_len_checks_reaches_the_batched_step(lazy_on_cpu):
+    """The loop as the reference writes it -- `if len(b_sr_list) > 0 and len(b_gt_list) > 0:` on the concatenated tensors
+    before each criterion -- must still run as ONE batched step (round 4's handles materialised on `len()`)."""
+    from ssl_amd.losses import KLDistanceLoss, L1Loss, similarity_map
+    sr, gt, mask = batch(5)
+    x = sr.clone().requires_grad_(True)
+    out = x * 1.0
+    b_gt_list, b_sr_list = [], []
+    for i in range(gt.shape[0]):
+        b_mask_gt = mask[i, :].unsqueeze(0)
+        if b_mask_gt.sum() == 0:
+            pass
+        else:
+            b_sr_list.append(similarity_map(img=out[i, :].unsqueeze(0).clone(), mask=b_mask_gt.clone(), ssl_mode='cuda',
+                                            kernel_size_search=KS, generalization=True, kernel_size_window=KW,
+                                            sigma=SIGMA).getitem())
+            b_gt_list.append(similarity_map(img=gt[i, :].unsqueeze(0).clone(), mask=b_mask_gt.clone(), ssl_mode='cuda',
+                                            kernel_size_search=KS, generalization=True, kernel_size_window=KW,
+                                            sigma=SIGMA).getitem())
+    if len(b_sr_list) > 0 and len(b_gt_list) > 0:
+        b_sr_list = torch.cat(b_sr_list, dim=1)
+        b_gt_list = torch.cat(b_gt_list, dim=1)
+    total = 0.0
+    if len(b_sr_list) > 0 and len(b_gt_list) > 0:
+        total = total + L1Loss(1e3)(b_sr_list, b_gt_list)
+    if len(b_sr_list) > 0 and len(b_gt_list) > 0:
+        total = total + KLDistanceLoss(1e3)(b_sr_list, b_gt_list)
+    assert _Step.calls == 1 and b_sr_list._t is None and "deferred" in repr(b_sr_list)
+    total.backward()
+    m = mask.numpy()[:, 0].astype(np.uint8)
+    ref = orc.ssg_loss(sr.numpy().astype(np.float64), gt.numpy().astype(np.float64), m, KS, KW, SIGMA, 1e3, 1e3)
+    assert abs(float(total) - (ref["l1"] + ref["kl"])) <= 1e-6 * (ref["l1"] + ref["kl"])
+    assert float((x.grad - torch.as_tensor(ref["grad"], dtype=torch.float32)).abs().max()) <= 1e-6 * np.abs(ref["grad"]).max()

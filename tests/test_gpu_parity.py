@@ -758,42 +758,42 @@ def test_kl_conditioning_on_flat_rows_paper_sizes(dev):
         engine.set_dense_threshold(prev)
 
 
-def test_experimental_dense_forward_kernel_parity(dev):
-    """The opt-in shared-term ("dense tile") forward kernel (SSG_DENSE_THR > 0, ssg_dense.hip): every tile
-    routed through it, SSG rows and the loss step vs the oracle.  Runs in a subprocess because the
-    threshold is read once per process."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-from oracle import ssg_oracle as orc
-from ssl_amd import engine, synth
-dev = torch.device("cuda:0")
-ks, kw = 25, 9
-gt = np.stack([synth.natural_like(1600 + i, 72, 100, 0.15, 0.05) for i in range(2)])
-sr = np.stack([synth.degrade(gt[i], 1700 + i, 0.04) for i in range(2)])
-mask = np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(2)])
-mask[:, 0, 0] = mask[:, -1, -1] = 1
-for sigma in (0.004, 1.0):
-    ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask, ks, kw, sigma, 1e3, 1e3)
-    step = engine.LossStep(2, 3, 72, 100, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
-    loss, grad = step(torch.as_tensor(sr, device=dev), torch.as_tensor(gt, device=dev),
-                      torch.as_tensor(mask[:, None].astype(np.float32), device=dev))
-    n = int(step.counts[0])
-    assert n == ref["n_edges"]
-    e1 = np.abs(step.ssg_sr[:n].cpu().numpy() - ref["s_sr"]).max()
-    e2 = np.abs(step.ssg_gt[:n].cpu().numpy() - ref["s_gt"]).max()
-    l = loss.cpu().numpy()
-    assert e1 <= 1e-5 and e2 <= 1e-5, (e1, e2)
-    assert abs(l[0] - ref["l1"]) <= 1e-5 * ref["l1"] and abs(l[1] - ref["kl"]) <= 1e-5 * ref["kl"] + 2e-8
-print("dense ok")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SSG_DENSE_THR="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "dense ok" in out.stdout, out.stdout[-3000:]
+def test_every_tile_through_the_dense_kernels_and_no_side_stream(dev):
+    """Dense threshold 1 (every tile that holds an edge pixel goes through the shared-term kernels, ssg_dense.hip /
+    ssg_bwd_dense.hip) and ssg_set_overlap(0) (no side stream): SSG rows, losses and gradient vs the oracle; then the
+    default settings give the same losses.  Both switches are C-ABI calls -- the product library reads no environment
+    variable (round 5)."""
+    from ssl_amd import engine, synth
+    ks, kw = 25, 9
+    gt = np.stack([synth.natural_like(1600 + i, 72, 100, 0.15, 0.05) for i in range(2)])
+    sr = np.stack([synth.degrade(gt[i], 1700 + i, 0.04) for i in range(2)])
+    mask = np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(2)])
+    mask[:, 0, 0] = mask[:, -1, -1] = 1
+    prev_thr, prev_ov = engine.set_dense_threshold(1), engine.set_overlap(False)
+    try:
+        for sigma in (0.004, 1.0):
+            ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask, ks, kw, sigma, 1e3, 1e3)
+            step = engine.LossStep(2, 3, 72, 100, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
+            loss, grad = step(T(sr, dev), T(gt, dev), T(mask[:, None].astype(np.float32), dev))
+            n = int(step.counts[0])
+            assert n == ref["n_edges"]
+            assert maxerr(step.ssg_sr[:n].cpu(), ref["s_sr"]) <= 1e-5 and maxerr(step.ssg_gt[:n].cpu(), ref["s_gt"]) <= 1e-5
+            l = loss.cpu().numpy()
+            assert abs(l[0] - ref["l1"]) <= 1e-5 * ref["l1"] and abs(l[1] - ref["kl"]) <= 1e-5 * ref["kl"] + 2e-8
+            gref, _ = ref_grad_with_gpu_signs(sr, mask, ks, kw, sigma, ref, step.ssg_sr[:n].cpu().numpy(),
+                                              step.ssg_gt[:n].cpu().numpy())
+            assert maxerr(grad.cpu(), gref) <= grad_tol_from_oracle(sr, gt, mask, ks, kw, sigma, ref)
+            engine.set_dense_threshold(prev_thr)
+            engine.set_overlap(True)
+            step2 = engine.LossStep(2, 3, 72, 100, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
+            loss2, grad2 = step2(T(sr, dev), T(gt, dev), T(mask[:, None].astype(np.float32), dev))
+            l2 = loss2.cpu().numpy()
+            assert abs(l2[0] - l[0]) <= 2e-6 * l[0] and abs(l2[1] - l[1]) <= 2e-5 * l[1] + 2e-8
+            engine.set_dense_threshold(1)
+            engine.set_overlap(False)
+    finally:
+        engine.set_dense_threshold(prev_thr)
+        engine.set_overlap(prev_ov)
 
 
 # ------------------------------------------------------------------ round 2

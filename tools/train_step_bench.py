@@ -5,7 +5,10 @@ share of a step the loss costs.  The network is a stand-in with RRDBNet's publis
 residual dense blocks, 64 features, growth 32, two nearest x2 upsamplings; cf. basicsr/archs/rrdbnet_arch.py:88-
 121) and random weights: it is context for the measurement, not part of the product.
 
-    python tools/train_step_bench.py [--batch 4] [--steps 10]
+    python tools/train_step_bench.py [--batch 4] [--steps 4]
+
+bench.py reports both figures as `extra.c3_step_share` / `extra.c4_step_share`; tests/test_gpu_training_steps.py asserts
+on the same two functions.
 """
 import argparse
 import os
@@ -57,46 +60,98 @@ class Generator(nn.Module):
         return self.last(F.leaky_relu(self.hr(f), 0.2))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=4)      # C3: bs 32 over 8 GPUs
-    ap.add_argument("--steps", type=int, default=10)
-    args = ap.parse_args()
-    dev = torch.device("cuda:0")
+def _time_steps(step, flag, n=4, repeats=3):
+    """Best of `repeats` timings of n steps (a fresh box ramps its clocks during the first seconds: one sample of 4
+    steps of a 55 ms generator step has swung by 25 % between the two flags)."""
+    for _ in range(2):
+        step(flag)
+    best = float("inf")
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(flag)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+    return best
+
+
+def c3_step_share(dev, batch=4, n=4, check=None):
+    """BASELINE configs[2] per GPU (bs 32 over 8 GPUs = 4 GT crops of 256 x 256): one generator step of the RRDBNet-shaped
+    stand-in (fp32, Adam) with pixel L1 only and with the SSG loss where the reference's per-image loop sits
+    (realesrganssl_model.py:379-430: sigma 0.004, weights 1e3).  Interleaved twice, best of three blocks each."""
     torch.manual_seed(0)
     net = Generator().to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-    _, gt_np, _ = synth.make_batch(args.batch, 256, 256, seed0=300)
-    gt = torch.as_tensor(gt_np, device=dev)
+    _, gt_np, mask_np = synth.make_batch(batch, 256, 256, seed0=300)
+    gt, mask = torch.as_tensor(gt_np, device=dev), torch.as_tensor(mask_np, device=dev)
     lq = F.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
-    crit = SSGLoss(kernel_size_search=25, kernel_size_window=9, sigma=0.004, generalization=True,
-                   loss_weight_l1=1e3, loss_weight_kl=1e3)
+    crit = SSGLoss(25, 9, 0.004, True, 1e3, 1e3)
+    last = {}
 
     def step(with_ssl):
         opt.zero_grad(set_to_none=True)
-        out = net(lq)
-        loss = F.l1_loss(out, gt)
+        sr = net(lq)
+        loss = F.l1_loss(sr, gt)
         if with_ssl:
-            l1, kl = crit(out, gt, None)          # edge mask of GT generated on the device
+            l1, kl = crit(sr, gt, mask)
+            loss = loss + l1 + kl
+            last.update(sr=sr.detach(), l1=l1.detach(), kl=kl.detach())
+        loss.backward()
+        opt.step()
+
+    base, ssl = _time_steps(step, False, n), _time_steps(step, True, n)
+    base, ssl = min(base, _time_steps(step, False, n)), min(ssl, _time_steps(step, True, n))
+    if check is not None:
+        check(net, last, gt, mask)
+    return dict(step_ms_without_ssl=base, step_ms_with_ssl=ssl, ssl_ms=ssl - base, ssl_share=(ssl - base) / ssl,
+                edge_px=int(mask_np.sum()),
+                what=f"RRDBNet-shaped x4 generator (23 RRDB, fp32, Adam), {batch} x 3x256x256 GT, SSL (25,9) sigma 0.004 w 1e3")
+
+
+def c4_step_share(dev, n=4, check=None):
+    """BASELINE configs[3] per GPU (bs 8 over 4 GPUs = 2 crops of 512 x 512): the tail of the LDM-SR step -- a stand-in
+    decoder producing 2 x 3x512x512 from a 4x64x64 latent, 0.1 pixel L1 (ddpmssl.py:424-425) -- with and without SSL on
+    the decoded image (mask_stride 3, eps 1e-20, weights 5e2: configs/StableSRISSLStage1/*.yml:32-41,268-277)."""
+    torch.manual_seed(0)
+    dec = nn.Sequential(nn.Conv2d(4, 128, 3, padding=1), nn.SiLU(),
+                        nn.Upsample(scale_factor=2), nn.Conv2d(128, 128, 3, padding=1), nn.SiLU(),
+                        nn.Upsample(scale_factor=2), nn.Conv2d(128, 64, 3, padding=1), nn.SiLU(),
+                        nn.Upsample(scale_factor=2), nn.Conv2d(64, 64, 3, padding=1), nn.SiLU(),
+                        nn.Conv2d(64, 3, 3, padding=1)).to(dev)
+    opt = torch.optim.Adam(dec.parameters(), lr=1e-4)
+    _, gt_np, m_np = synth.make_batch(2, 512, 512, seed0=2000)
+    gt, m = torch.as_tensor(gt_np, device=dev), torch.as_tensor(m_np, device=dev)
+    z = torch.randn(2, 4, 64, 64, device=dev)
+    crit = SSGLoss(25, 9, 0.004, True, 5e2, 5e2, mask_stride=3, eps=1e-20)
+
+    def step(with_ssl):
+        opt.zero_grad(set_to_none=True)
+        img = dec(z)
+        loss = 0.1 * F.l1_loss(img, gt)
+        if with_ssl:
+            l1, kl = crit(img, gt, m)
             loss = loss + l1 + kl
         loss.backward()
         opt.step()
 
-    res = {}
-    for with_ssl in (False, True, False, True):
-        for _ in range(3):
-            step(with_ssl)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(with_ssl)
-        torch.cuda.synchronize()
-        res.setdefault(with_ssl, []).append((time.perf_counter() - t0) / args.steps * 1e3)
-    base, ssl = min(res[False]), min(res[True])
-    n = int(crit.last_counts[0])
-    print(f"generator step, batch {args.batch} x 3x256x256 GT (x4, 23 RRDB, fp32, Adam): {base:.1f} ms without SSL, "
-          f"{ssl:.1f} ms with the SSG loss (N = {n} edge px, k_s=25, k_w=9, sigma=0.004, L1+KL): "
-          f"+{ssl - base:.2f} ms = {100 * (ssl - base) / ssl:.1f} % of the step")
+    base, ssl = _time_steps(step, False, n), _time_steps(step, True, n)
+    base, ssl = min(base, _time_steps(step, False, n)), min(ssl, _time_steps(step, True, n))
+    if check is not None:
+        check(dec)
+    return dict(step_ms_without_ssl=base, step_ms_with_ssl=ssl, ssl_ms=ssl - base, ssl_share=(ssl - base) / ssl,
+                edge_px=int(crit.last_counts[0]),
+                what="stand-in decoder tail (4x64x64 latent -> 2 x 3x512x512), 0.1 pixel L1, SSL (25,9) stride 3 eps 1e-20 w 5e2")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)      # C3: bs 32 over 8 GPUs
+    ap.add_argument("--steps", type=int, default=4)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    import json
+    print(json.dumps({"c3": c3_step_share(dev, args.batch, args.steps), "c4": c4_step_share(dev, args.steps)}, indent=1))
 
 
 if __name__ == "__main__":
