@@ -431,6 +431,8 @@ int ssg_poisson_noise(const float *img, float *out, const float *draw_color, con
  * lower bits ablate phases inside kernels (ssg_api.hip).  Returns the previous mask; 0 = production behaviour.  The
  * environment variable SSG_DEBUG_SKIP presets the mask, in this build only. */
 int ssg_set_profile_mask(int mask);
+/* workgroups per CU the HIP runtime reports for a kernel at its launch geometry (0: ssg_fwd_strip<49,13,3,3>) */
+int ssg_prof_occupancy(int which);
 #endif
 
 /* Host helper for profiling builds: name of the HIP kernel a configuration

@@ -128,6 +128,9 @@ static int dbg_mask() {
   }
   return v;
 }
+namespace ssg { int strip_occupancy(); int strip_times(unsigned long long *host, int n); }
+extern "C" int ssg_prof_strip_times(unsigned long long *host, int n) { return ssg::strip_times(host, n); }
+extern "C" int ssg_prof_occupancy(int which) { return which == 0 ? ssg::strip_occupancy() : -1; }
 extern "C" int ssg_set_profile_mask(int mask) {
   const int prev = dbg_mask();
   g_dbg.store(mask > 0 ? mask : 0, std::memory_order_relaxed);

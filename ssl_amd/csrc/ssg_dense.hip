@@ -109,7 +109,7 @@ struct DenseParams {
   int B, H, W;
   float sigma, eps;
   int generalization;
-  int dbg;  // profiling ablations: bit0 no stores, bit1 no edge stage, bit3 no rescale, bit6 no main loop
+  int dbg;  // profiling ablations: bit0 no stores, bit1 no edge stage, bit2 (strips) no E/H stage, bit3 no rescale, bit6 no main loop
   double *row_scale;  // nullable [nimg][n_host]: deferred normalisation -- the rows stay e, 1/(sum e + eps) goes here
   // tile-major scratch rows (fused step at k_s = 49, ssg_api.hip; tm_active() in ssg_common.hpp decides per call):
   // the tile in plan slot t leaves its e values at tm[img] + t * P * 128 + q * 128 + (64 ck + lane) -- every wave
@@ -725,28 +725,59 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // The image region does not fit LDS for 36 + 2 HALO rows and is not needed at once: offset row q_y touches region
 // rows q_y .. q_y + 47 only, a BAND of 48 rows kept as a ring (region row rho at slot rho % 48); one new row per q_y
 // is fetched at the top of the q_y loop and stored after its last step.
+//
+// Round 5: the two stages of an offset run on DIFFERENT waves (the recipe of the role-split dense backward).  A workgroup
+// is 2 NW waves: waves 0 .. NW-1 ("E/H role") own 16 U-rows each and do nothing but the E/H stage -- window, E, horizontal
+// sums, H rows --, waves NW .. 2 NW - 1 ("edge role") own the 6 centres per lane and do nothing but the edge stage -- H
+// gathers, vertical sums, exp, fp64 row sums, stores.  They meet at the one s_barrier per offset the kernel always had
+// (E/H of offset t+1 beside the edge stage of t, double-buffered H).  Each role keeps only its own registers (the
+// one-role-per-wave kernel needed 238 VGPRs -> 2 waves per SIMD, 1.3 resident: issue-limited at one instruction per ~5
+// cycles and wave), so the kernel fits 3 waves per SIMD: two workgroups = 12 waves per CU instead of 6.
+#ifdef SSG_PROFILE
+__device__ unsigned long long g_strip_times[3 * 1024];   // per workgroup: start, end (s_memtime), XCC id << 8 | CU id
+#endif
 template <int KS, int KW, int C, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_fwd_strip(DenseParams p) {
-  constexpr int NT = 64 * NW;
+__global__ __launch_bounds__(256 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void ssg_fwd_strip(DenseParams p) {
+#ifdef SSG_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_strip_times[3 * blockIdx.x] = __builtin_readcyclecounter();
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_strip_times[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
+  constexpr int NT = 128 * NW, NTR = 64 * NW;                     // threads of the workgroup / of one role
   constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK;
   constexpr int UH = 16 * NW, SY = UH - 2 * HK;                  // U-rows and centre rows of a strip
   constexpr int RWD = DT_X + 2 * HALO, RS = RWD + 1;             // band row
   constexpr int UW = DT_X + 2 * HK;
   constexpr int L = dense_lane_px(KW), HL = L / 2, NV = HL + KW - 1;
   constexpr int HS = DT_X + 1;                                   // H row stride: gathers AND the dword stores conflict-free
-  constexpr int PX = SY * DT_X / NT, NHV = PX + KW - 1;          // centres per lane (one column), H values they share
-  static_assert(SY == STRIP_ROWS && SY * DT_X == PX * NT && NT % DT_X == 0 && (NT / DT_X) * PX == SY && 4 * L >= UW && L % 2 == 0 &&
+  constexpr int PX = SY * DT_X / NTR, NHV = PX + KW - 1;          // centres per lane (one column), H values they share
+  static_assert(SY == STRIP_ROWS && SY * DT_X == PX * NTR && NTR % DT_X == 0 && (NTR / DT_X) * PX == SY && 4 * L >= UW && L % 2 == 0 &&
                 KW - 1 <= L && KW == 13 && PX == 6, "lane maps: 16 U-rows per wave, 6 centres of a column per lane");
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // TWO strips per workgroup (4 NW waves, each strip its own half of the LDS): measured (tools/r5_strip_times.py,
+  // tools/microbench_lds_residency.hip) the CU does not admit a second 2 NW-wave workgroup of this kernel although LDS,
+  // registers and the occupancy API allow it -- its 6 waves at 3 per SIMD only fit beside another 6 in one placement --
+  // so the strips ran in two rounds, one workgroup per CU.  One 12-wave workgroup fills the four SIMDs with 3 waves each.
+  constexpr int STRIP_LDS = C * UH * RS + 3 * UH * HS + UH * UW + 16;   // floats of one strip (launch_fwd_strip_t)
+  extern __shared__ __attribute__((aligned(16))) float smem_wg[];
+  const int half = threadIdx.x / NT;
+  float *smem = smem_wg + half * STRIP_LDS;
   float *band = smem;                 // [C][UH][RS]  region rows q_y .. q_y + UH - 1, row rho at slot rho % UH
   float *HF = band + C * UH * RS;     // [UH][HS]     full-window horizontal sums of |I|^2
   float *Hb = HF + UH * HS;           // [2][UH][HS]  horizontal sums of E_q, double-buffered over the steps
   float *F = Hb + 2 * UH * HS;        // [UH][UW]     |I|^2 on U (the columns a truncated window leaves behind)
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int which = blockIdx.x / p.max_strips, slot = blockIdx.x - which * p.max_strips;
-  if (slot >= p.strips[0]) return;
+  const int tid = threadIdx.x - half * NT, lane = tid & 63, wv = tid >> 6;   // thread / wave within the strip
+  // jobs = (image, strip) pairs of the call, two per workgroup; an odd last job is mirrored by the idle half (same
+  // values to the same addresses) so that both halves run the same barriers
+  const int n_act = p.strips[0] < p.max_strips ? p.strips[0] : p.max_strips, n_jobs = n_act * p.nimg;
+  if (2 * (int)blockIdx.x >= n_jobs) return;
+  const int job = 2 * (int)blockIdx.x + half < n_jobs ? 2 * (int)blockIdx.x + half : n_jobs - 1;
+  const int which = job / n_act, slot = job - which * n_act;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
   if (!tm_active(p.n_dense, p.tm_slots, nrows)) return;   // (row-major call: the tile kernel computes these tiles)
   const int H = p.H, W = p.W;
@@ -785,7 +816,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- set-up on the U rows themselves (region rows HP .. HP + UH - 1): own pixels, |I|^2 and its sums ----
   fill_band(HP);
   __syncthreads();
-  const int r = lane >> 2, g = lane & 3, R = 16 * wv + r;   // U-row of the lane
+  const bool eh_role = wv < NW;                              // (wave-uniform)
+  const int r = lane >> 2, g = lane & 3, R = 16 * (eh_role ? wv : 0) + r;   // E/H role: U-row of the lane
   f2 iu[C][HL];
 #pragma unroll
   for (int c = 0; c < C; ++c)
@@ -825,7 +857,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // base per offset + one 32-bit element offset per centre.
   // A strip at the bottom of the image has fewer than nine tiles: the centres below them go to the region's spare
   // slot (index tm_slots, behind the last real one: written by every short strip, read by nobody).
-  const int ecol = tid % DT_X, e0 = (tid / DT_X) * PX;
+  const int tid_e = eh_role ? 0 : tid - NTR;                  // edge role: thread within the role
+  const int ecol = tid_e % DT_X, e0 = (tid_e / DT_X) * PX;
   const int ty_n = (H + 3) / 4, n_tq = ty_n - ty0 / 4 < SY / 4 ? ty_n - ty0 / 4 : SY / 4;
   int orow[PX];
   float *cptr[PX];
@@ -852,6 +885,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const float *hfread = HF + e0 * HS + ecol;
   __syncthreads();
 
+  // The two roles run the same number of barriers per offset row: 1 (offset 0's H) + KS - 1 (one per further offset) +
+  // 1 (band row stored; not after the last row).
+  if (eh_role) {
 #pragma unroll 1
   for (int qyi = 0; qyi < KS; ++qyi) {
     // the band row the NEXT q_y needs (region row qyi + UH), fetched now, stored after this row's last step
@@ -861,29 +897,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
 #pragma unroll
       for (int c = 0; c < C; ++c) pf[c] = src[((size_t)c * H + gy) * W + pf_gx];
-    }
-    const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
-    float wgt[KW];
-#pragma unroll
-    for (int k = 0; k < KW; ++k)
-      wgt[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((k - HK >= ylo && k - HK <= yhi) ? 0x3f800000 : 0));
-    const bool interior = ylo == -HK && yhi == HK;
-    float av[PX];
-#pragma unroll
-    for (int j = 0; j < PX; ++j) av[j] = 0.f;
-    if (!interior) {
-      float hf[NHV], cw[KW];
-#pragma unroll
-      for (int t = 0; t < NHV; ++t) hf[t] = hfread[t * HS];
-#pragma unroll
-      for (int k = 0; k < KW; ++k) cw[k] = 1.f - wgt[k];
-#pragma unroll
-      for (int j = 0; j < PX; ++j) {
-        float fv[KW];
-#pragma unroll
-        for (int k = 0; k < KW; ++k) fv[k] = hf[j + k];
-        av[j] = tap_sum<KW>(fv, cw, 0.f);
-      }
     }
     const float *rq = band + ((R + qyi) % UH) * RS + L * g;  // + c*UH*RS + column
     f2 w[C][HL];
@@ -895,7 +908,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float *hw_even = hwrite + (qyi & 1) * UH * HS, *hw_odd = hwrite + ((qyi & 1) ^ 1) * UH * HS;
     float *hwa_even = g <= GA ? hw_even : hdummy, *hwa_odd = g <= GA ? hw_odd : hdummy;
     float *hwb_even = g <= GB ? hw_even : hdummy, *hwb_odd = g <= GB ? hw_odd : hdummy;
-    const float *hr_even = hread + (qyi & 1) * UH * HS, *hr_odd = hread + ((qyi & 1) ^ 1) * UH * HS;
     // One offset = an E/H stage (E_q on the lane's pixels, horizontal sums, H rows to this step's buffer, window moved
     // on) and an edge stage (the 18 H values of the lane's six centres, vertical sums, exp, row sums, stores).  They
     // are software-pipelined: a step runs the E/H stage of the NEXT offset, then the edge stage of its own -- whose H
@@ -987,9 +999,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // (no predicate: the lanes whose centres lie outside the strip's 32 columns -- group 3, and group 2 from its
       // ninth centre on -- point at a few dummy words instead, chosen once per offset row)
       float *hwa = qxi % 2 == 0 ? hwa_even : hwa_odd, *hwb = qxi % 2 == 0 ? hwb_even : hwb_odd;
+      if (SSG_DBG(p, 32)) {   // (profiling: no H stores)
+#pragma unroll
+        for (int k = 0; k < L; ++k) asm volatile("" ::"v"(hs[k]));
+      } else
 #pragma unroll
       for (int k = 0; k < L; ++k) (k < HSPLIT ? hwa : hwb)[k] = hs[k];
-      if (qxi + 1 < KS) {
+      if (qxi + 1 < KS && !SSG_DBG(p, 128)) {
         constexpr int sl = qxi % L;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -999,6 +1015,48 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
     };
+    if (!SSG_DBG(p, 4)) eh_stage(std::integral_constant<int, 0>{});
+    lds_barrier();
+    static_for(std::make_integer_sequence<int, KS - 1>{}, [&](auto qc) {
+      if (!SSG_DBG(p, 4)) eh_stage(std::integral_constant<int, decltype(qc)::value + 1>{});
+      lds_barrier();
+    });
+    if (qyi + 1 < KS) {
+      // (the last step's barrier is behind every wave's last read of region row qyi, whose slot this is)
+      if (tid < RWD) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) band[(c * UH + qyi % UH) * RS + tid] = pf[c];
+      }
+      lds_barrier();
+    }
+  }
+  } else {
+#pragma unroll 1
+  for (int qyi = 0; qyi < KS; ++qyi) {
+    const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
+    float wgt[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+      wgt[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((k - HK >= ylo && k - HK <= yhi) ? 0x3f800000 : 0));
+    const bool interior = ylo == -HK && yhi == HK;
+    float av[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) av[j] = 0.f;
+    if (!interior) {
+      float hf[NHV], cw[KW];
+#pragma unroll
+      for (int t = 0; t < NHV; ++t) hf[t] = hfread[t * HS];
+#pragma unroll
+      for (int k = 0; k < KW; ++k) cw[k] = 1.f - wgt[k];
+#pragma unroll
+      for (int j = 0; j < PX; ++j) {
+        float fv[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) fv[k] = hf[j + k];
+        av[j] = tap_sum<KW>(fv, cw, 0.f);
+      }
+    }
+    const float *hr_even = hread + (qyi & 1) * UH * HS, *hr_odd = hread + ((qyi & 1) ^ 1) * UH * HS;
     // the 18 H values of the lane's six centres as nine register pairs P[m] = (H[2m], H[2m+1]): the vertical sums
     // below are packed operations on them -- these waves are issue-limited (one VALU slot per 4 cycles, DESIGN
     // section 4), so two additions per slot count
@@ -1007,6 +1065,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     auto h_requests = [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
       const float *hc = qxi % 2 == 0 ? hr_even : hr_odd;
+      if (SSG_DBG(p, 16)) return;   // (profiling: no gathers)
 #pragma unroll
       for (int m = 0; m < NHV / 2; ++m) P[m] = f2{hc[2 * m * HS], hc[(2 * m + 1) * HS]};
     };
@@ -1059,6 +1118,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
       // e, row sums, stores: every half-wave's 32 values of a centre row are one aligned 128-byte run
+      if (SSG_DBG(p, 8)) {   // (profiling: no exp / row sums / stores)
+#pragma unroll
+        for (int j = 0; j < PX; ++j) asm volatile("" ::"v"(d[j]));
+      } else
 #pragma unroll
       for (int j = 0; j < PX; ++j) {
         const float ev = __builtin_amdgcn_exp2f(d[j] * nk);
@@ -1066,35 +1129,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // whole row's scale -- a relative 1e-7 off, which the KL part of the gradient sees as 1e-4 of itself)
         rs[j] += (double)ev;
         asm volatile("" : "+v"(rs[j]));   // (or the additions sink to the end of the row, with every e kept for them)
-        cptr[j][qyi * (KS * TM_PX) + qxi * TM_PX] = ev;
+        if (!SSG_DBG(p, 1)) cptr[j][qyi * (KS * TM_PX) + qxi * TM_PX] = ev;
       }
     };
-    eh_stage(std::integral_constant<int, 0>{});
-    lds_barrier();
+    lds_barrier();                                   // (offset 0's H rows are in LDS)
     h_requests(std::integral_constant<int, 0>{});
     static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
       constexpr int qxi = decltype(qc)::value;
-      if constexpr (qxi + 1 < KS) eh_stage(std::integral_constant<int, qxi + 1>{});
-      edge_stage(qc);
+      if (!SSG_DBG(p, 2)) edge_stage(qc);
       if constexpr (qxi + 1 < KS) {
         lds_barrier();
-        h_requests(std::integral_constant<int, qxi + 1>{});
+        if (!SSG_DBG(p, 2)) h_requests(std::integral_constant<int, qxi + 1>{});
       }
     });
-    if (qyi + 1 < KS) {
-      // (the last step's barrier is behind every wave's last read of region row qyi, whose slot this is)
-      if (tid < RWD) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) band[(c * UH + qyi % UH) * RS + tid] = pf[c];
-      }
-      lds_barrier();
-    }
+    if (qyi + 1 < KS) lds_barrier();                 // (the E/H role stores the next band row)
   }
+  }
+#ifdef SSG_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_strip_times[3 * blockIdx.x + 1] = __builtin_readcyclecounter();
+#endif
   // deferred normalisation, the tile-major mark (see the tile kernel)
   double *rsc = p.row_scale + (size_t)which * p.n_host;
+  if (!eh_role) {
 #pragma unroll
-  for (int j = 0; j < PX; ++j)
-    if (orow[j] >= 0) rsc[orow[j]] = -1.0 / (rs[j] + (double)p.eps);
+    for (int j = 0; j < PX; ++j)
+      if (orow[j] >= 0) rsc[orow[j]] = -1.0 / (rs[j] + (double)p.eps);
+  }
 }
 
 // ------------------------------------------------------------------ host ----
@@ -1149,10 +1209,26 @@ static int launch_fwd_strip_t(const DenseParams &p, hipStream_t st) {
   constexpr int UH = 16 * NW, HALO = KS / 2 + KW / 2, RS = DT_X + 2 * HALO + 1, HS = DT_X + 1;
   const size_t lds = sizeof(float) * (size_t)(C * UH * RS + 3 * UH * HS + UH * (DT_X + KW - 1) + 16);
   static std::atomic<unsigned long long> lds_set{0};
-  if (const int rc = ensure_dynamic_lds(ssg_fwd_strip<KS, KW, C, NW>, (int)lds, lds_set)) return rc;
-  hipLaunchKernelGGL((ssg_fwd_strip<KS, KW, C, NW>), dim3((unsigned)p.max_strips * p.nimg), dim3(64 * NW), lds, st, p);
+  if (const int rc = ensure_dynamic_lds(ssg_fwd_strip<KS, KW, C, NW>, 2 * (int)lds, lds_set)) return rc;
+  hipLaunchKernelGGL((ssg_fwd_strip<KS, KW, C, NW>), dim3((unsigned)(p.max_strips * p.nimg + 1) / 2), dim3(256 * NW), 2 * lds, st, p);
   return (int)hipGetLastError();
 }
+
+#ifdef SSG_PROFILE
+int strip_times(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_strip_times), sizeof(unsigned long long) * (size_t)(n < 3072 ? n : 3072));
+}
+// profiling build: workgroups of ssg_fwd_strip<49,13,3,3> the runtime says fit one CU with the launch's dynamic LDS
+int strip_occupancy() {
+  constexpr int KS = 49, KW = 13, C = 3, NW = 3, UH = 16 * NW, HALO = KS / 2 + KW / 2, RS = DT_X + 2 * HALO + 1, HS = DT_X + 1;
+  const size_t lds = sizeof(float) * (size_t)(C * UH * RS + 3 * UH * HS + UH * (DT_X + KW - 1) + 16);
+  static std::atomic<unsigned long long> lds_set{0};
+  if (ensure_dynamic_lds(ssg_fwd_strip<KS, KW, C, NW>, 2 * (int)lds, lds_set)) return -1;
+  int n = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ssg_fwd_strip<KS, KW, C, NW>, 256 * NW, 2 * lds) != hipSuccess) return -2;
+  return n;
+}
+#endif
 
 // a call with a tile-major region (k_s 49, fused step with a row-scale array) launches both variants over the tile
 // list; tm_active() -- device-side, from the plan's counts -- lets one of them run

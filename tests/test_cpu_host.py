@@ -23,8 +23,8 @@ def test_library_builds_loads_and_exports_header_symbols():
     declared = set(re.findall(r"\b(ssg_[a-z_0-9]+)\s*\(", hdr))
     declared -= {"ssg_stream_t"}
     assert len(declared) >= 18
-    # (the one declaration inside `#ifdef SSG_PROFILE` belongs to the profiling build only -- next test)
-    profile_only = {"ssg_set_profile_mask"}
+    # (the declarations inside `#ifdef SSG_PROFILE` belong to the profiling build only -- next test)
+    profile_only = {"ssg_set_profile_mask", "ssg_prof_occupancy"}
     L = ctypes.CDLL(_lib.SO_PATH)
     for name in sorted(declared - profile_only):
         assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
