@@ -880,7 +880,6 @@ __global__ __launch_bounds__(256 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))
   // centres k < HSPLIT of a lane are inside the strip for column groups g <= GA, the others for g <= GB
   constexpr int HSPLIT = DT_X - 2 * L, GA = 2, GB = 1;
   static_assert(L == 12 && DT_X == 32 && HSPLIT == 8, "groups 0, 1 whole, group 2 its first eight centres, group 3 none");
-  float *hdummy = F + UH * UW;                  // [L] dummy words behind F
   const float *hread = Hb + e0 * HS + ecol;     // window row k of centre j is U-row e0 + j + k
   const float *hfread = HF + e0 * HS + ecol;
   __syncthreads();
@@ -906,8 +905,6 @@ __global__ __launch_bounds__(256 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))
       for (int t = 0; t < HL; ++t) w[c][t] = f2{rq[c * UH * RS + t], rq[c * UH * RS + t + HL]};
     // step (qyi, qxi) writes H buffer (qyi + qxi) % 2 (k_s is odd: the parity alternates across rows too)
     float *hw_even = hwrite + (qyi & 1) * UH * HS, *hw_odd = hwrite + ((qyi & 1) ^ 1) * UH * HS;
-    float *hwa_even = g <= GA ? hw_even : hdummy, *hwa_odd = g <= GA ? hw_odd : hdummy;
-    float *hwb_even = g <= GB ? hw_even : hdummy, *hwb_odd = g <= GB ? hw_odd : hdummy;
     // One offset = an E/H stage (E_q on the lane's pixels, horizontal sums, H rows to this step's buffer, window moved
     // on) and an edge stage (the 18 H values of the lane's six centres, vertical sums, exp, row sums, stores).  They
     // are software-pipelined: a step runs the E/H stage of the NEXT offset, then the edge stage of its own -- whose H
@@ -996,15 +993,22 @@ __global__ __launch_bounds__(256 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))
           hs[k + HL] = t.y;
         }
       }
-      // (no predicate: the lanes whose centres lie outside the strip's 32 columns -- group 3, and group 2 from its
-      // ninth centre on -- point at a few dummy words instead, chosen once per offset row)
-      float *hwa = qxi % 2 == 0 ? hwa_even : hwa_odd, *hwb = qxi % 2 == 0 ? hwb_even : hwb_odd;
+      float *hw = qxi % 2 == 0 ? hw_even : hw_odd;
       if (SSG_DBG(p, 32)) {   // (profiling: no H stores)
 #pragma unroll
         for (int k = 0; k < L; ++k) asm volatile("" ::"v"(hs[k]));
-      } else
+      } else {
+        // (round 5: predicated -- the lanes outside the strip used to store to a dummy word instead, and that word's bank
+        // cost every store pass a conflict cycle: 72 of the 134 conflict cycles of a workgroup-step)
+        if (g <= GA) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) (k < HSPLIT ? hwa : hwb)[k] = hs[k];
+          for (int k = 0; k < HSPLIT; ++k) hw[k] = hs[k];
+        }
+        if (g <= GB) {
+#pragma unroll
+          for (int k = HSPLIT; k < L; ++k) hw[k] = hs[k];
+        }
+      }
       if (qxi + 1 < KS && !SSG_DBG(p, 128)) {
         constexpr int sl = qxi % L;
 #pragma unroll
