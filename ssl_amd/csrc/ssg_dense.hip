@@ -886,6 +886,8 @@ __global__ __launch_bounds__(256 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))
 
   // The two roles run the same number of barriers per offset row: 1 (offset 0's H) + KS - 1 (one per further offset) +
   // 1 (band row stored; not after the last row).
+  // (static priority for the E/H role, whose step is the longer one: -1.3 % same-box; the edge role at priority: +1.8 %)
+  if (eh_role) __builtin_amdgcn_s_setprio(1);
   if (eh_role) {
 #pragma unroll 1
   for (int qyi = 0; qyi < KS; ++qyi) {
