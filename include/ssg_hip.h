@@ -160,12 +160,14 @@ size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
  * next ssg_edge_list().  Returns the previous value.  No reference counterpart: the
  * reference has one code path. */
 int ssg_set_dense_threshold(int edge_pixels_per_tile);
-/* on = 0: every launch of a call goes to the caller's stream; on != 0 (default): for k_s <= 25 the direct kernel of a
- * pass runs on a library-owned side stream beside the dense-tile kernel (event fork / join on the caller's stream;
- * capturable).  Same results either way (the two work on disjoint rows).  Process-wide; returns the previous setting.
- * Used to take per-kernel rocprofv3 durations.  No reference counterpart (the reference launches on the legacy stream,
- * similarity.cu:69,147). */
-int ssg_set_overlap(int on);
+/* Stream assignment of the two kernels of a pass for k_s <= 25 (a library-owned side stream, event fork / join on the
+ * caller's stream; capturable).  0: every launch on the caller's stream (per-kernel profiling).  1 (default): the
+ * dense-tile kernel on the caller's stream, the direct kernel beside it on the side stream -- for masks whose dense
+ * tiles carry most rows (Laplacian edge masks).  2: the other way round -- for masks without dense tiles (Bernoulli,
+ * thin strided masks: the whole critical path on one stream; Bernoulli 1 % -15 %, C2 +3 %).  Same results in every
+ * mode (the two kernels work on disjoint rows).  Process-wide; returns the previous setting.  No reference counterpart
+ * (the reference launches on the legacy stream, similarity.cu:69,147). */
+int ssg_set_overlap(int mode);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int H, int W, int mask_stride, float lap_threshold,
                   int plan_ks /* k_s the fwd_plan is built for (tile rows: 8, or 4 for k_s = 49); 0 = 25.

@@ -78,7 +78,7 @@ int launch_filter2d(const float *img, const float *kernels, float *out, int B, i
                     hipStream_t st);
 int launch_usm_sharp(const float *img, float *out, int B, int C, int H, int W, int ksize, float sigma, float weight,
                      float threshold, void *scratch, hipStream_t st);
-int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, int assign, hipStream_t st);
+int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, int assign, hipStream_t st, const LossFinalize *fin = nullptr);
 int launch_grad_fix_bound(const BwdParams &p, hipStream_t st);
 int launch_grad_fix_reduce(const float *part, int n, long long *gfix, size_t n_fix, hipStream_t st);
 }  // namespace ssg
@@ -152,19 +152,34 @@ struct SideStream {
   hipEvent_t forked = nullptr, joined = nullptr;
 };
 static std::atomic<int> g_overlap{-1};
-static bool overlap_enabled() {
+static int overlap_mode() {   // 0 off, 1 dense-tile kernel on the caller's stream (default), 2 direct kernel on the caller's stream
   int v = g_overlap.load(std::memory_order_relaxed);
   if (v < 0) {
-    v = env_int("SSG_OVERLAP", 1) != 0;
+    v = env_int("SSG_OVERLAP", 1);
+    v = v < 0 ? 0 : (v > 2 ? 2 : v);
     g_overlap.store(v, std::memory_order_relaxed);
   }
-  return v != 0;
+  return v;
+}
+static bool overlap_enabled() { return overlap_mode() != 0; }
+// the two streams of a forked pass: .first takes the dense-tile kernel, .second the direct one
+struct StreamPair {
+  hipStream_t dense, direct;
+};
+static StreamPair assign_streams(hipStream_t st, hipStream_t st2) {
+  return overlap_mode() == 2 ? StreamPair{st2, st} : StreamPair{st, st2};
 }
 // ssg_set_overlap(0): every launch on the caller's stream (per-kernel rocprofv3 durations: profiles/*_kernel_stats.csv
-// are taken that way; same results -- the two branches work on disjoint rows).  Returns the previous setting.
-extern "C" int ssg_set_overlap(int on) {
-  const int prev = overlap_enabled() ? 1 : 0;
-  g_overlap.store(on ? 1 : 0, std::memory_order_relaxed);
+// are taken that way; same results -- the two branches work on disjoint rows).  1 (default): the dense-tile kernel on
+// the caller's stream, the direct one on the side stream -- right where dense tiles carry most rows (Laplacian masks:
+// C2).  2: the other way round -- right for masks WITHOUT dense tiles (Bernoulli / thin strided masks), whose whole
+// critical path then sits on one stream and whose join finds the side stream's empty launches finished.  Measured on one
+// box (profiles/r5_ab_stream_assignment.txt): mode 2 against 1: Bernoulli 1 % 0.213 -> 0.182 ms, 4 % 0.491 -> 0.466,
+// C4 0.498 -> 0.508, C2 1.275 -> 1.317 (the fork's latency lands on whichever kernel runs on the side stream).
+// Returns the previous setting.
+extern "C" int ssg_set_overlap(int mode) {
+  const int prev = overlap_mode();
+  g_overlap.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
   return prev;
 }
 static SideStream *side_stream() {
@@ -272,15 +287,7 @@ static bool tile_major_enabled() {
 // kernel, the remaining rows by the direct kernel in GRAD_D mode.  `p` carries the sources as for launch_bwd.
 // the loss finalize of a GRAD_LOSS step: it needs ssg_grad_rows' partial sums only, so it is queued on the side stream
 // ahead of the direct backward kernel instead of at the very end of the caller's stream (7 us off the critical path)
-struct FinalizeArgs {
-  const float *partials;
-  int nparts;
-  const int *n_dev;
-  int n_host, P;
-  float w_l1, w_kl;
-  float *loss_out;
-  int nan_on_overflow;
-};
+using FinalizeArgs = LossFinalize;   // {partials, nparts, n_dev, n_host, P, w_l1, w_kl, loss_out, nan_on_overflow}
 
 // nparts of a split backward's criteria sums: ssg_grad_rows' workgroups, then ssg_rows_tm's
 static int split_tm_tiles(const BwdParams &p, const TileMajor *tm) {
@@ -390,13 +397,17 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   }
   SideStream *fk = nullptr;
   hipStream_t st2 = (dbg_mask() & ((1 << 27) | (1 << 28))) ? st : fork_from(st, p.ks, fk);
-  if (fin && fk && st2 != st) {   // (only when there IS a side stream: on one stream it would only delay the backward)
+  // (which kernel runs on which stream: ssg_set_overlap.  With a side stream the loss finalize -- it needs ssg_grad_rows'
+  // partial sums only -- is queued there ahead of that stream's kernel, off the critical path; on one stream it rides in
+  // the last workgroup of grad_fix_flush (det_end, round 5) or, without a fixed-point buffer, follows the backward.)
+  if (fin && fk && st2 != st) {
     rc = launch_loss_finalize(fin->partials, fin->nparts, fin->n_dev, fin->n_host, fin->P, fin->w_l1, fin->w_kl,
                               fin->loss_out, fin->nan_on_overflow, st2);
     if (rc) return rc;
     if (fin_done) *fin_done = true;
   }
-  rc = (dbg_mask() & (1 << 27)) ? 0 : launch_bwd_dense(d, p.ks, p.kw, p.C, st);
+  const StreamPair sp = assign_streams(st, st2);
+  rc = (dbg_mask() & (1 << 27)) ? 0 : launch_bwd_dense(d, p.ks, p.kw, p.C, sp.dense);
   if (!rc && !(dbg_mask() & (1 << 28))) {
     BwdParams s = p;
     s.mode = GRAD_D;
@@ -404,8 +415,9 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
     s.order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
     s.n_dev = plan;  // n_sparse
     s.partials = nullptr;
-    rc = launch_bwd(s, st2);
+    rc = launch_bwd(s, sp.direct);
   }
+
   const int rcj = join_to(st, fk);
   return rc ? rc : rcj;
 }
@@ -418,9 +430,11 @@ static int det_begin(BwdParams &p, void *grad_fix, hipStream_t st, bool prezeroe
   if (prezeroed) return 0;   // (the fused step: cleared by the edge-list builder's first kernel)
   return (int)hipMemsetAsync(grad_fix, 0, sizeof(long long) * ((size_t)p.B * p.C * p.H * p.W + 8), st);
 }
-static int det_end(const BwdParams &p, hipStream_t st, bool assign = false) {
+static int det_end(const BwdParams &p, hipStream_t st, bool assign = false, const LossFinalize *fin = nullptr, bool *fin_done = nullptr) {
   if (!p.gfix) return 0;
-  return launch_grad_fix_flush(p.gfix, p.grad, (size_t)p.B * p.C * p.H * p.W, assign ? 1 : 0, st);
+  const int rc = launch_grad_fix_flush(p.gfix, p.grad, (size_t)p.B * p.C * p.H * p.W, assign ? 1 : 0, st, fin);
+  if (!rc && fin && fin_done) *fin_done = true;
+  return rc;
 }
 
 // ---- the reference operator with many positions: plan built inside the call -------------------------------------------
@@ -611,11 +625,12 @@ int ssg_compute_similarity(const float *image, const int *pos, float *out, int m
       d.status = device_status_word();
       SideStream *fk = nullptr;
       hipStream_t st2 = fork_from(st, psize, fk);
-      rc = launch_fwd_dense(d, psize, ksize, channel, st);
+      const StreamPair sp = assign_streams(st, st2);
+      rc = launch_fwd_dense(d, psize, ksize, channel, sp.dense);
       FwdParams q = p;
       q.order = o.plan + fwd_plan_order_offset(1, height, width);
       q.n_dev = o.plan;   // n_sparse
-      if (!rc) rc = launch_fwd(q, st2);
+      if (!rc) rc = launch_fwd(q, sp.direct);
       const int rcj = join_to(st, fk);
       if (!rc) rc = rcj;
       q.order = o.dup;
@@ -771,10 +786,11 @@ static int map_forward_impl(const float *img, const float *img2, int B, int C, i
     SideStream *fk = nullptr;
     hipStream_t st = (hipStream_t)stream;
     hipStream_t st2 = (dbg_mask() & ((1 << 25) | (1 << 26))) ? st : fork_from(st, ks, fk);
-    int rc = (dbg_mask() & (1 << 25)) ? 0 : launch_fwd_dense(d, ks, kw, C, st);
+    const StreamPair sp = assign_streams(st, st2);   // (ssg_set_overlap)
+    int rc = (dbg_mask() & (1 << 25)) ? 0 : launch_fwd_dense(d, ks, kw, C, sp.dense);
     p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
     p.n_dev = fwd_plan;  // n_sparse
-    if (!rc && !(dbg_mask() & (1 << 26))) rc = launch_fwd(p, st2);
+    if (!rc && !(dbg_mask() & (1 << 26))) rc = launch_fwd(p, sp.direct);
     const int rcj = join_to(st, fk);
     return rc ? rc : rcj;
   }
@@ -882,8 +898,9 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   if (rc) return rc;
   int nparts;
   bool fin_done = false;
-  if (split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) {
-    nparts = (int)grow_grid(n_rows) + rows_tm_parts(split_tm_tiles(p, tm));
+  const bool split = split_ok(ks, kw, C, rank_map, fwd_plan, scratch);
+  nparts = split ? (int)grow_grid(n_rows) + rows_tm_parts(split_tm_tiles(p, tm)) : 0;
+  if (split) {
     const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0};
     rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done, tm);
   } else {
@@ -891,7 +908,8 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
     if (!rc) rc = launch_bwd(p, st);
     nparts = (int)bwd_grid(p);
   }
-  if (!rc) rc = det_end(p, st, grad_is_output);
+  const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0};
+  if (!rc) rc = det_end(p, st, grad_is_output, fin_done ? nullptr : &fin, &fin_done);   // (the finalize rides in the flush)
   if (rc || fin_done) return rc;
   return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0, st);
 }

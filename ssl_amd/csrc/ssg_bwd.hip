@@ -648,48 +648,68 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
 }
 
 // loss_out[0] = w_l1 * sum|a-b| / M, loss_out[1] = w_kl * sum t'(log t' - log s') / M.
-// One workgroup, fp64, fixed summation order (lane-strided partial sums, then lane order).
-__global__ __launch_bounds__(1024) void ssg_loss_finalize(const float *partials, int nparts, const int *n_dev,
-                                                          int n_host, int P, float w_l1, float w_kl, float *loss_out,
-                                                          int nan_on_overflow) {
-  __shared__ double s1[1024], s2[1024];
-  const float2 *pp = (const float2 *)partials;
-  double a = 0, b = 0;
-  int i = threadIdx.x;
-  for (; i + 3 * 1024 < nparts; i += 4 * 1024) {  // four independent loads in flight
-    const float2 v0 = pp[i], v1 = pp[i + 1024], v2 = pp[i + 2048], v3 = pp[i + 3072];
-    a += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
-    b += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
+// One workgroup, fp64, fixed summation order: 1,024 lane-strided partial sums, then a binary tree over them -- written for
+// NT threads that each play 1024 / NT of those lanes, so that the standalone kernel (NT = 1024) and the tail of
+// grad_fix_flush (NT = 256, round 5: one launch less at the end of every deterministic step) give the same bits.
+template <int NT>
+__device__ __forceinline__ void loss_finalize_body(const LossFinalize &f, double *s1, double *s2) {
+  const float2 *pp = (const float2 *)f.partials;
+  for (int vt = threadIdx.x; vt < 1024; vt += NT) {
+    double a = 0, b = 0;
+    int i = vt;
+    for (; i + 3 * 1024 < f.nparts; i += 4 * 1024) {  // four independent loads in flight
+      const float2 v0 = pp[i], v1 = pp[i + 1024], v2 = pp[i + 2048], v3 = pp[i + 3072];
+      a += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
+      b += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
+    }
+    for (; i < f.nparts; i += 1024) {
+      const float2 v = pp[i];
+      a += (double)v.x;
+      b += (double)v.y;
+    }
+    s1[vt] = a;
+    s2[vt] = b;
   }
-  for (; i < nparts; i += 1024) {
-    const float2 v = pp[i];
-    a += (double)v.x;
-    b += (double)v.y;
-  }
-  s1[threadIdx.x] = a;
-  s2[threadIdx.x] = b;
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      s1[threadIdx.x] += s1[threadIdx.x + o];
-      s2[threadIdx.x] += s2[threadIdx.x + o];
+    for (int vt = threadIdx.x; vt < o; vt += NT) {
+      s1[vt] += s1[vt + o];
+      s2[vt] += s2[vt + o];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const int nrows = rows_to_do(n_dev, n_host);
-    const double M = (double)nrows * (double)P;
-    loss_out[0] = nrows > 0 ? (float)((double)w_l1 * s1[0] / M) : 0.f;
-    loss_out[1] = nrows > 0 ? (float)((double)w_kl * s2[0] / M) : 0.f;
+    const int nrows = rows_to_do(f.n_dev, f.n_host);
+    const double M = (double)nrows * (double)f.P;
+    f.loss_out[0] = nrows > 0 ? (float)((double)f.w_l1 * s1[0] / M) : 0.f;
+    f.loss_out[1] = nrows > 0 ? (float)((double)f.w_kl * s2[0] / M) : 0.f;
     // the fused entry points: a step that found more edge pixels than the caller's capacity has used the first
     // `capacity` of them only -- its losses are NaN, so that a truncated step cannot pass for a complete one
-    if (nan_on_overflow && n_dev && *n_dev > n_host) loss_out[0] = loss_out[1] = __builtin_nanf("");
+    if (f.nan_on_overflow && f.n_dev && *f.n_dev > f.n_host) f.loss_out[0] = f.loss_out[1] = __builtin_nanf("");
   }
+}
+__global__ __launch_bounds__(1024) void ssg_loss_finalize(LossFinalize f) {
+  __shared__ double s1[1024], s2[1024];
+  loss_finalize_body<1024>(f, s1, s2);
 }
 
 // deterministic mode: grad += fixed-point sums (one rounding per pixel); assign != 0: grad = the sums (ssg_loss_step:
 // the gradient is an output, nobody has to clear it first)
-__global__ __launch_bounds__(256) void grad_fix_flush(const long long *gfix, float *grad, size_t n, int assign) {
+// FIN: the step's loss finalize rides in the LAST workgroup (its partial sums were complete before this launch).
+template <bool FIN>
+__device__ __forceinline__ void grad_fix_flush_body(const long long *gfix, float *grad, size_t n, int assign);
+template <bool FIN>
+__global__ __launch_bounds__(256) void grad_fix_flush(const long long *gfix, float *grad, size_t n, int assign, LossFinalize f) {
+  grad_fix_flush_body<FIN>(gfix, grad, n, assign);
+  if constexpr (FIN) {
+    if (blockIdx.x == gridDim.x - 1) {
+      __shared__ double s1[1024], s2[1024];
+      loss_finalize_body<256>(f, s1, s2);
+    }
+  }
+}
+template <bool FIN>
+__device__ __forceinline__ void grad_fix_flush_body(const long long *gfix, float *grad, size_t n, int assign) {
   const double inv = 1.0 / (double)grad_fix_scale(gfix, n);
   if ((((size_t)gfix & 15) | ((size_t)grad & 7)) == 0) {
     // two sums per lane and iteration: one 16-byte load, one 8-byte store (the pass is 37 MB of traffic at C2, at the end
@@ -778,11 +798,12 @@ int launch_grad_fix_bound(const BwdParams &p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, int assign, hipStream_t st) {
-  if (!n) return 0;
+int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, int assign, hipStream_t st, const LossFinalize *fin) {
+  if (!n) return fin ? -1 : 0;
   const size_t units = (n + 1) / 2;   // (two sums per lane)
   const unsigned grid = (unsigned)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
-  hipLaunchKernelGGL(grad_fix_flush, dim3(grid), dim3(256), 0, st, gfix, grad, n, assign);
+  if (fin) hipLaunchKernelGGL(grad_fix_flush<true>, dim3(grid), dim3(256), 0, st, gfix, grad, n, assign, *fin);
+  else hipLaunchKernelGGL(grad_fix_flush<false>, dim3(grid), dim3(256), 0, st, gfix, grad, n, assign, LossFinalize{});
   return (int)hipGetLastError();
 }
 
@@ -843,8 +864,8 @@ int launch_bwd(const BwdParams &p, hipStream_t st) {
 
 int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
                          float w_kl, float *loss_out, int nan_on_overflow, hipStream_t st) {
-  hipLaunchKernelGGL(ssg_loss_finalize, dim3(1), dim3(1024), 0, st, partials, nparts, n_dev, n_host, P, w_l1, w_kl,
-                     loss_out, nan_on_overflow);
+  hipLaunchKernelGGL(ssg_loss_finalize, dim3(1), dim3(1024), 0, st,
+                     LossFinalize{partials, nparts, n_dev, n_host, P, w_l1, w_kl, loss_out, nan_on_overflow});
   return (int)hipGetLastError();
 }
 

@@ -236,6 +236,17 @@ __device__ __forceinline__ float criteria_elem_any(float a, float b, float w1m, 
   return g;
 }
 
+// arguments of the loss finalize (ssg_bwd.hip: ssg_loss_finalize, or the tail of grad_fix_flush)
+struct LossFinalize {
+  const float *partials;
+  int nparts;
+  const int *n_dev;
+  int n_host, P;
+  float w_l1, w_kl;
+  float *loss_out;
+  int nan_on_overflow;
+};
+
 // Environment switches exist in the PROFILING build only (libssg_hip_prof.so, -DSSG_PROFILE: the A/B measurements of
 // tools/).  The product library never reads the environment: what it does is set through the C ABI
 // (ssg_set_dense_threshold, ssg_set_operator_plan_threshold, ssg_set_overlap) or not at all, so that every path it can

@@ -769,7 +769,7 @@ def test_every_tile_through_the_dense_kernels_and_no_side_stream(dev):
     sr = np.stack([synth.degrade(gt[i], 1700 + i, 0.04) for i in range(2)])
     mask = np.stack([synth.laplacian_edge_mask(gt[i]) for i in range(2)])
     mask[:, 0, 0] = mask[:, -1, -1] = 1
-    prev_thr, prev_ov = engine.set_dense_threshold(1), engine.set_overlap(False)
+    prev_thr, prev_ov = engine.set_dense_threshold(1), engine.set_overlap(0)
     try:
         for sigma in (0.004, 1.0):
             ref = orc.ssg_loss(sr.astype(np.float64), gt.astype(np.float64), mask, ks, kw, sigma, 1e3, 1e3)
@@ -784,13 +784,15 @@ def test_every_tile_through_the_dense_kernels_and_no_side_stream(dev):
                                               step.ssg_gt[:n].cpu().numpy())
             assert maxerr(grad.cpu(), gref) <= grad_tol_from_oracle(sr, gt, mask, ks, kw, sigma, ref)
             engine.set_dense_threshold(prev_thr)
-            engine.set_overlap(True)
-            step2 = engine.LossStep(2, 3, 72, 100, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
-            loss2, grad2 = step2(T(sr, dev), T(gt, dev), T(mask[:, None].astype(np.float32), dev))
-            l2 = loss2.cpu().numpy()
-            assert abs(l2[0] - l[0]) <= 2e-6 * l[0] and abs(l2[1] - l[1]) <= 2e-5 * l[1] + 2e-8
+            for mode in (1, 2):      # dense kernel on the caller's stream / on the side stream (ssg_set_overlap)
+                engine.set_overlap(mode)
+                step2 = engine.LossStep(2, 3, 72, 100, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
+                loss2, grad2 = step2(T(sr, dev), T(gt, dev), T(mask[:, None].astype(np.float32), dev))
+                l2 = loss2.cpu().numpy()
+                assert abs(l2[0] - l[0]) <= 2e-6 * l[0] and abs(l2[1] - l[1]) <= 2e-5 * l[1] + 2e-8
+                assert maxerr(grad2.cpu(), gref) <= grad_tol_from_oracle(sr, gt, mask, ks, kw, sigma, ref)
             engine.set_dense_threshold(1)
-            engine.set_overlap(False)
+            engine.set_overlap(0)
     finally:
         engine.set_dense_threshold(prev_thr)
         engine.set_overlap(prev_ov)
