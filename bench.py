@@ -343,6 +343,9 @@ def binding_resource(kernel_name, kernel_ms):
           "valu": e.get("valu_insts_per_launch", 0.0) * VALU_CYCLES_PER_INST / N_SIMD / CLOCK_HZ / t,
           "lds": e.get("lds_active_cycles_per_launch", 0.0) / N_CU / CLOCK_HZ / t}
     bound = max(fr, key=fr.get)
+    # the same instruction count at the rate the MI355X measures for a plain fp32 instruction at 2 waves per SIMD
+    # (profiles/r1_microbench2_valu.txt: 2.8 cycles; packed ones ~5): still a lower bound where instructions are packed
+    fr["valu_measured_rate"] = fr["valu"] * 2.8 / VALU_CYCLES_PER_INST
     return bound, {"busy_fraction_of_kernel_time": fr,
                    "how": "profiles/pmc_traffic.json counters of this kernel / the duration measured here; hbm = PMC "
                           "bytes at 8 TB/s, valu = SQ_INSTS_VALU x 2 cycles / 1024 SIMDs at 2.4 GHz (lower bound: "
