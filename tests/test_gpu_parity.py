@@ -1335,6 +1335,35 @@ def test_tile_major_steps_replay_as_hip_graph(dev, materialise):
     assert same() == n1
 
 
+def test_tile_major_materialising_step_with_unaligned_ssg_tensors(dev):
+    """ssg_rows_tm_mat writes the caller's SSG tensors as 64-byte-aligned dwordx4 segments (round 5); the C ABI only asks
+    for fp32 pointers, so the segments must follow the POINTER's phase: SSG tensors that start 4 and 12 bytes into an
+    allocation (views of larger buffers) get bit for bit the rows of 256-byte-aligned ones, with guard words before and
+    behind them untouched; a ragged mask (holes, short strips) beside the dense one."""
+    from ssl_amd import engine, synth
+    B, H, W, ks, kw, sigma = 1, 80, 96, 49, 13, 0.05
+    gt_np = synth.natural_like(51, H, W)[None]
+    sr, gt = T(synth.degrade(gt_np[0], 52)[None], dev), T(gt_np, dev)
+    for dens in (1.1, 0.8):
+        mask = (torch.rand((B, 1, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) < dens).float()
+        ref = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True)
+        l0, g0 = ref(sr, gt, mask)
+        n = int(ref.counts[0])
+        P = ks * ks
+        odd = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True)
+        cap = odd.capacity
+        buf_a = torch.full((cap * P + 64,), -7.0, device=dev)
+        buf_b = torch.full((cap * P + 64,), -7.0, device=dev)
+        odd.ssg_sr = buf_a[1:1 + cap * P].view(cap, P)       # 4 bytes past a 256-byte boundary
+        odd.ssg_gt = buf_b[3:3 + cap * P].view(cap, P)       # 12 bytes
+        assert odd.ssg_sr.data_ptr() % 16 == 4 and odd.ssg_gt.data_ptr() % 16 == 12
+        l1, g1 = odd(sr, gt, mask)
+        assert int(odd.counts[0]) == n and torch.equal(l0, l1) and torch.equal(g0, g1)
+        assert torch.equal(odd.ssg_sr[:n], ref.ssg_sr[:n]) and torch.equal(odd.ssg_gt[:n], ref.ssg_gt[:n])
+        assert float(buf_a[0]) == -7.0 and float(buf_b[:3].min()) == -7.0 and float(buf_b[:3].max()) == -7.0
+        assert bool((buf_a[1 + n * P:] == -7.0).all()) and bool((buf_b[3 + n * P:] == -7.0).all())
+
+
 def tile_major_ssg(step):
     """(s_sr, s_gt), each (N, k_s^2) float32 in edge-list order, of a finished fused k_s = 49 call, rebuilt from its
     workspace (ssg_loss_workspace_layout): the plan's dense-tile list gives every tile its slot, the slot holds
