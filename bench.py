@@ -698,7 +698,7 @@ def main():
 
     # Pre-warm BY TIME before the counted warm-up (disclosure, not tuning: a fresh box ramps its shader clock over the
     # first tens of milliseconds of work, and `--warmup 10` is 13 ms of GPU time at C2): 10-step blocks until two
-    # consecutive ones agree to 1 % or 0.5 s have passed.  Reported as config.prewarm_steps / prewarm_ms; the W warm-up
+    # consecutive ones agree to 0.5 % (and 0.2 s have passed) or 0.5 s have passed.  Reported as config.prewarm_steps / prewarm_ms; the W warm-up
     # steps and the K timed steps below are exactly the ones asked for.
     prewarm_steps, prewarm_t0, last_blk = 0, time.perf_counter(), None
     if not args.dry_run and not args.no_prewarm and step is not None:
@@ -710,7 +710,9 @@ def main():
             torch.cuda.synchronize()
             blk = time.perf_counter() - tb
             prewarm_steps += 10
-            if last_blk is not None and abs(blk - last_blk) <= 0.01 * last_blk:
+            # (steady = two consecutive blocks within 0.5 % AND at least 0.2 s of work: a slowly ramping clock moves
+            #  consecutive 13 ms blocks by less than 1 % while the step is still 1.5 % off its final time)
+            if last_blk is not None and abs(blk - last_blk) <= 0.005 * last_blk and time.perf_counter() - prewarm_t0 >= 0.2:
                 break
             last_blk = blk
     prewarm_ms = (time.perf_counter() - prewarm_t0) * 1e3 if prewarm_steps else 0.0
