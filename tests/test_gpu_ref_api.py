@@ -325,6 +325,41 @@ def test_unchanged_loop_at_c2_full_size_equals_the_batched_step(dev):
     assert float((sr.grad - grad).abs().max()) <= 3e-6 * float(grad.abs().max())
 
 
+def test_native_criteria_on_foreign_tensors_nan_and_extreme_ratios(dev):
+    """L1Loss / KLDistanceLoss accept ANY fp32 GPU tensors, not only SSG rows: a NaN in either operand
+    reaches both losses and the gradient as it does through torch.clamp / F.kl_div / sign (v_max_f32 alone would drop it);
+    an L1-only gradient never sees the KL ratio (|target| / pred beyond fp32: no NaN / inf); tensors on the same device
+    only; `set_native_criteria(False)` gives the reference's torch expressions (double backward works there)."""
+    from ssl_amd.losses import KLDistanceLoss, L1Loss, set_native_criteria
+    a = torch.rand(1, 64, 121, device=dev) * 1e-3
+    b = torch.rand(1, 64, 121, device=dev) * 1e-3
+    for where in ("pred", "target"):
+        x, y = a.clone(), b.clone()
+        (x if where == "pred" else y)[0, 3, 7] = float("nan")
+        x.requires_grad_(True)
+        l1, kl = L1Loss(1.0)(x, y), KLDistanceLoss(1.0)(x, y)
+        assert torch.isnan(l1) and torch.isnan(kl), where
+        (l1 + kl).backward()
+        assert torch.isnan(x.grad[0, 3, 7]) and bool(torch.isfinite(x.grad[0, 0]).all())
+    x = a.clone()
+    x[0, 0, :8] = 1e-38                       # pred tiny, target huge: the ratio overflows fp32
+    y = b.clone()
+    y[0, 0, :8] = 3e38
+    x.requires_grad_(True)
+    L1Loss(1.0, "sum")(x, y).backward()
+    assert bool(torch.isfinite(x.grad).all()) and bool((x.grad[0, 0, :8] == -1.0).all())
+    prev = set_native_criteria(False)
+    try:
+        z = a.clone().requires_grad_(True)
+        l = KLDistanceLoss(1.0)(z, b)
+        assert not graph_nodes(l, "_CriterionSumBackward")
+        g, = torch.autograd.grad(l, z, create_graph=True)
+        g.pow(2).sum().backward()             # second derivative through the torch expressions
+        assert z.grad is not None and bool(torch.isfinite(z.grad).all())
+    finally:
+        set_native_criteria(prev)
+
+
 def test_criterion_modules_on_materialised_tensors_match_torch(dev):
     """L1Loss / KLDistanceLoss on real fp32 GPU tensors run the engine's streaming criteria kernels (one pass forward,
     one backward); values and gradients against the reference's torch expressions evaluated in fp64 (basic_loss.py:16,
