@@ -697,33 +697,34 @@ def main():
                 step(sr, gt, mask)
 
     # Pre-warm BY TIME before the counted warm-up (disclosure, not tuning: a fresh box ramps its shader clock over the
-    # first tens of milliseconds of work, and `--warmup 10` is 13 ms of GPU time at C2): 10-step blocks until two
-    # consecutive ones agree to 0.5 % (and 0.2 s have passed) or 0.5 s have passed.  Reported as config.prewarm_steps / prewarm_ms; the W warm-up
-    # steps and the K timed steps below are exactly the ones asked for.
-    prewarm_steps, prewarm_t0, last_blk = 0, time.perf_counter(), None
-    if not args.dry_run and not args.no_prewarm and step is not None:
+    # first tenths of a second of work, and `--warmup 10` is 13 ms of GPU time at C2).  The pre-warm REHEARSES the timed
+    # region -- W warm-up steps, synchronise, K steps, synchronise -- until two consecutive rehearsals agree to 0.5 % (and
+    # 0.3 s have passed) or 1 s has passed; the W warm-up steps and the K timed steps that follow are exactly the ones
+    # asked for.  (Rehearsing the same shape matters: after a pre-warm made of differently shaped blocks the first timed
+    # block came out 1.5-2 % slower than the two behind it, tools/r5_blocks*.py.)  Reported: config.prewarm_steps /
+    # prewarm_ms / prewarm_block_ms_per_step.
+    def timed_round():
+        for _ in range(args.warmup):
+            run_step()
+        sync_all()
+        t_0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        sync_all()
+        return time.perf_counter() - t_0
+
+    prewarm_steps, prewarm_t0, last_blk, prewarm_blocks = 0, time.perf_counter(), None, []
+    if not args.dry_run and not args.no_prewarm and step is not None and world == 1:
         torch.cuda.synchronize()
-        while time.perf_counter() - prewarm_t0 < 0.5:
-            tb = time.perf_counter()
-            for _ in range(10):
-                run_step()
-            torch.cuda.synchronize()
-            blk = time.perf_counter() - tb
-            prewarm_steps += 10
-            # (steady = two consecutive blocks within 0.5 % AND at least 0.2 s of work: a slowly ramping clock moves
-            #  consecutive 13 ms blocks by less than 1 % while the step is still 1.5 % off its final time)
-            if last_blk is not None and abs(blk - last_blk) <= 0.005 * last_blk and time.perf_counter() - prewarm_t0 >= 0.2:
+        while time.perf_counter() - prewarm_t0 < 1.0:
+            blk = timed_round()
+            prewarm_blocks.append(blk / max(args.steps, 1) * 1e3)
+            prewarm_steps += args.steps + args.warmup
+            if last_blk is not None and abs(blk - last_blk) <= 0.005 * last_blk and time.perf_counter() - prewarm_t0 >= 0.3:
                 break
             last_blk = blk
     prewarm_ms = (time.perf_counter() - prewarm_t0) * 1e3 if prewarm_steps else 0.0
-    for _ in range(args.warmup):
-        run_step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_round()
 
     # two more blocks of the same K steps, for information only (`config.ms_per_step_blocks`): the first entry is the
     # timed region above; a clock still ramping after the warm-up shows up as a first block slower than the others
@@ -770,7 +771,7 @@ def main():
                        "mask_density": n_edges / max(B * cfg["H"] * cfg["W"], 1),
                        "input_checksum": synth.checksum(sr_np, gt_np, mask_np),
                        "gradient_accumulation": "fixed-point integer atomics (bit-reproducible, the shipped default)",
-                       "prewarm_steps": prewarm_steps, "prewarm_ms": prewarm_ms,
+                       "prewarm_steps": prewarm_steps, "prewarm_ms": prewarm_ms, "prewarm_block_ms_per_step": prewarm_blocks,
                        "ms_per_step_blocks": blocks,
                        "ms_per_step_block2": blocks[1] if len(blocks) > 1 else None,
                        "ms_per_step_block3": blocks[2] if len(blocks) > 2 else None,
