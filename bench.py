@@ -714,13 +714,17 @@ def main():
         return time.perf_counter() - t_0
 
     prewarm_steps, prewarm_t0, last_blk, prewarm_blocks = 0, time.perf_counter(), None, []
-    if not args.dry_run and not args.no_prewarm and step is not None and world == 1:
+    if not args.dry_run and not args.no_prewarm and step is not None:
         torch.cuda.synchronize()
-        while time.perf_counter() - prewarm_t0 < 1.0:
+        rounds = 0
+        # (several ranks: a fixed number of rehearsals -- every round ends in a barrier, so the ranks must agree on the count)
+        while (rounds < 3) if world > 1 else (time.perf_counter() - prewarm_t0 < 1.0):
             blk = timed_round()
+            rounds += 1
             prewarm_blocks.append(blk / max(args.steps, 1) * 1e3)
             prewarm_steps += args.steps + args.warmup
-            if last_blk is not None and abs(blk - last_blk) <= 0.005 * last_blk and time.perf_counter() - prewarm_t0 >= 0.3:
+            if world == 1 and last_blk is not None and abs(blk - last_blk) <= 0.005 * last_blk and \
+                    time.perf_counter() - prewarm_t0 >= 0.3:
                 break
             last_blk = blk
     prewarm_ms = (time.perf_counter() - prewarm_t0) * 1e3 if prewarm_steps else 0.0
