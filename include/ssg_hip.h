@@ -435,6 +435,9 @@ int ssg_poisson_noise(const float *img, float *out, const float *draw_color, con
 int ssg_set_profile_mask(int mask);
 /* workgroups per CU the HIP runtime reports for a kernel at its launch geometry (0: ssg_fwd_strip<49,13,3,3>) */
 int ssg_prof_occupancy(int which);
+/* ssg_fwd_strip's per-workgroup clocks of its last launch: host[3 i] = start, [3 i + 1] = end (s_memtime; comparable
+ * within one XCD only), [3 i + 2] = XCC id << 32 | HW_ID, for the first n / 3 (<= 1024) workgroups */
+int ssg_prof_strip_times(unsigned long long *host, int n);
 #endif
 
 /* Host helper for profiling builds: name of the HIP kernel a configuration
