@@ -1021,7 +1021,10 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   }
   // tile-major rows: always in the fused step; in a materialising call when the caller's workspace has room for the
   // two regions (ssg_loss_tm_bytes) -- ssg_rows_tm_mat then writes the normalised SSG rows from them
+  // (ssg_fwd_strip addresses a region with 32-bit ELEMENT offsets: regions of 2^32 floats = 16 GB and more -- from 1.78 M
+  // rows per call -- stay on row-major rows)
   if (ks == 49 && kw == 13 && C == 3 && generalization && tile_major_enabled() &&
+      (size_t)(lw.tm_slots + 1) * (size_t)(ks * ks) * TM_PX < (1ull << 32) &&
       (fused || workspace_bytes >= base_bytes + ssg_loss_tm_bytes(capacity, ks))) {
     tm.rows[0] = (float *)(ws + lw.tm[0]);
     tm.rows[1] = (float *)(ws + lw.tm[1]);

@@ -861,7 +861,8 @@ __global__ __launch_bounds__(256 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))
   const int ecol = tid_e % DT_X, e0 = (tid_e / DT_X) * PX;
   const int ty_n = (H + 3) / 4, n_tq = ty_n - ty0 / 4 < SY / 4 ? ty_n - ty0 / 4 : SY / 4;
   int orow[PX];
-  unsigned coff[PX];   // BYTE offset of the centre's pixel in the tile-major region (4 (slot * P * 128 + pixel index) < 2^32)
+  unsigned coff[PX];   // ELEMENT offset of the centre's pixel in the tile-major region: (slots + 1) * P * 128 < 2^32 (16 GB per
+                       // image: ssg_api.hip keeps larger calls on row-major rows)
   // (wave-uniform, and told so: `which` comes from the thread index through the strip pairing, and only a base the
   // compiler knows to live in SGPRs gives `global_store_dword v_off, v_data, s[base]`)
   float *const tmbase = __builtin_amdgcn_readfirstlane(which) ? p.tm[1] : p.tm[0];
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(256 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int rk = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
     orow[j] = rk >= nrows ? -1 : rk;
     const int tq = (e0 + j) >> 2, ey = (e0 + j) & 3;
-    coff[j] = 4u * ((unsigned)(tq < n_tq ? first + tq : p.tm_slots) * (unsigned)(P * TM_PX) + (unsigned)(64 * (ey & 1) + 32 * (ey >> 1) + ecol));
+    coff[j] = (unsigned)(tq < n_tq ? first + tq : p.tm_slots) * (unsigned)(P * TM_PX) + (unsigned)(64 * (ey & 1) + 32 * (ey >> 1) + ecol);
   }
   int pf_gx = reflect_idx(tx0 - HALO + (tid < RWD ? tid : 0), W);   // column of the band row this thread fetches
   pf_gx = pf_gx < 0 ? 0 : (pf_gx >= W ? W - 1 : pf_gx);
@@ -1138,9 +1139,9 @@ __global__ __launch_bounds__(256 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))
         // whole row's scale -- a relative 1e-7 off, which the KL part of the gradient sees as 1e-4 of itself)
         rs[j] += (double)ev;
         asm volatile("" : "+v"(rs[j]));   // (or the additions sink to the end of the row, with every e kept for them)
-        // (a wave-uniform base per offset + a 32-bit lane offset: `global_store_dword v, v, s[..]`, no 64-bit address
-        // arithmetic per store)
-        if (!SSG_DBG(p, 1)) *(float *)((char *)(tmbase + (size_t)(qyi * KS + qxi) * TM_PX) + coff[j]) = ev;
+        // (a wave-uniform base per offset + a 32-bit element offset per lane: one v_lshl_add_u64 per store instead of a
+        // 64-bit add pair)
+        if (!SSG_DBG(p, 1)) (tmbase + (size_t)(qyi * KS + qxi) * TM_PX)[coff[j]] = ev;
       }
     };
     lds_barrier();                                   // (offset 0's H rows are in LDS)

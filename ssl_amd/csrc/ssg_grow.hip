@@ -365,7 +365,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
   const float *pb = p.tm[1] + (size_t)tslot * P * TM_PX + (size_t)qx0 * TM_PX + ck * 64 + lane;
   // ring position of offset q of this lane's pixel: (q + rot) & 127 -- rot = the 16-byte phase of the pixel's row in the
   // tensor, so that a 4-float group aligned in the tensor is aligned (and unbroken by the wrap) in the ring
-  const int rot_a = (goff_a + (r > 0 ? r : 0) * (P & 3)) & 3, rot_b = (goff_b + (r > 0 ? r : 0) * (P & 3)) & 3;
+  const int rot_a = (int)(((unsigned)goff_a + (unsigned)(r > 0 ? r : 0) * (unsigned)(P & 3)) & 3u);
+  const int rot_b = (int)(((unsigned)goff_b + (unsigned)(r > 0 ? r : 0) * (unsigned)(P & 3)) & 3u);
   float *ring_a = stage + lane * PITCH, *ring_b = ring_a + CPX * PITCH;
   float l1 = 0.f, d1 = 0.f, d2 = 0.f, bs = 0.f, bg = 0.f, m1 = 0.f, m2 = 0.f;
   double kld = 0.0;
@@ -383,8 +384,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
   // the store phase's identity: eight lanes per pixel, each a 16-byte quarter of two consecutive 64-byte segments
   const int spx = threadIdx.x >> 3, sj = threadIdx.x & 7;
   const int srow = prow[spx];
-  const int sbase_a = goff_a + (srow > 0 ? srow : 0) * P, sbase_b = goff_b + (srow > 0 ? srow : 0) * P;   // row start, in floats from the aligned pointer
-  int kc_a = sbase_a / SEG, kc_b = sbase_b / SEG;                  // next segment to write
+  // the pixel's row in each tensor, taken from its own 64-byte boundary: `sbase` = floats between that boundary and the row's
+  // first element (0..15), `rowp` = the boundary; everything below is 32-bit arithmetic relative to it (round 5 fix: row
+  // index x k_s^2 as a 32-bit product overflowed from 894 k rows on -- four dense 512 x 512 images)
+  const size_t srow0 = (size_t)(srow > 0 ? srow : 0) * P;
+  const int sbase_a = (int)((srow0 + goff_a) & (SEG - 1)), sbase_b = (int)((srow0 + goff_b) & (SEG - 1));
+  float *const rowp_a = out_a + (srow0 + goff_a - sbase_a), *const rowp_b = out_b + (srow0 + goff_b - sbase_b);
+  int kc_a = 0, kc_b = 0;                                          // next segment of the row to write
   const float *sring_a = stage + spx * PITCH, *sring_b = sring_a + CPX * PITCH;
 #pragma unroll 1
   for (int it = 0; it < NIT; ++it) {
@@ -449,7 +455,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
         const int sbase = img ? sbase_b : sbase_a;
         int &kc = img ? kc_b : kc_a;
         const float *sring = img ? sring_b : sring_a;
-        float *outp = img ? out_b : out_a;
+        float *outp = img ? rowp_b : rowp_a;
         // complete segments: below the first float not yet in the ring; the row's last hand-over takes its partial tail
         const int kend = qa == P ? (sbase + P + SEG - 1) / SEG : (sbase + qa) / SEG;
         if (srow >= 0) {

@@ -1364,6 +1364,34 @@ def test_tile_major_materialising_step_with_unaligned_ssg_tensors(dev):
         assert bool((buf_a[1 + n * P:] == -7.0).all()) and bool((buf_b[3 + n * P:] == -7.0).all())
 
 
+def test_k49_materialising_batch_beyond_2_31_row_elements(dev):
+    """Four dense 512 x 512 images in one k_s = 49 call: 1,048,576 rows x 2,401 floats -- row index x k_s^2 exceeds 2^31
+    from row 894,785 on (round 5 found a 32-bit product in ssg_rows_tm_mat's store addressing).  The rows of the last
+    image must equal, bit for bit, the rows the same image gets in a call of its own; guard words behind the tensors stay."""
+    from ssl_amd import engine, synth
+    free, _ = torch.cuda.mem_get_info()
+    if free < 70e9:
+        pytest.skip("needs ~55 GB of device memory")
+    B, H, W, ks, kw, sigma = 4, 512, 512, 49, 13, 1.0
+    gt_np = np.stack([synth.natural_like(300 + i, H, W) for i in range(B)])
+    sr_np = np.stack([synth.degrade(gt_np[i], 7 + i) for i in range(B)])
+    mask = torch.ones((B, 1, H, W), device=dev)
+    step = engine.LossStep(B, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, capacity=B * H * W)
+    step.ssg_sr.fill_(-3.0)
+    step(T(sr_np, dev), T(gt_np, dev), mask)
+    n = int(step.counts[0])
+    assert n == B * H * W and bool(torch.isfinite(step.loss).all())
+    one = engine.LossStep(1, 3, H, W, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev, capacity=H * W)
+    one(T(sr_np[3:], dev), T(gt_np[3:], dev), mask[:1])
+    rows = torch.as_tensor(np.r_[0, 1, 511, 512, 108640, 108641, 108642, 200000, 262142, 262143], device=dev)   # 894,785 = 3 * 262,144 + 108,353
+    assert torch.equal(step.ssg_sr[3 * H * W + rows], one.ssg_sr[rows]) and torch.equal(step.ssg_gt[3 * H * W + rows], one.ssg_gt[rows])
+    chk = torch.arange(3 * H * W + 108000, 3 * H * W + 109000, device=dev)
+    assert torch.equal(step.ssg_sr[chk], one.ssg_sr[chk - 3 * H * W])
+    assert float(step.ssg_sr[:n].min()) >= 0.0          # every row was written (the fill value is gone)
+    del step, one
+    torch.cuda.empty_cache()
+
+
 def tile_major_ssg(step):
     """(s_sr, s_gt), each (N, k_s^2) float32 in edge-list order, of a finished fused k_s = 49 call, rebuilt from its
     workspace (ssg_loss_workspace_layout): the plan's dense-tile list gives every tile its slot, the slot holds
