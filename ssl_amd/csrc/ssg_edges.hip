@@ -736,7 +736,7 @@ __global__ __launch_bounds__(1024) void band_scan(int B, int H, int W, int nseg,
 }
 
 __global__ __launch_bounds__(256) void band_scatter(EdgeParams p, int nseg, const int *segoff, const uint8_t *bits_in,
-                                                    int *edges, int capacity, int *rank, const int *toff, const int *tcnt,
+                                                    int *edges, int capacity, int *rank, const int *toff,
                                                     const int *dflag, int *order_out, const int *n_order) {
   __shared__ int s_v[8][33];
   __shared__ unsigned short s_x[OT * BAND_COLS];   // column of every listed row of the block, by its place in the order
@@ -753,7 +753,15 @@ __global__ __launch_bounds__(256) void band_scatter(EdgeParams p, int nseg, cons
   const int t_off = listed ? toff[tile0 + sx] : 0;
   const int sx_last = seg * 32 + 31 < tx_n ? seg * 32 + 31 : tx_n - 1;
   const int blk_first = order_out ? toff[tile0 + seg * 32] : 0;
-  const int blk_end = order_out ? toff[tile0 + sx_last] + tcnt[tile0 + sx_last] : 0;   // (dense tiles: count 0)
+  // end of the block's piece of the order = the offset of the NEXT block's first order tile (tiles are numbered in block
+  // order), the whole order's length behind the last one.  (Not toff + tcnt of the block's last tile: band_scan's
+  // single-round path zeroes the counts of dense tiles in registers only, so that sum ran past the block's piece when its
+  // last tile was a dense one -- a group reaching into the next band then read s_x entries nobody had written and could
+  // be flagged mergeable on LDS garbage: its rows outside the first row's merge window came out wrong.)
+  const size_t t_next = tile0 + sx_last + 1;
+  int n_listed = order_out ? n_order[0] : 0;
+  n_listed = n_listed < capacity ? n_listed : capacity;
+  const int blk_end = !order_out ? 0 : (t_next < (size_t)p.B * ty_n * tx_n ? toff[t_next] : n_listed);
   const int c = __popc(bits);
   int incl = c;   // inclusive scan over the row's 32 lanes (a half-wave: lanes g >= o take from their own half)
 #pragma unroll
@@ -801,8 +809,7 @@ __global__ __launch_bounds__(256) void band_scatter(EdgeParams p, int nseg, cons
   // runs across two blocks stays unflagged (the single variants take it: same values) -- across band rows it could
   // only qualify in an image of <= MERGE_COLS columns.
   if (listed && valid > 0) {
-    int n = n_order[0];
-    n = n < capacity ? n : capacity;
+    const int n = n_listed;
     for (int j = 0; j < valid; ++j) {
       const int k0 = idx + j;
       if (k0 >= capacity) break;
@@ -951,7 +958,7 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
     hipLaunchKernelGGL(band_scan, dim3(1), dim3(1024), 0, st, B, H, W, nseg, segcnt, segoff, counts, capacity, bits, tcnt, toff,
                        dense_thr, plan ? dflag : nullptr, plan);
     // (the merge flags of the groups are set by the scatter pass itself: three launches)
-    hipLaunchKernelGGL(band_scatter, dim3(grid), dim3(256), 0, st, p, nseg, segoff, bits, edges, capacity, rank, toff, tcnt,
+    hipLaunchKernelGGL(band_scatter, dim3(grid), dim3(256), 0, st, p, nseg, segoff, bits, edges, capacity, rank, toff,
                        plan ? dflag : nullptr, order_out, plan ? plan : counts);
     return (int)hipGetLastError();
   }

@@ -2159,6 +2159,41 @@ def test_banded_edge_list_builder_vs_numpy(dev, B, H, W, dens, stride, cap_frac,
 
 
 @pytest.mark.gpu
+def test_banded_builder_groups_reaching_into_the_next_band_stay_unflagged(dev):
+    """A band whose LAST 8 x 8 tile belongs to a dense super-tile, followed by a group of five that starts in it and ends in
+    the next band: the group is not inside one block, so it must stay unflagged (round 5: the block's end was taken from
+    the dense tile's un-zeroed count, the group looked inside, and its flag came from LDS entries nobody had written --
+    with every listed row in the same 12 columns, as here, whatever an earlier block left there passes for mergeable, and
+    the merged forward variant then produced wrong rows for the pixels outside the first row's window: the sporadic
+    2e-5 loss deviation of the C2 loop test).  Several masks, so that some block follows a fuller one on its CU."""
+    from ssl_amd import engine
+    B, H, W = 4, 128, 256
+    thr = engine.set_dense_threshold(20)
+    try:
+        for seed in range(6):
+            rng = np.random.default_rng(900 + seed)
+            m = np.zeros((B, H, W), bool)
+            for b in range(B):
+                for band in range(H // 8):
+                    m[b, band * 8:band * 8 + 8, 96:108] = rng.random((8, 12)) < rng.uniform(0.02, 0.12)
+            m[:, :, 224:256] = rng.random((B, H, 32)) < 0.5          # the last super-tile of every band: dense
+            mk = torch.as_tensor(m[:, None].astype(np.float32), device=dev)
+            cap = B * H * W
+            el = engine.edge_list(mask=mk, capacity=cap, ks=25, order=False, plan=True)
+            ref = _plan_reference(m, cap, 20, True)
+            plan = el.plan.cpu().numpy()
+            off = engine._lib.lib().ssg_forward_plan_bytes(B, H, W, cap) // 4 - cap
+            n_sp = int(plan[0])
+            assert n_sp == len(ref["order"]) and np.array_equal(plan[off:off + n_sp] & ((1 << 30) - 1), ref["order"])
+            across = ref["flags"] & ~ref["flags_banded"]
+            got = (plan[off:off + n_sp] >> 30) & 1
+            assert across.sum() >= 3, "the masks are meant to hold groups across two bands"
+            assert np.array_equal(got, ref["flags_banded"].astype(got.dtype)), (seed, np.nonzero(got != ref["flags_banded"])[0][:8])
+    finally:
+        engine.set_dense_threshold(thr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,stride", [(2, 61, 83, 0), (1, 40, 600, 0), (2, 72, 300, 3), (1, 256, 256, 0)])
 def test_banded_builder_laplacian_mask_on_the_fly(dev, B, H, W, stride):
     """mask_kind 2 through the banded builder (the block's 'L' values staged in LDS with a reflected one-pixel frame,
