@@ -21,3 +21,26 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_allocator(request):
+    """Audit mode (SSL_AMD_TEST_POISON=int:3 | nan | f32:1e30 | int:-1 ...): before every GPU test the caching
+    allocator's free blocks are filled with the pattern, so that whatever a kernel reads without having written it is
+    that pattern instead of a previous test's (often harmless) values.  Off by default; tools/r5_poison_suite.sh runs
+    the GPU suite under several patterns."""
+    spec = os.environ.get("SSL_AMD_TEST_POISON")
+    if spec and request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            kind, _, val = spec.partition(":")
+            torch.cuda.synchronize()
+            n, blocks = 64 * 1024 * 1024, int(os.environ.get("SSL_AMD_TEST_POISON_BLOCKS", "16"))
+            if kind == "int":
+                junk = [torch.full((n,), int(val), dtype=torch.int32, device="cuda:0") for _ in range(blocks)]
+            else:
+                junk = [torch.full((n,), float("nan") if kind == "nan" else float(val), device="cuda:0") for _ in range(blocks)]
+            # small-pool blocks as well (allocations below 1 MB come from 2 MB segments of their own)
+            small = [torch.full((1 << 16,), junk[0][0].item(), dtype=junk[0].dtype, device="cuda:0") for _ in range(256)]
+            del junk, small
+    yield
