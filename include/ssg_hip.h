@@ -438,6 +438,10 @@ int ssg_prof_occupancy(int which);
 /* ssg_fwd_strip's per-workgroup clocks of its last launch: host[3 i] = start, [3 i + 1] = end (s_memtime; comparable
  * within one XCD only), [3 i + 2] = XCC id << 32 | HW_ID, for the first n / 3 (<= 1024) workgroups */
 int ssg_prof_strip_times(unsigned long long *host, int n);
+/* on != 0: every launch of the library is preceded by a kernel that fills the LDS of every CU with `pattern` (a kernel
+ * that reads an LDS word it has not written then sees the pattern, not a previous workgroup's data: audit of
+ * uninitialised LDS reads, tools/r5_poison_suite.sh).  Results stay correct.  Returns the previous switch. */
+int ssg_prof_set_lds_poison(int on, unsigned pattern);
 #endif
 
 /* Host helper for profiling builds: name of the HIP kernel a configuration

@@ -72,7 +72,8 @@ PROTOTYPES = {
     "ssg_criteria_sums": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "ssg_criteria_grad": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
 }
-PROF_PROTOTYPES = {"ssg_set_profile_mask": (_i, [_i]), "ssg_prof_occupancy": (_i, [_i])}   # libssg_hip_prof.so only
+PROF_PROTOTYPES = {"ssg_set_profile_mask": (_i, [_i]), "ssg_prof_occupancy": (_i, [_i]),
+                   "ssg_prof_set_lds_poison": (_i, [_i, ctypes.c_uint])}   # libssg_hip_prof.so only
 # C++-linkage symbols of include/similarity.h (Itanium mangling of the reference's declarations, similarity.h:2-23)
 CXX_SYMBOLS = ("_Z19_compute_similarityPKfPKiPfiiiiii", "_Z28_compute_similarity_backwardPKfS0_PKiPfiiiiii")
 

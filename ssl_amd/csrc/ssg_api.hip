@@ -129,6 +129,29 @@ static int dbg_mask() {
   return v;
 }
 namespace ssg { int strip_occupancy(); int strip_times(unsigned long long *host, int n); }
+// LDS poison (ssg_common.hpp): one workgroup per CU at a time (all 160 KB), several rounds so that every CU gets one
+static std::atomic<int> g_lds_poison_on{0};
+static std::atomic<unsigned> g_lds_poison_pat{0};
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned pat, int words) {
+  extern __shared__ unsigned s_poison[];
+  volatile unsigned *w = s_poison;
+  for (int i = threadIdx.x; i < words; i += 256) w[i] = pat;
+}
+namespace ssg {
+void prof_poison_lds(hipStream_t st) {
+  if (!g_lds_poison_on.load(std::memory_order_relaxed)) return;
+  constexpr int BYTES = 160 * 1024;
+  static std::atomic<unsigned long long> lds_set{0};
+  if (ensure_dynamic_lds(lds_poison_kernel, BYTES, lds_set)) return;
+  lds_poison_kernel<<<dim3(1024), dim3(256), BYTES, st>>>(g_lds_poison_pat.load(std::memory_order_relaxed), BYTES / 4);
+}
+}  // namespace ssg
+extern "C" int ssg_prof_set_lds_poison(int on, unsigned pattern) {
+  const int prev = g_lds_poison_on.load(std::memory_order_relaxed);
+  g_lds_poison_pat.store(pattern, std::memory_order_relaxed);
+  g_lds_poison_on.store(on ? 1 : 0, std::memory_order_relaxed);
+  return prev;
+}
 extern "C" int ssg_prof_strip_times(unsigned long long *host, int n) { return ssg::strip_times(host, n); }
 extern "C" int ssg_prof_occupancy(int which) { return which == 0 ? ssg::strip_occupancy() : -1; }
 extern "C" int ssg_set_profile_mask(int mask) {

@@ -452,3 +452,18 @@ __device__ __forceinline__ int rows_to_do(const int *n_dev, int n_host) {
 }
 
 }  // namespace ssg
+
+#ifdef SSG_PROFILE
+// Profiling build only: every launch of the library can be preceded by a kernel that fills the LDS of every CU with a
+// pattern (ssg_prof_set_lds_poison; off by default).  LDS keeps what the previous workgroup on the CU left in it, so a
+// kernel that reads a word it has not written normally sees plausible stale data and fails once in a blue moon (the merge
+// flags of band_scatter, round 5); with the poison it sees the pattern every time.  tools/r5_poison_suite.sh runs the
+// GPU suite that way.
+namespace ssg { void prof_poison_lds(hipStream_t st); }
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                         \
+  do {                                                                                                            \
+    ::ssg::prof_poison_lds(streamId);                                                                             \
+    kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                            \
+  } while (0)
+#endif

@@ -44,3 +44,21 @@ def _poisoned_allocator(request):
             small = [torch.full((1 << 16,), junk[0][0].item(), dtype=junk[0].dtype, device="cuda:0") for _ in range(256)]
             del junk, small
     yield
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _poisoned_lds():
+    """Audit mode (SSL_AMD_TEST_LDS_POISON=<hex word>): the whole session runs on the PROFILING build with its LDS poison
+    on -- every launch of the library is preceded by a kernel that fills the LDS of every CU with the word, so a kernel
+    that reads LDS it has not written sees that word every time (include/ssg_hip.h: ssg_prof_set_lds_poison)."""
+    spec = os.environ.get("SSL_AMD_TEST_LDS_POISON")
+    if not spec:
+        yield
+        return
+    from ssl_amd import _lib
+    with _lib.profile_build() as L:
+        L.ssg_prof_set_lds_poison(1, int(spec, 16))
+        try:
+            yield
+        finally:
+            L.ssg_prof_set_lds_poison(0, 0)

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     declared -= {"ssg_stream_t"}
     assert len(declared) >= 18
     # (the declarations inside `#ifdef SSG_PROFILE` belong to the profiling build only -- next test)
-    profile_only = {"ssg_set_profile_mask", "ssg_prof_occupancy", "ssg_prof_strip_times"}
+    profile_only = {"ssg_set_profile_mask", "ssg_prof_occupancy", "ssg_prof_strip_times", "ssg_prof_set_lds_poison"}
     L = ctypes.CDLL(_lib.SO_PATH)
     for name in sorted(declared - profile_only):
         assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
