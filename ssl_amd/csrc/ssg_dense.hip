@@ -397,8 +397,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   const int n_e_stage = SSG_DBG(p, 2) ? 0 : n_e;  // profiling ablations: 2 no edge stage, 1 no stores, 64 no main loop
   const bool do_store = !SSG_DBG(p, 1);
-#pragma unroll 1
-  for (int qyi = wv; qyi < (SSG_DBG(p, 64) ? 0 : KS); qyi += NW) {
+  // Offset rows per wave: KS / NW whole rows each (q_y = wv, wv + NW, ...).  (49,13): 7 x 7.  (25,9): 4 x 6 and ONE row
+  // left over, which used to be wave 0's seventh -- 175 steps on SIMD 0 of every CU against 150 on the other three.  The
+  // left-over row (q_y = KS - 1) is SHARED instead: wave k takes the q_x steps [RUN[k], RUN[k+1]) of it, run bounds on the
+  // bounds of the store groups halved, so that every run leaves as its own stores: 157 / 156 / 156 / 156 steps per wave.
+  // A wave enters the unrolled row at its run (window filled for that step) and leaves after it; the shared row's steps
+  // are a second instantiation of the step body (SPLIT), without the software pipeline across steps.
+  constexpr int SB = (KS == 49 && !TM) ? 7 : 13;   // offsets buffered per store group (see the stores below)
+  // (the four-chunk instantiation of the TILE_HUGE tiles is at its 256 registers: it keeps the left-over row on wave 0)
+  constexpr int REM = (NCHUNK <= 2) ? KS % NW : 0;
+  static_assert(REM == 0 || (REM == 1 && NW == 4 && KS > SB && KS <= 2 * SB), "one shared row, four runs: two store groups halved");
+  constexpr int RUN1 = (SB + 1) / 2, RUN3 = SB + (KS - SB) / 2;   // runs [0, RUN1) [RUN1, SB) [SB, RUN3) [RUN3, KS)
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const int run_lo = wvu == 0 ? 0 : wvu == 1 ? RUN1 : wvu == 2 ? SB : RUN3;
+  const int run_hi = wvu == 0 ? RUN1 : wvu == 1 ? SB : wvu == 2 ? RUN3 : KS;
+  auto do_row = [&](const int qyi, auto shared_c) {
+    constexpr bool shared_row = decltype(shared_c)::value;
     // D[n,q] = sum_{k in K(q)} E_q[x+k] + sum_{k not in K(q)} |I[x+k]|^2 with K(q) = rows [ylo,yhi] x columns
     // [xlo,xhi] of the window.  Rows: wave-uniform 0/1 weights.  Columns: the lane adds the |I|^2 of the
     // columns that left (compile-time set) to its horizontal sums, so H' rows carry E inside and |I|^2 outside
@@ -425,19 +439,35 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     const float *rq = reg + (r + qyi) * RS + L * g;  // + c*RH*RS + column (i + qxi)
     f2 w[C][HL];  // slots (t, t + L/2)
+    // the window as step S finds it: slot a holds pixel (a - S) mod L of the lane, i.e. region column (a - S) mod L + S
+    auto fill_window = [&](auto sc) {
+      constexpr int S0 = decltype(sc)::value;
 #pragma unroll
-    for (int c = 0; c < C; ++c)
+      for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int t = 0; t < HL; ++t) w[c][t] = f2{rq[c * RH * RS + t], rq[c * RH * RS + t + HL]};
+        for (int a = 0; a < L; ++a) {
+          const float v = rq[c * RH * RS + ((a - S0) % L + L) % L + S0];
+          if (a < HL) w[c][a].x = v;
+          else w[c][a - HL].y = v;
+        }
+    };
+    if constexpr (!shared_row) {
+      fill_window(std::integral_constant<int, 0>{});
+    } else {
+      if (run_lo == 0) fill_window(std::integral_constant<int, 0>{});
+      else if (run_lo == RUN1) fill_window(std::integral_constant<int, RUN1>{});
+      else if (run_lo == SB) fill_window(std::integral_constant<int, SB>{});
+      else fill_window(std::integral_constant<int, RUN3>{});
+    }
     // consecutive offsets per edge pixel buffered in registers and stored together; the (49,13) row-major variant (the
     // fallback of tile-major calls: masks under 60 % tile fill) keeps 7 (seven groups per offset row) -- with 13 it spilled 10 values per lane, 44 B of scratch
-    constexpr int SB = (KS == 49 && !TM) ? 7 : 13;
     float evb[TM ? 1 : NCHUNK][TM ? 1 : SB];   // (tile-major rows: nothing is buffered)
     float *tmq = nullptr;                      // tile-major: this wave's offset row, + 64 ck + lane
     if constexpr (TM) tmq = p.tm[which] + ((size_t)tslot * P + (size_t)qyi * KS) * (size_t)NE_MAX + lane;
     float hvp[PIPE ? NCHUNK : 1][KW];   // pipelined edge stage: the taps gathered in the previous step
-    static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
+    auto step = [&](auto qc, auto split_c) {
       constexpr int qxi = decltype(qc)::value;
+      constexpr bool SPLIT = decltype(split_c)::value;   // a step of the shared row: one of this wave's run
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
       // E_q on the lane's L pixels, E[j] = (pixel j, pixel j + L/2); pixel i of step qxi lives in window slot
       // (i + qxi) % L -- a compile-time function of the step
@@ -605,11 +635,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           evb[ck][QE % SB] = ev;
           if (eon[ck] && do_store) {
             float *o = outp + orow[ck] + qyi * KS;
-            if constexpr (QE % SB == SB - 1 || QE == KS - 1) {
-              constexpr int cnt = QE % SB + 1, q0 = QE - (cnt - 1);
+            // the group (regular rows) or the run (shared row) that ends with this offset: first offset q0, cnt of them
+            constexpr bool ends = SPLIT ? (QE + 1 == RUN1 || QE + 1 == SB || QE + 1 == RUN3 || QE + 1 == KS)
+                                        : (QE % SB == SB - 1 || QE == KS - 1);
+            if constexpr (ends) {
+              constexpr int q0 = !SPLIT ? QE - QE % SB : (QE + 1 == RUN1 ? 0 : QE + 1 == SB ? RUN1 : QE + 1 == RUN3 ? SB : RUN3);
+              constexpr int cnt = QE + 1 - q0, i0 = q0 % SB;
 #pragma unroll
               for (int t = 0; t + 4 <= cnt; t += 4) {
-                float4 v4 = make_float4(evb[ck][t], evb[ck][t + 1], evb[ck][t + 2], evb[ck][t + 3]);
+                float4 v4 = make_float4(evb[ck][i0 + t], evb[ck][i0 + t + 1], evb[ck][i0 + t + 2], evb[ck][i0 + t + 3]);
                 if constexpr (RAW) {   // out += D: the row's own lane is the only writer of these words
                   float4 old;
                   __builtin_memcpy(&old, o + q0 + t, 16);
@@ -619,8 +653,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
               }
 #pragma unroll
               for (int t = cnt & ~3; t < cnt; ++t) {
-                if constexpr (RAW) o[q0 + t] += evb[ck][t];
-                else o[q0 + t] = evb[ck][t];
+                if constexpr (RAW) o[q0 + t] += evb[ck][i0 + t];
+                else o[q0 + t] = evb[ck][i0 + t];
               }
             }
           }
@@ -629,7 +663,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int ck = 0; ck < NCHUNK; ++ck) {
         if (ck * 64 < n_e_stage) {
-          if constexpr (PIPE) {
+          if constexpr (PIPE && !SPLIT) {
             // consume the taps gathered a step ago (offset qxi - 1), then gather this step's behind its H stores
             if constexpr (qxi > 0) edge_emit(std::integral_constant<int, qxi - 1>{}, ck, tap_sum<KW>(hvp[ck], wgt, av[ck]));
             edge_gather(ck, hvp[ck]);
@@ -643,7 +677,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           }
         }
       }
-    });
+    };
+    if constexpr (!shared_row) {
+      static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) { step(qc, std::false_type{}); });
+    } else {
+      static_for(std::make_integer_sequence<int, KS>{}, [&](auto qc) {
+        constexpr int qxi = decltype(qc)::value;
+        if (qxi >= run_lo && qxi < run_hi) step(qc, std::true_type{});   // (wave-uniform: scalar branches)
+      });
+    }
+  };
+  if (!SSG_DBG(p, 64)) {
+#pragma unroll 1
+    for (int qyi = wv; qyi < KS - REM; qyi += NW) do_row(qyi, std::false_type{});
+    if constexpr (REM > 0) do_row(KS - 1, std::true_type{});
   }
 
   // ---- row sums over the four waves, then rescale the rows this workgroup wrote ----
