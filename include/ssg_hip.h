@@ -57,9 +57,9 @@ typedef void *ssg_stream_t; /* hipStream_t */
 
 /* 4 (round 4): + ssg_device_status, ssg_criteria_sums / _grad / _scratch_bytes, SSG_E_ALIGN, SSG_E_PLAN; a fused step
  * whose edge count exceeds its capacity returns NaN losses; a plan of the wrong tile height no longer traps. */
-/* 5 (round 5): + ssg_set_overlap; the product library no longer reads ANY environment variable (SSG_DENSE_THR,
- * SSG_OVERLAP, SSG_OP_PLAN_FROM ... are honoured by the profiling build only); the one-wave tile-major dense backward
- * is gone. */
+/* 5 (round 5): + ssg_set_overlap (modes 0-3, default 3 = per pass from the last plan's shape), ssg_last_overlap_assignment;
+ * the product library no longer reads ANY environment variable (SSG_DENSE_THR, SSG_OVERLAP, SSG_OP_PLAN_FROM ... are
+ * honoured by the profiling build only); the one-wave tile-major dense backward is gone. */
 int ssg_abi_version(void);
 const char *ssg_status_string(int status);
 /* Device-side refusals that no return value can carry (everything is asynchronous): waits for `stream`, then returns
@@ -161,13 +161,18 @@ size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
  * reference has one code path. */
 int ssg_set_dense_threshold(int edge_pixels_per_tile);
 /* Stream assignment of the two kernels of a pass for k_s <= 25 (a library-owned side stream, event fork / join on the
- * caller's stream; capturable).  0: every launch on the caller's stream (per-kernel profiling).  1 (default): the
- * dense-tile kernel on the caller's stream, the direct kernel beside it on the side stream -- for masks whose dense
- * tiles carry most rows (Laplacian edge masks).  2: the other way round -- for masks without dense tiles (Bernoulli,
- * thin strided masks: the whole critical path on one stream; Bernoulli 1 % -15 %, C2 +3 %).  Same results in every
- * mode (the two kernels work on disjoint rows).  Process-wide; returns the previous setting.  No reference counterpart
- * (the reference launches on the legacy stream, similarity.cu:69,147). */
+ * caller's stream; capturable).  0: every launch on the caller's stream (per-kernel profiling).  1: the dense-tile
+ * kernel on the caller's stream, the direct kernel beside it on the side stream -- for masks whose dense tiles carry
+ * most rows (Laplacian edge masks).  2: the other way round -- for masks without dense tiles (Bernoulli, thin strided
+ * masks: the whole critical path on one stream; Bernoulli 1 % -15 %, C2 +3 %).  3 (default): 1 or 2 per pass, by the
+ * shape of the last plan ssg_edge_list / the fused step built on the device -- its scan kernel leaves {rows for the
+ * direct kernels, dense tiles} in host-mapped memory, the host reads it at the next pass without synchronising; the
+ * branch expected to take longer (38 ns per direct row against 0.74 us per dense tile) stays on the caller's stream.
+ * Same results in every mode (the two kernels work on disjoint rows).  Process-wide; returns the previous setting.  No
+ * reference counterpart (the reference launches on the legacy stream, similarity.cu:69,147). */
 int ssg_set_overlap(int mode);
+/* Diagnostics: the assignment the calling thread's last forked pass used (0 not forked, 1, 2 as above). */
+int ssg_last_overlap_assignment(void);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int H, int W, int mask_stride, float lap_threshold,
                   int plan_ks /* k_s the fwd_plan is built for (tile rows: 8, or 4 for k_s = 49); 0 = 25.

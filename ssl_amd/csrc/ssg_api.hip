@@ -175,23 +175,70 @@ struct SideStream {
   hipEvent_t forked = nullptr, joined = nullptr;
 };
 static std::atomic<int> g_overlap{-1};
-static int overlap_mode() {   // 0 off, 1 dense-tile kernel on the caller's stream (default), 2 direct kernel on the caller's stream
+// 0 off, 1 dense-tile kernel on the caller's stream, 2 direct kernel on the caller's stream, 3 (default) whichever of the
+// two the previous plan built on this device makes the longer branch
+static int overlap_mode() {
   int v = g_overlap.load(std::memory_order_relaxed);
   if (v < 0) {
-    v = env_int("SSG_OVERLAP", 1);
-    v = v < 0 ? 0 : (v > 2 ? 2 : v);
+    v = env_int("SSG_OVERLAP", 3);
+    v = v < 0 ? 0 : (v > 3 ? 3 : v);
     g_overlap.store(v, std::memory_order_relaxed);
   }
   return v;
 }
 static bool overlap_enabled() { return overlap_mode() != 0; }
-// the two streams of a forked pass: .first takes the dense-tile kernel, .second the direct one
+
+// What the last plan built on a device looked like: {rows left to the direct kernels, dense tiles}, written by the
+// edge-list builder's scan kernel with a plain store into host-mapped pinned memory (one 64-byte block per device,
+// allocated at the first build, never freed; a posted PCIe write, no stream operation) and read by the HOST at the next
+// forked pass -- no synchronisation: whatever has landed is a hint, and both stream assignments give the same results.
+struct PlanHint {
+  int *host = nullptr, *dev = nullptr;
+};
+static PlanHint plan_hint() {
+  constexpr int MAXDEV = 64;
+  static std::mutex mu;
+  static PlanHint tab[MAXDEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return PlanHint{};
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tab[dev].host) {
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return PlanHint{};
+    ((int *)h)[0] = ((int *)h)[1] = -1;   // nothing seen yet
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipHostFree(h);
+      return PlanHint{};
+    }
+    tab[dev] = PlanHint{(int *)h, (int *)d};
+  }
+  return tab[dev];
+}
+namespace ssg {
+int *plan_hint_device_word() { return overlap_mode() == 3 ? plan_hint().dev : nullptr; }
+}
+// the two streams of a forked pass: .dense takes the dense-tile kernel, .direct the direct one
 struct StreamPair {
   hipStream_t dense, direct;
 };
+static thread_local int t_last_assignment = 0;
 static StreamPair assign_streams(hipStream_t st, hipStream_t st2) {
-  return overlap_mode() == 2 ? StreamPair{st2, st} : StreamPair{st, st2};
+  int mode = overlap_mode();
+  if (mode == 3) {
+    // whole-chip costs at (25,9), MI355X: a dense tile 0.74 us through forward + backward, a direct row 38 ns
+    mode = 1;
+    const PlanHint h = plan_hint();
+    if (h.host) {
+      const int n_sparse = ((volatile int *)h.host)[0], n_tiles = ((volatile int *)h.host)[1];
+      if (n_sparse >= 0 && n_tiles >= 0 && (long long)n_sparse * 38 > (long long)n_tiles * 740) mode = 2;
+    }
+  }
+  t_last_assignment = st2 == st ? 0 : mode;
+  return mode == 2 ? StreamPair{st2, st} : StreamPair{st, st2};
 }
+// (diagnostics: the assignment the calling thread's last forked pass used -- 0 none, 1 dense-tile kernel on the caller's
+// stream, 2 direct kernel on the caller's stream)
+extern "C" int ssg_last_overlap_assignment(void) { return t_last_assignment; }
 // ssg_set_overlap(0): every launch on the caller's stream (per-kernel rocprofv3 durations: profiles/*_kernel_stats.csv
 // are taken that way; same results -- the two branches work on disjoint rows).  1 (default): the dense-tile kernel on
 // the caller's stream, the direct one on the side stream -- right where dense tiles carry most rows (Laplacian masks:
@@ -199,10 +246,12 @@ static StreamPair assign_streams(hipStream_t st, hipStream_t st2) {
 // critical path then sits on one stream and whose join finds the side stream's empty launches finished.  Measured on one
 // box (profiles/r5_ab_stream_assignment.txt): mode 2 against 1: Bernoulli 1 % 0.213 -> 0.182 ms, 4 % 0.491 -> 0.466,
 // C4 0.498 -> 0.508, C2 1.275 -> 1.317 (the fork's latency lands on whichever kernel runs on the side stream).
+// 3 (default since round 5): 1 or 2 per pass, from the shape of the last plan built on the device (PlanHint above): the
+// branch expected to run longer stays on the caller's stream.  Steady streams of similar masks settle after one call.
 // Returns the previous setting.
 extern "C" int ssg_set_overlap(int mode) {
   const int prev = overlap_mode();
-  g_overlap.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
+  g_overlap.store(mode < 0 ? 0 : (mode > 3 ? 3 : mode), std::memory_order_relaxed);
   return prev;
 }
 static SideStream *side_stream() {

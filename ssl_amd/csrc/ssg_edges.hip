@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void band_count(EdgeParams p, int nseg, int *s
 
 __global__ __launch_bounds__(1024) void band_scan(int B, int H, int W, int nseg, const int *segcnt, int *segoff, int *counts,
                                                   int capacity, const uint8_t *bits, int *tcnt, int *toff, int thr,
-                                                  int *dflag, int *plan) {
+                                                  int *dflag, int *plan, int *hint) {
   __shared__ int wtot[16], wincl[16];
   __shared__ int s_heavy, s_light;
   const int tid = threadIdx.x;
@@ -673,6 +673,10 @@ __global__ __launch_bounds__(1024) void band_scan(int B, int H, int W, int nseg,
         plan[1] = s_heavy;
         plan[2] = OT;
         plan[3] = s_light;
+        if (hint) {   // (host-mapped: what the next forked pass on this device assigns its streams by, ssg_api.hip)
+          hint[0] = n_sparse;
+          hint[1] = s_heavy + s_light;
+        }
       }
       return;
     }
@@ -732,6 +736,10 @@ __global__ __launch_bounds__(1024) void band_scan(int B, int H, int W, int nseg,
     plan[1] = s_heavy;
     plan[2] = OT;
     plan[3] = s_light;
+    if (hint) {
+      hint[0] = n_sparse;
+      hint[1] = s_heavy + s_light;
+    }
   }
 }
 
@@ -911,6 +919,8 @@ size_t edge_scratch_bytes(int B, int H, int W) {
   return chunked > banded ? chunked : banded;
 }
 
+int *plan_hint_device_word();   // ssg_api.hip: host-mapped {rows for the direct kernels, dense tiles} of the device's last plan
+
 static bool banded_enabled() {
   static const bool on = env_int("SSG_EDGE_BANDED", 1) != 0;   // (profiling build only: the chunked builder for every call)
   return on;
@@ -956,7 +966,7 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
     int *order_out = plan ? plan + fwd_plan_order_offset(B, H, W) : order;
     hipLaunchKernelGGL(band_count, dim3(grid), dim3(256), 0, st, p, nseg, segcnt, tcnt, bits, z);
     hipLaunchKernelGGL(band_scan, dim3(1), dim3(1024), 0, st, B, H, W, nseg, segcnt, segoff, counts, capacity, bits, tcnt, toff,
-                       dense_thr, plan ? dflag : nullptr, plan);
+                       dense_thr, plan ? dflag : nullptr, plan, plan ? plan_hint_device_word() : nullptr);
     // (the merge flags of the groups are set by the scatter pass itself: three launches)
     hipLaunchKernelGGL(band_scatter, dim3(grid), dim3(256), 0, st, p, nseg, segoff, bits, edges, capacity, rank, toff,
                        plan ? dflag : nullptr, order_out, plan ? plan : counts);

@@ -133,9 +133,10 @@ def edge_list(mask=None, gt=None, mask_stride=0, lap_threshold=20.0, capacity=No
 
 def set_overlap(mode):
     """Stream assignment of the dense-tile and the direct kernel of a pass (k_s <= 25): False / 0 = every launch on the
-    caller's stream (per-kernel profiling); True / 1 (default) = dense kernel on the caller's stream, direct kernel on
-    the side stream (masks with dense tiles: Laplacian edges); 2 = the other way round (masks without dense tiles:
-    Bernoulli / thin strided masks, -15 % at 1 % density; +3 % at C2).  Same results.  Returns the previous mode."""
+    caller's stream (per-kernel profiling); True / 1 = dense kernel on the caller's stream, direct kernel on the side
+    stream (masks with dense tiles: Laplacian edges); 2 = the other way round (masks without dense tiles: Bernoulli /
+    thin strided masks, -15 % at 1 % density; +3 % at C2); 3 (default) = 1 or 2 per pass, from the shape of the last
+    plan built on the device (include/ssg_hip.h).  Same results.  Returns the previous mode."""
     return _lib.lib().ssg_set_overlap(int(mode))
 
 

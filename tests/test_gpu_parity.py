@@ -784,7 +784,7 @@ def test_every_tile_through_the_dense_kernels_and_no_side_stream(dev):
                                               step.ssg_gt[:n].cpu().numpy())
             assert maxerr(grad.cpu(), gref) <= grad_tol_from_oracle(sr, gt, mask, ks, kw, sigma, ref)
             engine.set_dense_threshold(prev_thr)
-            for mode in (1, 2):      # dense kernel on the caller's stream / on the side stream (ssg_set_overlap)
+            for mode in (1, 2, 3):   # dense kernel on the caller's stream / on the side stream / by the last plan (ssg_set_overlap)
                 engine.set_overlap(mode)
                 step2 = engine.LossStep(2, 3, 72, 100, ks, kw, sigma, 1e-10, True, 1e3, 1e3, device=dev)
                 loss2, grad2 = step2(T(sr, dev), T(gt, dev), T(mask[:, None].astype(np.float32), dev))
@@ -796,6 +796,36 @@ def test_every_tile_through_the_dense_kernels_and_no_side_stream(dev):
     finally:
         engine.set_dense_threshold(prev_thr)
         engine.set_overlap(prev_ov)
+
+
+def test_stream_assignment_follows_the_last_plan(dev):
+    """ssg_set_overlap(3), the default: the edge-list builder leaves {rows for the direct kernels, dense tiles} of its
+    plan in host-mapped memory and the next forked pass keeps the branch expected to run longer on the caller's stream
+    (include/ssg_hip.h).  A Bernoulli 1 % mask has no dense tile -> assignment 2 from the second step on; Laplacian edge
+    masks put most rows into dense tiles -> assignment 1.  Same losses and gradient as with the assignment forced."""
+    from ssl_amd import engine, synth
+    L = engine._lib.lib()
+    B, H, W = 4, 128, 128
+    sr_np, gt_np, mask_np = synth.make_batch(B, H, W, seed0=2100)
+    rng = np.random.default_rng(5)
+    bern = (rng.random((B, 1, H, W)) < 0.01).astype(np.float32)
+    prev = engine.set_overlap(3)
+    try:
+        assert prev == 3, "mode 3 is the default"
+        for mask, want in ((bern, 2), (mask_np[:, :1], 1), (bern, 2)):
+            step = engine.LossStep(B, 3, H, W, 25, 9, 0.004, 1e-10, True, 1e3, 1e3, device=dev)
+            for _ in range(3):
+                loss, grad = step(T(sr_np, dev), T(gt_np, dev), T(mask, dev))
+                torch.cuda.synchronize()          # (the builder's hint has landed before the next call reads it)
+            assert L.ssg_last_overlap_assignment() == want
+            engine.set_overlap(3 - want)          # the other assignment, forced
+            step2 = engine.LossStep(B, 3, H, W, 25, 9, 0.004, 1e-10, True, 1e3, 1e3, device=dev)
+            loss2, grad2 = step2(T(sr_np, dev), T(gt_np, dev), T(mask, dev))
+            assert L.ssg_last_overlap_assignment() == 3 - want
+            assert torch.equal(loss, loss2) and torch.equal(grad, grad2)      # (deterministic accumulation: bit for bit)
+            engine.set_overlap(3)
+    finally:
+        engine.set_overlap(prev)
 
 
 # ------------------------------------------------------------------ round 2
