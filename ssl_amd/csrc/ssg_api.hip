@@ -172,7 +172,7 @@ static constexpr int dbg_mask() { return 0; }
 // 9.15 -> 9.64 ms -- so the fork is taken for k_s <= 25 only.
 struct SideStream {
   hipStream_t side = nullptr;
-  hipEvent_t forked = nullptr, joined = nullptr;
+  hipEvent_t forked = nullptr, joined = nullptr, gate = nullptr;
 };
 static std::atomic<int> g_overlap{-1};
 // 0 off, 1 dense-tile kernel on the caller's stream, 2 direct kernel on the caller's stream, 3 (default) whichever of the
@@ -187,6 +187,16 @@ static int overlap_mode() {
   return v;
 }
 static bool overlap_enabled() { return overlap_mode() != 0; }
+// Two-chain step (ForkChain below) or fork / join around forward and backward each?  Free-running chains pay when the
+// direct chain carries the step (Bernoulli 4 %: 0.485 -> 0.463 ms) or the dense kernels are too few workgroups to keep
+// the chip to themselves (C4, 330 tiles: 0.50 -> 0.466).  Where long dense kernels dominate (C2: 1,287 tiles, direct
+// 0.38 ms of kernel time against 0.95) the direct kernels spend themselves beside the dense FORWARD, the dense backward
+// runs alone with its tail unfilled, and the step is 8 % slower (holding the direct backward with a one-way event until
+// the dense backward starts: still +1.3 %; a low-priority side stream: no effect).  Decided per call from the last plan's
+// shape (PlanHint: the numbers the stream assignment uses), unknown = no.
+// (profiling build: SSG_TWO_CHAINS=0 always gated, 2 always free-running, -1 no chains: fork / join around each pass)
+static bool two_chains_wanted();
+static bool two_chains_allowed();
 
 // What the last plan built on a device looked like: {rows left to the direct kernels, dense tiles}, written by the
 // edge-list builder's scan kernel with a plain store into host-mapped pinned memory (one 64-byte block per device,
@@ -236,6 +246,22 @@ static StreamPair assign_streams(hipStream_t st, hipStream_t st2) {
   t_last_assignment = st2 == st ? 0 : mode;
   return mode == 2 ? StreamPair{st2, st} : StreamPair{st, st2};
 }
+static bool two_chains_allowed() {   // (profiling build: SSG_TWO_CHAINS=-1 restores fork / join around forward and backward each)
+  static const bool on = env_int("SSG_TWO_CHAINS", 1) >= 0;
+  return on;
+}
+static bool two_chains_wanted() {    // free-running (true) or gated (false)
+  static const int sw = env_int("SSG_TWO_CHAINS", 1);
+  if (sw != 1) return sw == 2;
+  if (overlap_mode() != 3) return false;
+  const PlanHint h = plan_hint();
+  if (!h.host) return false;
+  const int n_sparse = ((volatile int *)h.host)[0], n_tiles = ((volatile int *)h.host)[1];
+  if (n_sparse < 0 || n_tiles < 0) return false;
+  // the direct chain carries the step, or the dense kernels' grids (two images per tile) are at most two resident rounds
+  // of 512 workgroups: too short to keep the chip to themselves anyway
+  return (long long)n_sparse * 38 > (long long)n_tiles * 740 || n_tiles <= 512;
+}
 // (diagnostics: the assignment the calling thread's last forked pass used -- 0 none, 1 dense-tile kernel on the caller's
 // stream, 2 direct kernel on the caller's stream)
 extern "C" int ssg_last_overlap_assignment(void) { return t_last_assignment; }
@@ -263,7 +289,8 @@ static SideStream *side_stream() {
   if (!s.side) {
     if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s.forked, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.joined, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s.joined, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.gate, hipEventDisableTiming) != hipSuccess) {
       s.side = nullptr;
       return nullptr;
     }
@@ -286,6 +313,24 @@ static int join_to(hipStream_t st, SideStream *s) {
   if (!rc) rc = (int)hipStreamWaitEvent(st, s->joined, 0);
   return rc;
 }
+// Two-chain step (the fused entry points at k_s <= 25, round 5): the forward's fork is NOT joined before the backward.
+// The dense-tile chain (forward, its rows' ssg_grad_rows pass, backward) and the direct chain (the same three for the
+// rows of the plan's sparse list) share nothing until the end: the row passes are per class anyway (split_backward), the
+// fixed-point scale of the deterministic accumulation comes from the a-priori bound of |G| (no maximum over all rows
+// to wait for), integer sums do not care who adds first, the criteria sums go to separate slots.  One join, then flush
+// and finalize.  Same bits as the joined schedule -- only the streams differ.  Against fork / join around forward and
+// backward each: one cross-stream round trip less, and the memory-bound row pass of one chain runs beside the VALU-bound
+// kernels of the other.
+// `gated`: the direct chain's backward is held (a one-way event: the dense chain never waits) until the dense chain's
+// row pass is through -- the schedule for steps whose long dense kernels dominate (two_chains_wanted() says no): the
+// direct backward then runs beside the dense backward and fills its tail instead of spending itself beside the dense
+// forward.  The loss finalize rides on the direct chain's stream behind the gate, off the critical path.
+struct ForkChain {
+  SideStream *fk = nullptr;
+  StreamPair sp{nullptr, nullptr};
+  bool active = false;   // forked by the forward, to be joined by the backward
+  bool gated = false;
+};
 
 // One 4-byte status word per device, owned by the library (allocated at the first call that can set it, never freed):
 // kernels that refuse their input without a host-visible error -- a dense kernel handed a plan cut for another tile
@@ -368,8 +413,14 @@ static int split_tm_tiles(const BwdParams &p, const TileMajor *tm) {
   return tm->slots < mt ? tm->slots : mt;
 }
 
+// per-class row passes (split_backward): the criteria sums then take two sets of grow_grid(n_rows) slots
+static bool split_row_classes(const BwdParams &p, int n_tm) {
+  return p.mode == GRAD_LOSS && n_tm == 0 && p.row_scale && p.ks <= 25;
+}
+
 static int split_backward(BwdParams p, const int *rank, const int *plan, void *scratch, hipStream_t st,
-                          const FinalizeArgs *fin = nullptr, bool *fin_done = nullptr, const TileMajor *tm = nullptr) {
+                          const FinalizeArgs *fin = nullptr, bool *fin_done = nullptr, const TileMajor *tm = nullptr,
+                          ForkChain *chain = nullptr) {
   float *G = (float *)scratch;
   const size_t nfl = align_up(sizeof(float) * (size_t)(p.n_host > 0 ? p.n_host : 1), 256);
   float *sum_b = (float *)((char *)scratch + align_up(sizeof(float) * (size_t)p.n_host * p.ks * p.ks, 256));
@@ -401,7 +452,44 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
     g.tm_slots = tm->slots;
     g.sparse_order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
   }
-  int rc = (dbg_mask() & (1 << 29)) ? 0 : launch_grad_rows(g, p.ks, p.kw, st);
+  // GRAD_LOSS without tile-major rows (every k_s <= 25 call): the fixed-point scale comes from the a-priori bound of |G|
+  // (ssg_grad_rows' first workgroup writes it: no maximum over the rows, no reduction launch); and with deferred row
+  // scales the rows are passed over PER CLASS -- the dense-tile kernels' rows (non-zero scale), then the plan's sparse
+  // list -- whatever the schedule, so that the criteria sums are grouped the same way on one stream and on two.
+  const size_t n_fix = (size_t)p.B * p.C * p.H * p.W;
+  const bool apriori = p.gfix && p.mode == GRAD_LOSS && n_tm == 0;
+  const bool classes = split_row_classes(p, n_tm);
+  const bool chained = chain && chain->active;
+  hipStream_t sd = chained ? chain->sp.dense : st, ss = chained ? chain->sp.direct : st;
+  auto leave = [&](int rc0) {   // (a forward that left its streams forked is joined on every way out)
+    if (!chained) return rc0;
+    const int rcj = join_to(st, chain->fk);
+    chain->active = false;
+    return rc0 ? rc0 : rcj;
+  };
+  if (chained && !(classes && p.grad)) return leave(SSG_E_BADARG);
+  if (apriori) {
+    g.gmax_part = nullptr;
+    g.fix_word = (unsigned *)(p.gfix + n_fix);
+  }
+  int rc = 0;
+  if (dbg_mask() & (1 << 29)) {
+  } else if (classes) {
+    const unsigned gg = grow_grid(p.n_host);
+    GrowParams gd = g;   // the dense-tile rows
+    gd.only = 1;
+    rc = launch_grad_rows(gd, p.ks, p.kw, sd);
+    GrowParams gs = g;   // the plan's sparse list; its criteria sums behind the first pass's
+    gs.only = 2;
+    gs.grid_cap = 4096;
+    gs.tm_hdr = plan + 1;
+    gs.tm_slots = 0;
+    gs.sparse_order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
+    gs.partials = p.partials + 2 * (size_t)gg;
+    if (!rc) rc = launch_grad_rows(gs, p.ks, p.kw, ss);
+  } else {
+    rc = launch_grad_rows(g, p.ks, p.kw, st);
+  }
   if (!rc && n_tm > 0) {   // the rows of the tile-major tiles (ssg_grad_rows skipped them: negative row scale)
     TmRowsParams t{};
     t.tm[0] = tm->rows[0];
@@ -432,10 +520,10 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
     }
     rc = (dbg_mask() & (1 << 29)) ? 0 : launch_rows_tm(t, p.ks, p.kw, st);
   }
-  if (rc || !p.grad) return rc;
-  if (p.gfix) {
-    rc = launch_grad_fix_reduce(gmax_part, (int)grow_grid(p.n_host) + rows_tm_parts(n_tm), p.gfix, (size_t)p.B * p.C * p.H * p.W, st);
-    if (rc) return rc;
+  if (rc || !p.grad) return leave(rc);
+  if (p.gfix && !apriori) {
+    rc = launch_grad_fix_reduce(gmax_part, (int)grow_grid(p.n_host) + rows_tm_parts(n_tm), p.gfix, n_fix, st);
+    if (rc) return leave(rc);
   }
   const float *grows = p.mode == GRAD_D ? p.gin : G;
   DenseBwdParams d{};
@@ -466,6 +554,29 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
     d.w_l1 = p.w_l1;
     d.w_kl = p.w_kl;
     d.upstream = p.upstream;
+  }
+  if (chained) {   // two-chain step: each backward kernel behind its own chain's row pass; then the one join
+    if (chain->gated && sd == st && ss != st) {
+      rc = (int)hipEventRecord(chain->fk->gate, sd);
+      if (!rc) rc = (int)hipStreamWaitEvent(ss, chain->fk->gate, 0);
+      if (!rc && fin) {   // (both passes' criteria sums are complete behind the gate)
+        rc = launch_loss_finalize(fin->partials, fin->nparts, fin->n_dev, fin->n_host, fin->P, fin->w_l1, fin->w_kl,
+                                  fin->loss_out, fin->nan_on_overflow, ss);
+        if (!rc && fin_done) *fin_done = true;
+      }
+      if (rc) return leave(rc);
+    }
+    rc = launch_bwd_dense(d, p.ks, p.kw, p.C, sd);
+    if (!rc) {
+      BwdParams s = p;
+      s.mode = GRAD_D;
+      s.gin = grows;
+      s.order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
+      s.n_dev = plan;  // n_sparse
+      s.partials = nullptr;
+      rc = launch_bwd(s, ss);
+    }
+    return leave(rc);
   }
   SideStream *fk = nullptr;
   hipStream_t st2 = (dbg_mask() & ((1 << 27) | (1 << 28))) ? st : fork_from(st, p.ks, fk);
@@ -794,7 +905,7 @@ static int map_forward_impl(const float *img, const float *img2, int B, int C, i
                             const int *tile_order, const int *rank_map, const int *fwd_plan, const int *n_edges_dev,
                             int n_rows, int ks, int kw, float sigma, float eps, int generalization, float *ssg,
                             float *ssg2, double *row_scale, bool row_scale_zeroed, ssg_stream_t stream,
-                            const TileMajor *tm = nullptr) {
+                            const TileMajor *tm = nullptr, ForkChain *chain = nullptr) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   if (n_rows == 0) return 0;
@@ -863,6 +974,12 @@ static int map_forward_impl(const float *img, const float *img2, int B, int C, i
     p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
     p.n_dev = fwd_plan;  // n_sparse
     if (!rc && !(dbg_mask() & (1 << 26))) rc = launch_fwd(p, sp.direct);
+    if (!rc && chain && fk && st2 != st) {   // two-chain step: the backward's kernels follow on the same two streams
+      chain->fk = fk;
+      chain->sp = sp;
+      chain->active = true;
+      return 0;
+    }
     const int rcj = join_to(st, fk);
     return rc ? rc : rcj;
   }
@@ -933,12 +1050,22 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
                          float sigma, int generalization, float *ssg_sr, float *ssg_gt, float w_l1, float w_kl,
                          const float *upstream, float *loss_out, float *grad_sr, void *scratch, void *grad_fix,
                          const double *row_scale, bool rows_scratch, bool fix_zeroed, bool grad_is_output,
-                         ssg_stream_t stream, const TileMajor *tm = nullptr, bool nan_on_overflow = false) {
+                         ssg_stream_t stream, const TileMajor *tm = nullptr, bool nan_on_overflow = false,
+                         ForkChain *chain = nullptr) {
   if (n_rows < 0 || !sizes_ok(ks, kw) || B <= 0 || C <= 0 || !loss_out) return SSG_E_BADARG;
   if (H <= ks / 2 || W <= ks / 2) return SSG_E_IMAGESMALL;
   hipStream_t st = (hipStream_t)stream;
-  if (n_rows == 0) return (int)hipMemsetAsync(loss_out, 0, 2 * sizeof(float), st);
-  if (!sr || !edges || !ssg_sr || !ssg_gt || !scratch) return SSG_E_BADARG;
+  // (a forward that left its streams forked is joined on every way out)
+  auto leave = [&](int rc0) {
+    if (chain && chain->active) {
+      const int rcj = join_to(st, chain->fk);
+      chain->active = false;
+      return rc0 ? rc0 : rcj;
+    }
+    return rc0;
+  };
+  if (n_rows == 0) return leave((int)hipMemsetAsync(loss_out, 0, 2 * sizeof(float), st));
+  if (!sr || !edges || !ssg_sr || !ssg_gt || !scratch) return leave(SSG_E_BADARG);
   BwdParams p{};
   p.img = sr;
   p.grad = grad_sr;
@@ -965,18 +1092,21 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   p.dbg = (dbg_mask() >> 8) & 0xff;
   p.row_scale = row_scale;
   p.rows_scratch = rows_scratch ? 1 : 0;
-  if (row_scale && !split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) return SSG_E_BADARG;  // only ssg_grad_rows rescales
+  if (row_scale && !split_ok(ks, kw, C, rank_map, fwd_plan, scratch)) return leave(SSG_E_BADARG);  // only ssg_grad_rows rescales
   int rc = det_begin(p, grad_fix, st, fix_zeroed);
-  if (rc) return rc;
+  if (rc) return leave(rc);
   int nparts;
   bool fin_done = false;
   const bool split = split_ok(ks, kw, C, rank_map, fwd_plan, scratch);
-  nparts = split ? (int)grow_grid(n_rows) + rows_tm_parts(split_tm_tiles(p, tm)) : 0;
+  // (per-class row passes: two sets of grow_grid(n_rows) slots of criteria sums)
+  nparts = split ? (split_row_classes(p, split_tm_tiles(p, tm)) ? 2 : 1) * (int)grow_grid(n_rows) + rows_tm_parts(split_tm_tiles(p, tm)) : 0;
   if (split) {
     const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0};
-    rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done, tm);
+    rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done, tm,
+                        chain);
   } else {
-    if (p.gfix) rc = launch_grad_fix_bound(p, st);
+    rc = leave(0);
+    if (!rc && p.gfix) rc = launch_grad_fix_bound(p, st);
     if (!rc) rc = launch_bwd(p, st);
     nparts = (int)bwd_grid(p);
   }
@@ -1120,6 +1250,9 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   // the row scales and the fixed-point gradient sums start at zero: cleared by the edge-list builder's first kernel
   // (16-byte granules: both sizes are multiples of 16)
   const bool zero_fix = grad_fix && grad_sr;
+  // two chains (ForkChain): sizes with a dense / direct split and a side stream to put one of them on
+  const bool two_chains = defer && grad_sr && ks <= 25 && overlap_enabled() && two_chains_allowed();
+  const bool free_running = two_chains && two_chains_wanted();
   const size_t fix_bytes = sizeof(long long) * ((size_t)B * C * H * W + 8), rs_bytes = 2 * sizeof(double) * (size_t)capacity;
   int rc = edge_list_impl(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
                           W, mask_stride, lap_threshold, ks, edges, capacity, counts, rank, order, plan, escratch,
@@ -1132,12 +1265,16 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
     rc = (int)hipMemsetAsync((char *)grad_sr + ((sizeof(float) * (size_t)B * C * H * W) & ~(size_t)15), 0,
                              (sizeof(float) * (size_t)B * C * H * W) & 15, (hipStream_t)stream);
   if (rc) return rc;
+  ForkChain chain;
+  chain.gated = !free_running;
   rc = map_forward_impl(sr, gt, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, eps,
-                        generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, defer, stream, &tm);
+                        generalization, ssg_sr, ssg_gt, defer ? row_scale : nullptr, defer, stream, &tm,
+                        two_chains ? &chain : nullptr);
   if (rc) return rc;
   return loss_backward(sr, B, C, H, W, edges, order, rank, plan, counts, capacity, ks, kw, sigma, generalization,
                        ssg_sr, ssg_gt, w_l1, w_kl, nullptr, loss_out, grad_sr, lscratch, grad_fix,
-                       defer ? row_scale : nullptr, fused, zero_fix, grad_is_output && zero_fix, stream, &tm, true);
+                       defer ? row_scale : nullptr, fused, zero_fix, grad_is_output && zero_fix, stream, &tm, true,
+                       two_chains ? &chain : nullptr);
 }
 
 int ssg_loss_fwd_bwd(const float *sr, const float *gt, const void *mask, int mask_kind, int mask_channels, int B,

@@ -353,6 +353,12 @@ struct GrowParams {
   const int *tm_hdr;
   int tm_slots;
   const int *sparse_order;
+  // two-chain step (ssg_api.hip): 0 every row; 1 the rows with a non-zero row scale only (the dense-tile kernels' rows,
+  // un-normalised); 2 the rows of the plan's sparse list only (tm_hdr = plan + 1, sparse_order; the direct kernels' rows)
+  int only;
+  // nullable: the bound word behind the fixed-point sums -- the first workgroup writes the a-priori bound of |G| there
+  // (GRAD_LOSS: 4 kfac (|w_l1| u_1 + |w_kl| u_2) / (n P), grad_fix_bound_kernel's) instead of every group's maximum
+  unsigned *fix_word;
 };
 
 // Tile-major scratch rows (fused step at k_s = 49): the tile in slot t of the plan's dense list keeps

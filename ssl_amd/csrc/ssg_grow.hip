@@ -32,7 +32,13 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
   // slot g of the partial arrays (same values, same order in the finalize)
   // (a call whose dense tiles are tile-major: only the rows NOT in a dense tile are left, taken from the plan's own
   // list of them; the groups behind the list write their zero sums without reading anything)
-  const bool via_list = p.tm_hdr && tm_active(p.tm_hdr, p.tm_slots, nrows);
+  if (p.fix_word && blockIdx.x == 0 && threadIdx.x == 0) {   // (same value from every pass of a call: a plain store)
+    const float invM = 1.f / ((float)(nrows > 0 ? nrows : 1) * (float)P);
+    const float u1 = p.upstream ? fabsf(p.upstream[0]) : 1.f, u2 = p.upstream ? fabsf(p.upstream[1]) : 1.f;
+    const float kfac0 = 1.f / (p.sigma * (float)(p.C * KW * KW));
+    *p.fix_word = __float_as_uint(4.f * kfac0 * (fabsf(p.w_l1) * u1 + fabsf(p.w_kl) * u2) * invM);
+  }
+  const bool via_list = p.tm_hdr && p.sparse_order && (p.only == 2 || tm_active(p.tm_hdr, p.tm_slots, nrows));
   const int n_list = via_list ? (p.tm_hdr[-1] < nrows ? p.tm_hdr[-1] : nrows) : 0;
   const int live_groups = via_list ? (n_list + 3) / 4 : p.ngroups;
   // the groups behind the list: zero sums, one thread per group (no barrier, nothing read)
@@ -50,7 +56,10 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
   // a NEGATIVE row scale: the row lives in the tile-major region (fused step at k_s = 49); ssg_rows_tm and the dense
   // backward own it, nothing of it is read or written here
   const bool tm_row = n < nrows && p.row_scale && p.mode == GRAD_LOSS && p.row_scale[n] < 0.0;
-  if (n < nrows && !tm_row) {
+  // (two-chain step, the dense chain's pass: a zero row scale marks a row of the direct kernels -- the other chain's pass
+  // takes it; the scales were cleared before the chains forked, so the test does not race with the other stream)
+  const bool other_chain = p.only == 1 && n < nrows && p.row_scale[n] == 0.0;
+  if (n < nrows && !tm_row && !other_chain) {
     const size_t base = (size_t)n * P;
     float va[EPL], vg[EPL];
     const float *src_a = p.mode == GRAD_D ? p.gin : p.ssg;
