@@ -168,8 +168,13 @@ int ssg_set_dense_threshold(int edge_pixels_per_tile);
  * shape of the last plan ssg_edge_list / the fused step built on the device -- its scan kernel leaves {rows for the
  * direct kernels, dense tiles} in host-mapped memory, the host reads it at the next pass without synchronising; the
  * branch expected to take longer (38 ns per direct row against 0.74 us per dense tile) stays on the caller's stream.
- * Same results in every mode (the two kernels work on disjoint rows).  Process-wide; returns the previous setting.  No
- * reference counterpart (the reference launches on the legacy stream, similarity.cu:69,147). */
+ * In mode 3 the fused steps (ssg_loss_fwd_bwd, ssg_loss_step) also run forward AND backward of the two branches as two
+ * chains with ONE join at the end: free-running when the direct chain carries the step or the plan holds at most 512
+ * dense tiles, otherwise with the direct backward held by a one-way event until the dense backward starts (C2 1.27 ->
+ * 1.25 ms, C4 0.50 -> 0.46, Bernoulli 1 % 0.185 -> 0.175).
+ * Same results, bit for bit in deterministic mode, in every mode and schedule (disjoint rows, integer sums at a scale that
+ * does not depend on the schedule).  Process-wide; returns the previous setting.  No reference counterpart (the
+ * reference launches on the legacy stream, similarity.cu:69,147). */
 int ssg_set_overlap(int mode);
 /* Diagnostics: the assignment the calling thread's last forked pass used (0 not forked, 1, 2 as above). */
 int ssg_last_overlap_assignment(void);
@@ -240,8 +245,14 @@ int ssg_map_backward(const float *img, int B, int C, int H, int W,
  * from run to run (as with the reference's atomicAdd, similarity.cu:123-128).  Passing `grad_fix` --
  * ssg_grad_fix_bytes(B,C,H,W) bytes of device memory, contents irrelevant -- to the backward entry points makes
  * the result bit-reproducible: contributions are rounded to multiples of a power of two chosen on the device
- * from the largest |dL/dD| of the call (2^-35 of it: 11 bits finer than an fp32 sum of the same terms; headroom for pixel differences up to 16) and summed
- * with 64-bit integer atomics (integer addition is associative), then folded into grad once per pixel. */
+ * from an upper bound of |dL/dD| over the call (2^-35 of it; headroom for pixel differences up to 16) and summed
+ * with 64-bit integer atomics (integer addition is associative), then folded into grad once per pixel.  The bound:
+ * ssg_map_backward and the k_s = 49 tile-major step take the exact maximum (11 bits finer than an fp32 sum of the same
+ * terms); the loss steps take the a-priori bound 4 (|w_l1| u_1 + |w_kl| u_2) / (sigma C k_w^2 n k_s^2) -- |s g| <= w_1 +
+ * w_2 because s, t <= 1 -- which needs no pass over the rows and does not depend on how the step is scheduled
+ * (ssg_set_overlap).  It lies further above the maximum the flatter the rows are; measured at sigma 0.004, 0.05 and 1,
+ * (25,9) and (11,5): the deterministic gradient stays within 2e-7 max|grad| of the fp32-atomic one, which is the atomics'
+ * own run-to-run spread (tools/r5_fix_resolution.py). */
 size_t ssg_grad_fix_bytes(int B, int C, int H, int W);
 
 /* ---------------------------------------------------------------- (D) ----

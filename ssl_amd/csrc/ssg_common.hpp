@@ -282,7 +282,7 @@ inline int ensure_dynamic_lds(K kernel, int bytes, std::atomic<unsigned long lon
 // Deterministic mode (gfix != nullptr): the contribution is rounded to a multiple of 1/scale and added with a 64-bit
 // INTEGER atomic; integer addition is associative, so the sum does not depend on the order and two runs agree bit
 // for bit.  The scale is a power of two derived ON THE DEVICE from an upper bound of |G| = |dL/dD| (exact maximum
-// from ssg_grad_rows, or an a-priori bound on the direct-only path), stored as float bits in the word after the
+// from ssg_grad_rows for ssg_map_backward and the tile-major step; the a-priori bound of the loss steps otherwise), stored as float bits in the word after the
 // n = B*C*H*W sums: |G| * scale < 2^36.  A pixel collects fewer than 2^21 terms 2 G d (2 k_w^2 k_s^2 = 8.1e5 for
 // (49,13) under a dense mask, 1.0e5 for (25,9)), so the sum stays below 2^36 * 2^21 * 2 |d| = 2^58 |d|: no wrap for
 // pixel differences up to 16 -- the loss is applied to the un-clamped generator output, whose differences exceed 1

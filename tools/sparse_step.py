@@ -1,5 +1,5 @@
 """One sparse / small configuration of the loss step, for rocprofv3 kernel traces and launch-overhead measurements:
-   python tools/sparse_step.py <c1|b1|b4|c4|i1> [iters] [--graph]
+   python tools/sparse_step.py <c1|b1|b4|c4|i1|c2> [iters] [--graph]
 c1 = BASELINE configs[0] (1x3x64x64, 209 px, (11,5)); b1 / b4 = 4x3x256x256 Bernoulli 1 % / 4 % masks, (25,9);
 c4 = BASELINE configs[3] per GPU (2x3x512x512, Laplacian x stride 3, eps 1e-20).  Prints ms/step (HIP events)."""
 import os, sys
@@ -24,6 +24,9 @@ elif name in ("b1", "b4"):
         if d == dens:
             m = mm
     ks, kwin, sigma = 25, 9, 1.0
+elif name == "c2":     # BASELINE configs[1]: the headline batch (for kernel timelines; bench.py is the measurement)
+    sr, gt, m = synth.make_batch(16, 256, 256, seed0=100)
+    ks, kwin, sigma = 25, 9, 0.004
 elif name == "i1":     # one image of the C2 batch (what a per-image caller hands over)
     sr, gt, m = synth.make_batch(1, 256, 256, seed0=7)
     ks, kwin, sigma = 25, 9, 0.004
