@@ -228,7 +228,11 @@ def stage_times(step, sr, gt, mask, n_edges, iters, cfg=None):
     dense = f"<{KS},{KW},3>"
     out[f"ssg_fwd_dense{dense}"] = only(f_fwd, "fwd_dense", fwd_group)
     out[f"ssg_fwd_tiled<{KS},{KW}> merged+single (2 launches)"] = only(f_fwd, "fwd_direct", fwd_group)
-    out[f"ssg_grad_rows<{KS},{KW}>+finalize"] = only(f_bwd, "grad_rows", bwd_group)
+    # (the masked forward runs above left the row scales of the dense-tile rows cleared: a complete forward again, so
+    #  that the row passes below see the rows of both classes -- the dense-class pass skips rows with a zero scale)
+    f_fwd()
+    torch.cuda.synchronize()
+    out[f"ssg_grad_rows<{KS},{KW}> (2 passes)+finalize"] = only(f_bwd, "grad_rows", bwd_group)
     out[f"ssg_bwd_dense{dense}"] = only(f_bwd, "bwd_dense", bwd_group)
     out[f"ssg_bwd_tiled<{KS},{KW}>"] = only(f_bwd, "bwd_direct", bwd_group)
     # the masked runs of the backward still launch the 6 us finalize kernel; it is part of the grad_rows line only
