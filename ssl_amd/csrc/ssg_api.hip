@@ -459,6 +459,20 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   const size_t n_fix = (size_t)p.B * p.C * p.H * p.W;
   const bool apriori = p.gfix && p.mode == GRAD_LOSS && n_tm == 0;
   const bool classes = split_row_classes(p, n_tm);
+  // A backward on its own (ssg_loss_backward: the deferred loop's node, the module) forks HERE and runs the same two
+  // chains from the row passes on: the sparse list's pass beside the dense-tile rows' instead of behind it.
+  ForkChain local;
+  if (!(chain && chain->active) && classes && p.grad && !(dbg_mask() & ((1 << 27) | (1 << 28) | (1 << 29)))) {
+    SideStream *fk0 = nullptr;
+    hipStream_t st20 = fork_from(st, p.ks, fk0);
+    if (fk0 && st20 != st) {
+      local.fk = fk0;
+      local.sp = assign_streams(st, st20);
+      local.active = true;
+      local.gated = !two_chains_wanted();
+      chain = &local;
+    }
+  }
   const bool chained = chain && chain->active;
   hipStream_t sd = chained ? chain->sp.dense : st, ss = chained ? chain->sp.direct : st;
   auto leave = [&](int rc0) {   // (a forward that left its streams forked is joined on every way out)

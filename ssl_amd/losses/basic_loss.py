@@ -267,8 +267,17 @@ class SSGLoss(nn.Module):
         else:
             with torch.cuda.device(sr.device):   # the copy and the event go to the stream of sr's device
                 # (pinned words and events are recycled once their count has been read: no page-locking per call)
-                pool = self._free.setdefault(sr.device.index, [])
-                host, ev = pool.pop() if pool else (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                # (one page-locked block of 64 words per device, cut into (word, event) pairs at first use: page-locking
+                #  a fresh word per call cost ~1 ms of host time each until enough of them had come back -- the first
+                #  dozens of steps of a loop that runs ahead of the GPU.  With all 64 in flight the oldest is waited for.)
+                pool = self._free.get(sr.device.index)
+                if pool is None:
+                    block = torch.zeros(64, dtype=torch.int32).pin_memory()
+                    pool = self._free[sr.device.index] = [(block[i:i + 1], torch.cuda.Event()) for i in range(64)]
+                while not pool and self._pending:
+                    self._pending[0][0].synchronize()
+                    self._check_previous()
+                host, ev = pool.pop()
                 host.copy_(counts[:1], non_blocking=True)
                 ev.record(torch.cuda.current_stream(sr.device))
             self._pending.append((ev, host, cap, sr.device.index))
