@@ -1120,7 +1120,7 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
                         chain);
   } else {
     rc = leave(0);
-    if (!rc && p.gfix) rc = launch_grad_fix_bound(p, st);
+    p.fix_inline = p.gfix ? 1 : 0;   // (GRAD_LOSS: the backward kernel derives the a-priori scale itself -- one launch less)
     if (!rc) rc = launch_bwd(p, st);
     nparts = (int)bwd_grid(p);
   }

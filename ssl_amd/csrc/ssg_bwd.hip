@@ -128,7 +128,14 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   const float *zrow = zero + HK;
   float l1p = 0.f, klp = 0.f;
   const bool need_grad = p.grad != nullptr;
-  const float gsc = grad_fix_scale(p.gfix, (size_t)p.B * p.C * p.H * p.W);
+  float gsc;
+  if (p.fix_inline && p.gfix) {   // (loss step on the direct-only path: no launch in front of this one computes the bound)
+    const unsigned bb = __float_as_uint(loss_grad_bound(p.sigma, C, KW, p.w_l1, p.w_kl, p.upstream, rows_to_do(p.n_dev, p.n_host), P));
+    gsc = grad_fix_scale_of(bb);
+    if (blockIdx.x == 0 && tid == 0) *(unsigned *)(p.gfix + (size_t)p.B * p.C * p.H * p.W) = bb;   // for grad_fix_flush
+  } else {
+    gsc = grad_fix_scale(p.gfix, (size_t)p.B * p.C * p.H * p.W);
+  }
 
   // Barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global
   // atomics (a __syncthreads() would drain vmcnt and stall every barrier behind the atomics'
@@ -603,7 +610,14 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
   __syncthreads();
   if (tid == 0) gt[hp * ks + hp] = 0.f;  // exact: the centre offset has A - B == 0 (see the tiled kernel)
   const size_t ibase = (size_t)e.b * C * H * W;
-  const float gsc = grad_fix_scale(p.gfix, (size_t)p.B * p.C * p.H * p.W);
+  float gsc;
+  if (p.fix_inline && p.gfix) {
+    const unsigned bb = __float_as_uint(loss_grad_bound(p.sigma, C, p.kw, p.w_l1, p.w_kl, p.upstream, rows_to_do(p.n_dev, p.n_host), P));
+    gsc = grad_fix_scale_of(bb);
+    if (blockIdx.x == 0 && tid == 0) *(unsigned *)(p.gfix + (size_t)p.B * p.C * p.H * p.W) = bb;
+  } else {
+    gsc = grad_fix_scale(p.gfix, (size_t)p.B * p.C * p.H * p.W);
+  }
   for (int i = tid; i < C * P; i += 256) {
     const int c = i / P, r = i - c * P, ry = r / ks, rx = r - ry * ks;
     tile[i] = p.img[ibase + ((size_t)c * H + reflect_idx(e.y - hp + ry, H)) * W + reflect_idx(e.x - hp + rx, W)];
@@ -750,9 +764,7 @@ __global__ __launch_bounds__(256) void grad_fix_bound_kernel(BwdParams p, size_t
   const float kfac = 1.f / (p.sigma * (float)(p.C * p.kw * p.kw));
   if (p.mode == GRAD_LOSS) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const float invM = 1.f / ((float)(nrows > 0 ? nrows : 1) * (float)P);
-      const float u1 = p.upstream ? fabsf(p.upstream[0]) : 1.f, u2 = p.upstream ? fabsf(p.upstream[1]) : 1.f;
-      grad_fix_bound(p.gfix, n_fix, 4.f * kfac * (fabsf(p.w_l1) * u1 + fabsf(p.w_kl) * u2) * invM);
+      grad_fix_bound(p.gfix, n_fix, loss_grad_bound(p.sigma, p.C, p.kw, p.w_l1, p.w_kl, p.upstream, nrows, P));
     }
     return;
   }

@@ -181,6 +181,8 @@ struct BwdParams {
   const float *img;  // (B,C,H,W)
   float *grad;       // (B,C,H,W), accumulated with fp32 atomics (may be null in GRAD_LOSS: loss only)
   long long *gfix;   // nullable (B,C,H,W): deterministic mode, the same sums in 2^-40 fixed point (integer atomics)
+  int fix_inline;    // GRAD_LOSS on the direct-only path: every workgroup derives the scale from loss_grad_bound() itself
+                     // and the first one leaves the bound in the word behind the sums for the flush (no bound launch)
   const int *edges;
   int estride;
   const int *order;  // nullable (n) int32: job k works on row order[k] (tile-major permutation of the rows)
@@ -288,11 +290,23 @@ inline int ensure_dynamic_lds(K kernel, int bytes, std::atomic<unsigned long lon
 // pixel differences up to 16 -- the loss is applied to the un-clamped generator output, whose differences exceed 1
 // early in training but not by that much.  Resolution: 2^-35 of the largest |G|, 11 bits finer than an fp32 sum of
 // the same terms.  (Round 2 used 2^-38, which left a factor 4 for |d| at (49,13).)
+__device__ __forceinline__ float grad_fix_scale_of(unsigned bound_bits) {
+  unsigned e = (bound_bits >> 23) & 0xffu;   // biased exponent of the bound: bound < 2^(e-126)
+  e = e < 40u ? 40u : e;
+  return __uint_as_float((289u - e) << 23);  // 2^(35 - (e - 127))
+}
 __device__ __forceinline__ float grad_fix_scale(const long long *gfix, size_t n) {
   if (!gfix) return 1.f;
-  unsigned e = (*(const unsigned *)(gfix + n) >> 23) & 0xffu;  // biased exponent of the bound: bound < 2^(e-126)
-  e = e < 40u ? 40u : e;
-  return __uint_as_float((289u - e) << 23);                    // 2^(35 - (e - 127))
+  return grad_fix_scale_of(*(const unsigned *)(gfix + n));
+}
+// a-priori bound of |G| of a loss step (GRAD_LOSS): |s g| <= w1m + w2m (s, t <= 1) and |sum g s| likewise -> 4 kfac (w1m +
+// w2m) with a factor 2 to spare; kfac = 1 / (sigma C k_w^2), w.m = |w.| u. / (n k_s^2)
+__device__ __forceinline__ float loss_grad_bound(float sigma, int C, int kw, float w_l1, float w_kl, const float *upstream,
+                                                 int nrows, int P) {
+  const float kfac = 1.f / (sigma * (float)(C * kw * kw));
+  const float invM = 1.f / ((float)(nrows > 0 ? nrows : 1) * (float)P);
+  const float u1 = upstream ? fabsf(upstream[0]) : 1.f, u2 = upstream ? fabsf(upstream[1]) : 1.f;
+  return 4.f * kfac * (fabsf(w_l1) * u1 + fabsf(w_kl) * u2) * invM;
 }
 __device__ __forceinline__ void grad_add(float *grad, long long *gfix, size_t idx, float v, float scale) {
   if (gfix)

@@ -33,10 +33,7 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
   // (a call whose dense tiles are tile-major: only the rows NOT in a dense tile are left, taken from the plan's own
   // list of them; the groups behind the list write their zero sums without reading anything)
   if (p.fix_word && blockIdx.x == 0 && threadIdx.x == 0) {   // (same value from every pass of a call: a plain store)
-    const float invM = 1.f / ((float)(nrows > 0 ? nrows : 1) * (float)P);
-    const float u1 = p.upstream ? fabsf(p.upstream[0]) : 1.f, u2 = p.upstream ? fabsf(p.upstream[1]) : 1.f;
-    const float kfac0 = 1.f / (p.sigma * (float)(p.C * KW * KW));
-    *p.fix_word = __float_as_uint(4.f * kfac0 * (fabsf(p.w_l1) * u1 + fabsf(p.w_kl) * u2) * invM);
+    *p.fix_word = __float_as_uint(loss_grad_bound(p.sigma, p.C, KW, p.w_l1, p.w_kl, p.upstream, nrows, P));
   }
   const bool via_list = p.tm_hdr && p.sparse_order && (p.only == 2 || tm_active(p.tm_hdr, p.tm_slots, nrows));
   const int n_list = via_list ? (p.tm_hdr[-1] < nrows ? p.tm_hdr[-1] : nrows) : 0;
