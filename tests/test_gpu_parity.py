@@ -1026,6 +1026,28 @@ def test_ssl_pytorch_mode_with_differing_mask_channels(dev):
     assert maxerr(s[0].cpu(), ref) <= 1e-5
 
 
+def test_ssgloss_more_calls_in_flight_than_count_words(dev):
+    """SSGLoss keeps the edge counts of its asynchronous calls in ONE page-locked block of 64 words per device (page-locking
+    a word per call cost ~1 ms of host time each): 150 forward + backward calls without a synchronisation in between --
+    more than the block holds when the host runs ahead -- wait for the oldest count instead of failing, report nothing
+    (no overflow) and give the first call's numbers every time."""
+    from ssl_amd import SSGLoss, synth
+    sr, gt, m = synth.make_batch(2, 64, 64, seed0=900)
+    tsr, tgt, tm = T(sr, dev), T(gt, dev), T(m, dev)
+    crit = SSGLoss(25, 9, 0.004, True, 1e3, 1e3, sync_checks=0)
+    first = None
+    for it in range(150):
+        x = tsr.clone().requires_grad_(True)
+        a, b = crit(x, tgt, tm)
+        (a + b).backward()
+        if first is None:
+            first = (a.detach().clone(), b.detach().clone(), x.grad.clone())
+    assert len(crit._pending) <= 64
+    crit.flush()
+    assert not crit._pending and len(crit._free[tsr.device.index]) == 64
+    assert torch.equal(a.detach(), first[0]) and torch.equal(b.detach(), first[1]) and torch.equal(x.grad, first[2])
+
+
 def test_ssgloss_capacity_growth_and_uint8_semantics(dev):
     """SSGLoss capacity handling.  (1) The first calls are checked in their own step: an under-sized capacity is
     grown and the call RECOMPUTED, so the very first result already covers every edge pixel.  (2) Later calls are
