@@ -147,8 +147,12 @@ def gpu_clock():
 
 
 def event_time_ms(fn, iters):
-    """Mean duration of fn() on torch's current stream (HIP events)."""
+    """Mean duration of fn() on torch's current stream (HIP events).  A full collection first: right after a section that
+    created many objects (the kernel table) the interpreter's cyclic GC ran a full pass in nearly every call of a
+    host-bound loop -- the drop-in module's line read 1.6-2.3 ms per call at C4 instead of 0.47 (`profiles/EXPERIMENTS.md`)."""
+    import gc
     import torch
+    gc.collect()
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
     for _ in range(iters):
