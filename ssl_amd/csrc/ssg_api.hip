@@ -250,6 +250,12 @@ static bool two_chains_allowed() {   // (profiling build: SSG_TWO_CHAINS=-1 rest
   static const bool on = env_int("SSG_TWO_CHAINS", 1) >= 0;
   return on;
 }
+// (a stream that is being captured into a HIP graph: free-running chains replay well -- C4 0.452 ms as a graph, 0.495
+// joined --, a GATED pair does not: C2 as a graph 1.44 ms gated, 1.26 with fork / join around each pass, which it keeps)
+static bool stream_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 static bool two_chains_wanted() {    // free-running (true) or gated (false)
   static const int sw = env_int("SSG_TWO_CHAINS", 1);
   if (sw != 1) return sw == 2;
@@ -462,7 +468,8 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   // A backward on its own (ssg_loss_backward: the deferred loop's node, the module) forks HERE and runs the same two
   // chains from the row passes on: the sparse list's pass beside the dense-tile rows' instead of behind it.
   ForkChain local;
-  if (!(chain && chain->active) && classes && p.grad && !(dbg_mask() & ((1 << 27) | (1 << 28) | (1 << 29)))) {
+  if (!(chain && chain->active) && classes && p.grad && !(dbg_mask() & ((1 << 27) | (1 << 28) | (1 << 29))) &&
+      two_chains_allowed() && (two_chains_wanted() || !stream_capturing(st))) {
     SideStream *fk0 = nullptr;
     hipStream_t st20 = fork_from(st, p.ks, fk0);
     if (fk0 && st20 != st) {
@@ -1265,7 +1272,9 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   // (16-byte granules: both sizes are multiples of 16)
   const bool zero_fix = grad_fix && grad_sr;
   // two chains (ForkChain): sizes with a dense / direct split and a side stream to put one of them on
-  const bool two_chains = defer && grad_sr && ks <= 25 && overlap_enabled() && two_chains_allowed();
+  // (under capture only the free-running chains: a GATED pair replays badly, see stream_capturing)
+  const bool two_chains = defer && grad_sr && ks <= 25 && overlap_enabled() && two_chains_allowed() &&
+                          (two_chains_wanted() || !stream_capturing((hipStream_t)stream));
   const bool free_running = two_chains && two_chains_wanted();
   const size_t fix_bytes = sizeof(long long) * ((size_t)B * C * H * W + 8), rs_bytes = 2 * sizeof(double) * (size_t)capacity;
   int rc = edge_list_impl(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
