@@ -166,7 +166,7 @@ static constexpr int dbg_mask() { return 0; }
 // The dense-tile kernel and the direct kernel of a pass work on disjoint SSG rows (and add into the gradient with
 // atomics), so the direct one runs on a side stream beside the dense one: fork = side waits for an event on the
 // caller's stream, join = the caller's stream waits for the side's event.  Both are plain event edges, so a stream
-// capture of the caller's stream (hipGraph) records the fork as two parallel branches.  One side stream and two
+// capture of the caller's stream (hipGraph) records the fork as two parallel branches.  One side stream and three
 // events per (host thread, device); ssg_set_overlap(0) keeps every launch on the caller's stream.  Measured on MI355X:
 // C2 (k_s 25) 1.541 -> 1.510 ms per step; C5 (k_s 49, every kernel already fills the chip for its whole run)
 // 9.15 -> 9.64 ms -- so the fork is taken for k_s <= 25 only.
@@ -187,13 +187,14 @@ static int overlap_mode() {
   return v;
 }
 static bool overlap_enabled() { return overlap_mode() != 0; }
-// Two-chain step (ForkChain below) or fork / join around forward and backward each?  Free-running chains pay when the
-// direct chain carries the step (Bernoulli 4 %: 0.485 -> 0.463 ms) or the dense kernels are too few workgroups to keep
-// the chip to themselves (C4, 330 tiles: 0.50 -> 0.466).  Where long dense kernels dominate (C2: 1,287 tiles, direct
-// 0.38 ms of kernel time against 0.95) the direct kernels spend themselves beside the dense FORWARD, the dense backward
-// runs alone with its tail unfilled, and the step is 8 % slower (holding the direct backward with a one-way event until
-// the dense backward starts: still +1.3 %; a low-priority side stream: no effect).  Decided per call from the last plan's
-// shape (PlanHint: the numbers the stream assignment uses), unknown = no.
+// Schedules of a fused step at k_s <= 25 (ForkChain below).  FREE-RUNNING chains pay when the direct chain carries the
+// step (Bernoulli 4 %: 0.485 -> 0.463 ms) or the dense kernels are too few workgroups to keep the chip to themselves
+// (C4, 330 tiles: 0.50 -> 0.466).  Where long dense kernels dominate (C2: 1,287 tiles, direct 0.38 ms of kernel time
+// against 0.95) free-running direct kernels spend themselves beside the dense FORWARD and the dense backward runs alone
+// with its tail unfilled (+8 %); there the chains are GATED -- the direct backward waits, one way, for the dense chain's
+// row pass (C2 1.271 -> 1.248 against fork / join around each pass; a low-priority side stream: no effect).
+// two_chains_wanted(): free-running (true) or gated (false), per call from the last plan's shape (PlanHint: the numbers
+// the stream assignment uses); unknown = gated.
 // (profiling build: SSG_TWO_CHAINS=0 always gated, 2 always free-running, -1 no chains: fork / join around each pass)
 static bool two_chains_wanted();
 static bool two_chains_allowed();
