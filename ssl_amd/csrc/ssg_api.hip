@@ -15,7 +15,7 @@ int launch_bwd(const BwdParams &p, hipStream_t st);
 unsigned bwd_grid(const BwdParams &p);
 size_t bwd_max_partials(int B, int H, int W, int n_rows);
 int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
-                         float w_kl, float *loss_out, int nan_on_overflow, hipStream_t st);
+                         float w_kl, float *loss_out, int nan_on_overflow, hipStream_t st, int set_size = 0);
 const char *fwd_kernel_name(int ks, int kw);
 const char *bwd_kernel_name(int ks, int kw);
 size_t edge_scratch_bytes(int B, int H, int W);
@@ -583,7 +583,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
       if (!rc) rc = (int)hipStreamWaitEvent(ss, chain->fk->gate, 0);
       if (!rc && fin) {   // (both passes' criteria sums are complete behind the gate)
         rc = launch_loss_finalize(fin->partials, fin->nparts, fin->n_dev, fin->n_host, fin->P, fin->w_l1, fin->w_kl,
-                                  fin->loss_out, fin->nan_on_overflow, ss);
+                                  fin->loss_out, fin->nan_on_overflow, ss, fin->set_size);
         if (!rc && fin_done) *fin_done = true;
       }
       if (rc) return leave(rc);
@@ -607,7 +607,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   // the last workgroup of grad_fix_flush (det_end, round 5) or, without a fixed-point buffer, follows the backward.)
   if (fin && fk && st2 != st) {
     rc = launch_loss_finalize(fin->partials, fin->nparts, fin->n_dev, fin->n_host, fin->P, fin->w_l1, fin->w_kl,
-                              fin->loss_out, fin->nan_on_overflow, st2);
+                              fin->loss_out, fin->nan_on_overflow, st2, fin->set_size);
     if (rc) return rc;
     if (fin_done) *fin_done = true;
   }
@@ -1122,8 +1122,10 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   const bool split = split_ok(ks, kw, C, rank_map, fwd_plan, scratch);
   // (per-class row passes: two sets of grow_grid(n_rows) slots of criteria sums)
   nparts = split ? (split_row_classes(p, split_tm_tiles(p, tm)) ? 2 : 1) * (int)grow_grid(n_rows) + rows_tm_parts(split_tm_tiles(p, tm)) : 0;
+  // (ssg_grad_rows' slots come in sets of grow_grid(n_rows), live up to the device's row count: LossFinalize::set_size)
+  const int set_size = split && split_tm_tiles(p, tm) == 0 ? (int)grow_grid(n_rows) : 0;
   if (split) {
-    const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0};
+    const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0, set_size};
     rc = split_backward(p, rank_map, fwd_plan, (char *)scratch + partials_bytes(B, H, W, n_rows), st, &fin, &fin_done, tm,
                         chain);
   } else {
@@ -1132,12 +1134,13 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
     if (!rc) rc = launch_bwd(p, st);
     nparts = (int)bwd_grid(p);
   }
-  const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0};
+  const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0, set_size};
   // (the finalize rides in the flush's last workgroup when its partial sums are few -- 256 threads play its 1,024 lanes: C5's
   // 70 k partials took 30 us there against 10 + 11 as two launches)
   if (!rc) rc = det_end(p, st, grad_is_output, (fin_done || nparts > 4096) ? nullptr : &fin, &fin_done);
   if (rc || fin_done) return rc;
-  return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0, st);
+  return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0, st,
+                              set_size);
 }
 
 int ssg_loss_backward(const float *sr, int B, int C, int H, int W, const int *edges, const int *tile_order,

@@ -667,19 +667,30 @@ __global__ __launch_bounds__(256) void ssg_bwd_generic(BwdParams p) {
 // grad_fix_flush (NT = 256, round 5: one launch less at the end of every deterministic step) give the same bits.
 template <int NT>
 __device__ __forceinline__ void loss_finalize_body(const LossFinalize &f, double *s1, double *s2) {
-  const float2 *pp = (const float2 *)f.partials;
+  // (sets of slots: only the live prefix of every set, see LossFinalize::set_size -- the dead slots hold zeros, so the
+  //  sums are the same numbers in the same order of lanes either way)
+  const int nsets = f.set_size > 0 ? f.nparts / f.set_size : 1;
+  const int set_size = f.set_size > 0 ? f.set_size : f.nparts;
+  int live = set_size;
+  if (f.set_size > 0) {
+    const int lr = (rows_to_do(f.n_dev, f.n_host) + 3) / 4;
+    live = lr < set_size ? lr : set_size;
+  }
   for (int vt = threadIdx.x; vt < 1024; vt += NT) {
     double a = 0, b = 0;
-    int i = vt;
-    for (; i + 3 * 1024 < f.nparts; i += 4 * 1024) {  // four independent loads in flight
-      const float2 v0 = pp[i], v1 = pp[i + 1024], v2 = pp[i + 2048], v3 = pp[i + 3072];
-      a += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
-      b += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
-    }
-    for (; i < f.nparts; i += 1024) {
-      const float2 v = pp[i];
-      a += (double)v.x;
-      b += (double)v.y;
+    for (int sset = 0; sset < nsets; ++sset) {
+      const float2 *pp = (const float2 *)f.partials + (size_t)sset * set_size;
+      int i = vt;
+      for (; i + 3 * 1024 < live; i += 4 * 1024) {  // four independent loads in flight
+        const float2 v0 = pp[i], v1 = pp[i + 1024], v2 = pp[i + 2048], v3 = pp[i + 3072];
+        a += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
+        b += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
+      }
+      for (; i < live; i += 1024) {
+        const float2 v = pp[i];
+        a += (double)v.x;
+        b += (double)v.y;
+      }
     }
     s1[vt] = a;
     s2[vt] = b;
@@ -875,9 +886,9 @@ int launch_bwd(const BwdParams &p, hipStream_t st) {
 }
 
 int launch_loss_finalize(const float *partials, int nparts, const int *n_dev, int n_host, int P, float w_l1,
-                         float w_kl, float *loss_out, int nan_on_overflow, hipStream_t st) {
+                         float w_kl, float *loss_out, int nan_on_overflow, hipStream_t st, int set_size) {
   hipLaunchKernelGGL(ssg_loss_finalize, dim3(1), dim3(1024), 0, st,
-                     LossFinalize{partials, nparts, n_dev, n_host, P, w_l1, w_kl, loss_out, nan_on_overflow});
+                     LossFinalize{partials, nparts, n_dev, n_host, P, w_l1, w_kl, loss_out, nan_on_overflow, set_size});
   return (int)hipGetLastError();
 }
 

@@ -247,6 +247,10 @@ struct LossFinalize {
   float w_l1, w_kl;
   float *loss_out;
   int nan_on_overflow;
+  // > 0: the slots are sets of `set_size` (ssg_grad_rows' passes: one slot per 4 rows, sized by the HOST's bound on the
+  // rows), of which only the first ceil(rows / 4) by the DEVICE count can be non-zero: the rest is not read (a generous
+  // capacity costs nothing here).  0: all nparts slots are read.
+  int set_size;
 };
 
 // Environment switches exist in the PROFILING build only (libssg_hip_prof.so, -DSSG_PROFILE: the A/B measurements of

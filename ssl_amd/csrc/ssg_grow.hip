@@ -37,7 +37,10 @@ __global__ __launch_bounds__(256) void ssg_grad_rows(GrowParams p) {
   }
   const bool via_list = p.tm_hdr && p.sparse_order && (p.only == 2 || tm_active(p.tm_hdr, p.tm_slots, nrows));
   const int n_list = via_list ? (p.tm_hdr[-1] < nrows ? p.tm_hdr[-1] : nrows) : 0;
-  const int live_groups = via_list ? (n_list + 3) / 4 : p.ngroups;
+  // (groups = what the HOST's bound on the rows allows; the live ones follow from the DEVICE count: a generous capacity
+  //  then costs the zero fill below, not a workgroup per dead group)
+  const int live_rows = (nrows + 3) / 4 < p.ngroups ? (nrows + 3) / 4 : p.ngroups;
+  const int live_groups = via_list ? (n_list + 3) / 4 : live_rows;
   // the groups behind the list: zero sums, one thread per group (no barrier, nothing read)
   for (int g = live_groups + blockIdx.x * 256 + threadIdx.x; g < p.ngroups; g += gridDim.x * 256) {
     if (p.gmax_part) p.gmax_part[g] = 0.f;
@@ -676,12 +679,16 @@ int launch_criteria_grad(const float *a, const float *b, size_t n, const float *
 bool grow_supported(int ks, int kw) { return (ks == 25 && kw == 9) || (ks == 49 && kw == 13); }
 
 unsigned grow_grid(int n_host) { return (unsigned)((n_host + 3) / 4); }
+constexpr int GROW_GRID_MAX = 32768;
 
 int launch_grad_rows(const GrowParams &p0, int ks, int kw, hipStream_t st) {
   if (p0.n_host <= 0) return 0;
   GrowParams p = p0;
   p.ngroups = (int)grow_grid(p.n_host);
-  const unsigned grid = p.grid_cap > 0 && p.grid_cap < p.ngroups ? (unsigned)p.grid_cap : (unsigned)p.ngroups;
+  // (a call without its own cap: at most GROW_GRID_MAX workgroups -- beyond that the bound on the rows is far above any
+  //  count the kernel will see at this image size, and the workgroups walk the groups)
+  const int cap = p.grid_cap > 0 ? p.grid_cap : GROW_GRID_MAX;
+  const unsigned grid = cap < p.ngroups ? (unsigned)cap : (unsigned)p.ngroups;
   if (ks == 25 && kw == 9)
     hipLaunchKernelGGL((ssg_grad_rows<25, 9>), dim3(grid), dim3(256), 0, st, p);
   else if (ks == 49 && kw == 13)

@@ -146,8 +146,8 @@ class SSGLoss(nn.Module):
     the (B,C,H,W) gradient for backward.  At k_s = 49 the workspace holds FOUR row regions (two
     row-major, two tile-major: ssg_loss_rows_bytes in include/ssg_hip.h): 4 * capacity * 2401 * 4
     bytes = 10 GB at capacity 512 x 512; size `capacity` accordingly for dense masks at that size.  `capacity` bounds the number of edge pixels of a call
-    without a host round trip.  Default (capacity=None): a quarter of the call's pixels (edge masks
-    are ~7 % dense; computed per call, so a small first batch does not pin it) or the largest count
+    without a host round trip.  Default (capacity=None): a quarter of the call's pixels, divided by
+    mask_stride (edge masks are ~7 % dense; computed per call, so a small first batch does not pin it) or the largest count
     seen so far plus 1/8, whichever is larger.  DENSE masks (mask_stride patterns over textured
     crops, the 100 % stress mask) need `capacity=B*H*W` -- or rely on the checks below:
       * the first `sync_checks` calls (default 2), and the call after any overflow, read the edge
@@ -186,7 +186,9 @@ class SSGLoss(nn.Module):
         self._free = {}            # device index -> (pinned count, event) pairs whose count has been read
 
     def _capacity_for(self, B, H, W):
-        cap = self.capacity if self.capacity is not None else max(1024, (B * H * W) // 4)
+        # (a strided mask keeps 1 / stride of the pixels: the default bound shrinks with it -- the direct kernels' grids and
+        #  the workspace follow the bound, a 10 x generous one cost the C4 step 8 %)
+        cap = self.capacity if self.capacity is not None else max(1024, (B * H * W) // (4 * max(1, int(self.mask_stride or 0))))
         return min(max(cap, self._grown), B * H * W)   # (clamped for THIS call only)
 
     def _grow(self, n, cap):
