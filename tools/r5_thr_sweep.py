@@ -25,7 +25,8 @@ for name, ((sr, gt, m), sigma, stride, eps, w) in cases.items():
         for t in thrs:
             prev = engine.set_dense_threshold(t)
             try:
-                step = engine.LossStep(B, C, H, W, 25, 9, sigma, eps, True, w, w, device=dev, mask_stride=stride)
+                n = int(engine.edge_list(mask=mm, mask_stride=stride).counts[0])
+                step = engine.LossStep(B, C, H, W, 25, 9, sigma, eps, True, w, w, device=dev, mask_stride=stride, capacity=n + 1024)
                 res.append((t, run(step, a, b, mm, 100 if name == "c2" else 300)))
             finally:
                 engine.set_dense_threshold(prev)
