@@ -63,8 +63,10 @@ __device__ __forceinline__ void load_grow(const float *tg, const float *zrow, in
 // tiles are first summed into ONE LDS window (plain read-modify-write, one job at a time: LDS
 // fp32 atomics run at 0.4 lane-ops/clk/CU on gfx950, measured) and only that window goes to HBM
 // with fp32 atomics -- 3.5x fewer global atomics, which is what bounds this kernel.
+// One group of JOBS rows; `vb` plays blockIdx.x (the main kernel passes it, the tail kernel walks it).  Returns 1 when the
+// group ran (its LDS is in use), -1 when vb maps behind the last group.
 template <class G, int KHC>
-__global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
+__device__ __forceinline__ int bwd_tiled_group(const BwdParams &p, const int vb) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
   constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
   constexpr int JOBS = G::JOBS, PW = G::PW, S = G::GS, CHG = KS * S;  // G tile: row stride, size
@@ -90,19 +92,19 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  In tile order, job groups
   // g and g+1 update overlapping gradient pixels: give every XCD one contiguous range of groups so
   // that those atomics meet in one L2.
-  int grp = blockIdx.x;
+  int grp = vb;
   if (p.order && !SSG_DBG(p, 16)) {
     const int ng = (nrows + JOBS - 1) / JOBS, per = (ng + 7) >> 3;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xcd = vb & 7, idx = vb >> 3;
     grp = idx < per ? xcd * per + idx : ng;
   }
   const int job0 = grp * JOBS;
   if (job0 >= nrows) {
     if (p.mode == GRAD_LOSS && tid == 0) {
-      p.partials[2 * blockIdx.x] = 0.f;
-      p.partials[2 * blockIdx.x + 1] = 0.f;
+      p.partials[2 * vb] = 0.f;
+      p.partials[2 * vb + 1] = 0.f;
     }
-    return;
+    return -1;   // (every later workgroup index maps behind the last group as well)
   }
   if (tid < JOBS) {
     const int k = job0 + tid;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
   if (p.fix_inline && p.gfix) {   // (loss step on the direct-only path: no launch in front of this one computes the bound)
     const unsigned bb = __float_as_uint(loss_grad_bound(p.sigma, C, KW, p.w_l1, p.w_kl, p.upstream, rows_to_do(p.n_dev, p.n_host), P));
     gsc = grad_fix_scale_of(bb);
-    if (blockIdx.x == 0 && tid == 0) *(unsigned *)(p.gfix + (size_t)p.B * p.C * p.H * p.W) = bb;   // for grad_fix_flush
+    if (vb == 0 && tid == 0) *(unsigned *)(p.gfix + (size_t)p.B * p.C * p.H * p.W) = bb;   // for grad_fix_flush
   } else {
     gsc = grad_fix_scale(p.gfix, (size_t)p.B * p.C * p.H * p.W);
   }
@@ -204,8 +206,8 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
             t1 += red[2 * WG + k];
             t2 += red[2 * WG + 8 + k];
           }
-          p.partials[2 * blockIdx.x] = t1;
-          p.partials[2 * blockIdx.x + 1] = t2;
+          p.partials[2 * vb] = t1;
+          p.partials[2 * vb + 1] = t2;
         }
         dot = jsc[jl * 4 + 0];
 #pragma unroll
@@ -231,8 +233,8 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
       red2[tid] = ls;  // (the dot products were consumed before the barrier above)
     }
     if (p.mode == GRAD_LOSS && SSG_DBG(p, 1) && tid == 0) {  // (profiling ablation without criteria)
-      p.partials[2 * blockIdx.x] = 0.f;
-      p.partials[2 * blockIdx.x + 1] = 0.f;
+      p.partials[2 * vb] = 0.f;
+      p.partials[2 * vb + 1] = 0.f;
     }
     if (need_grad) {
     // centre windows A (reflect by index mirroring); loads of all jobs in flight together
@@ -546,6 +548,22 @@ __global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
     }  // need_grad
   }
 
+  return 1;
+}
+
+template <class G, int KHC>
+__global__ __launch_bounds__(G::WG) void ssg_bwd_tiled(BwdParams p) {
+  bwd_tiled_group<G, KHC>(p, (int)blockIdx.x);
+}
+// The workgroup indices from `first` on, walked by a small grid (see ssg_fwd_tiled_tail: the tail of a launch whose bound on
+// the rows is far above what the main launch covers with one workgroup per group).
+template <class G, int KHC>
+__global__ __launch_bounds__(G::WG) void ssg_bwd_tiled_tail(BwdParams p, int first) {
+#pragma unroll 1
+  for (int vb = first + (int)blockIdx.x;; vb += (int)gridDim.x) {
+    if (bwd_tiled_group<G, KHC>(p, vb) < 0) break;
+    __syncthreads();   // the group's LDS is rewritten by the next one
+  }
 }
 
 // Any odd (ks, kw): one 256-lane workgroup per edge pixel.
@@ -839,6 +857,7 @@ static size_t bwd_lds_bytes(int C) {
 }
 
 unsigned bwd_grid(const BwdParams &p);
+constexpr unsigned BWD_MAIN_GROUPS = 20480, BWD_TAIL_GRID = 512;   // (multiples of 8: the XCD-contiguous group mapping)
 
 template <class G, int KHC>
 static int launch_bwd_tiled(const BwdParams &p, hipStream_t st) {
@@ -848,6 +867,15 @@ static int launch_bwd_tiled(const BwdParams &p, hipStream_t st) {
   if (const int rc = ensure_dynamic_lds(ssg_bwd_tiled<G, KHC>, 160 * 1024, lds_set)) return rc;
   const unsigned grid = bwd_grid(p);
   if (p.n_host == 0) return 0;
+  // (a bound on the rows far above BWD_MAIN_GROUPS x JOBS: one workgroup per group up to there, the looping tail behind --
+  //  not where the workgroups' criteria sums have a slot each, GRAD_LOSS on the direct-only path)
+  if (grid > BWD_MAIN_GROUPS && !p.partials) {
+    static std::atomic<unsigned long long> lds_set_tail{0};
+    if (const int rc = ensure_dynamic_lds(ssg_bwd_tiled_tail<G, KHC>, 160 * 1024, lds_set_tail)) return rc;
+    hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(BWD_MAIN_GROUPS), dim3(G::WG), lds, st, p);
+    hipLaunchKernelGGL((ssg_bwd_tiled_tail<G, KHC>), dim3(BWD_TAIL_GRID), dim3(G::WG), lds, st, p, (int)BWD_MAIN_GROUPS);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(grid), dim3(G::WG), lds, st, p);
   return (int)hipGetLastError();
 }

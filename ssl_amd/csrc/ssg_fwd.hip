@@ -51,8 +51,10 @@ __device__ __forceinline__ void load_row(const float *tc, int rs, const float *z
 constexpr int SMALL_CALL_JOBS = 8192;
 __device__ __forceinline__ bool small_call(int njobs) { return njobs <= SMALL_CALL_JOBS; }
 
+// returns 1: the group ran here (its LDS is in use: barrier before the next one), 0: not this variant's group, -1: the
+// group lies behind the last job (so does every later one: a workgroup's loop ends)
 template <class G, bool MERGED>
-__device__ __forceinline__ bool fwd_tiled_group(const FwdParams &p, int grp) {
+__device__ __forceinline__ int fwd_tiled_group(const FwdParams &p, int grp) {
   constexpr int KS = G::KS, KW = G::KW, BS = G::BS, WG = G::WG;
   constexpr int HP = G::HP, HK = G::HK, P = G::P, NB = G::NB, LPJ = G::LPJ;
   constexpr int JOBS = G::JOBS, PW = G::PW, S = G::S, CH = G::CH;
@@ -70,7 +72,8 @@ __device__ __forceinline__ bool fwd_tiled_group(const FwdParams &p, int grp) {
 
   int tid_ = threadIdx.x;
   // (inside the k_s = 49 group loop: opaque to the optimiser, which would otherwise hoist the lane constants derived
-  // from it out of the loop and hold them across the whole body -- spills)
+  // from it out of the loop and hold them across the whole body -- spills.  The k_s <= 25 tail kernel loops too, rarely:
+  // its registers are its own business)
   if constexpr (G::KS >= 49) asm volatile("" : "+v"(tid_));
   const int tid = tid_;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
@@ -79,22 +82,22 @@ __device__ __forceinline__ bool fwd_tiled_group(const FwdParams &p, int grp) {
   const int npad = p.order ? (nrows + JOBS - 1) / JOBS * JOBS : nrows;
   const int njobs = npad * p.nimg;
   const int job0 = grp * JOBS;
-  if (job0 >= njobs) return false;
+  if (job0 >= njobs) return -1;
   int which0 = 0, k0 = 0;
   bool mergeable = false;
   if (p.order) {
     static_assert(!MERGED || JOBS == ORDER_GROUP, "order flags are computed for groups of ORDER_GROUP jobs");
     which0 = job0 / npad;
     k0 = job0 - which0 * npad;
-    if (k0 >= nrows) return false;                       // padding-only group
+    if (k0 >= nrows) return 0;                           // padding-only group
     mergeable = (p.order[k0] & ORDER_FLAG) != 0;         // one wave-uniform load decides the variant
   }
   // p.small: 0 = this launch is the only set of variants; 1 = this variant takes every group whatever its flag (the
   // small-call variant launched alone); 2 = regular and small-call variants were both launched and the device-side job
   // count picks (small_call() below)
   constexpr bool SMALLV = G::BS < 5 && G::KS == 25;
-  if (p.small == 2 && small_call(nrows * p.nimg) != SMALLV) return false;
-  if (!(SMALLV && p.small != 0) && mergeable != MERGED) return false;
+  if (p.small == 2 && small_call(nrows * p.nimg) != SMALLV) return -1;   // (the whole launch is the other class's)
+  if (!(SMALLV && p.small != 0) && mergeable != MERGED) return 0;
 
   if (tid < JOBS) {
     int row = -1, which = 0;
@@ -412,6 +415,8 @@ __device__ __forceinline__ bool fwd_tiled_group(const FwdParams &p, int grp) {
 // smaller.  k_s <= 25 keeps one group per workgroup (the loop and its register cost fold away).
 template <class G>
 constexpr int fwd_groups_per_wg() { return G::KS >= 49 ? 16 : 1; }
+// k_s <= 25: one workgroup per group up to this many groups (C2's bench bound is 31 k), a looping tail behind them
+constexpr unsigned FWD_MAIN_GROUPS = 40960, FWD_TAIL_GRID = 1024;
 
 template <class G, bool MERGED>
 __global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void ssg_fwd_tiled(FwdParams p) {
@@ -421,9 +426,24 @@ __global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void
   } else {
 #pragma unroll 1
     for (int g = 0; g < GPW; ++g) {
-      if (fwd_tiled_group<G, MERGED>(p, (int)blockIdx.x * GPW + g))
+      if (fwd_tiled_group<G, MERGED>(p, (int)blockIdx.x * GPW + g) > 0)
         __syncthreads();   // the group's LDS (job table, staging) is rewritten by the next one
     }
+  }
+}
+
+// The groups from `first` on, walked by a small grid with stride gridDim: the tail of a launch whose bound on the rows
+// (the caller's capacity) is far above what the main launch covers with one workgroup per group (FWD_MAIN_GROUPS).  Its
+// workgroups leave at the first group behind the last job the DEVICE count knows, i.e. at once unless the step really has
+// that many rows; the loop's registers (12 more: the merged variant would drop from 4 to 3 waves per SIMD) stay out of
+// the main kernel.
+template <class G, bool MERGED>
+__global__ __launch_bounds__(G::WG) __attribute__((amdgpu_waves_per_eu(2))) void ssg_fwd_tiled_tail(FwdParams p, int first) {
+#pragma unroll 1
+  for (int grp = first + (int)blockIdx.x;; grp += (int)gridDim.x) {
+    const int r = fwd_tiled_group<G, MERGED>(p, grp);
+    if (r < 0) break;
+    if (r > 0) __syncthreads();
   }
 }
 
@@ -500,7 +520,16 @@ static int launch_fwd_tiled(const FwdParams &p, hipStream_t st) {
   const long njobs = per_img * p.nimg;
   if (njobs == 0) return 0;
   const long ngroups = (njobs + G::JOBS - 1) / G::JOBS;
-  const unsigned grid = (unsigned)((ngroups + fwd_groups_per_wg<G>() - 1) / fwd_groups_per_wg<G>());
+  unsigned grid = (unsigned)((ngroups + fwd_groups_per_wg<G>() - 1) / fwd_groups_per_wg<G>());
+  if constexpr (fwd_groups_per_wg<G>() == 1) {
+    if (grid > FWD_MAIN_GROUPS) {   // (a generous capacity: the groups behind FWD_MAIN_GROUPS go to the looping tail)
+      static std::atomic<unsigned long long> lds_set_tail{0};
+      if (const int rc = ensure_dynamic_lds(ssg_fwd_tiled_tail<G, MERGED>, 160 * 1024, lds_set_tail)) return rc;
+      hipLaunchKernelGGL((ssg_fwd_tiled<G, MERGED>), dim3(FWD_MAIN_GROUPS), dim3(G::WG), lds, st, p);
+      hipLaunchKernelGGL((ssg_fwd_tiled_tail<G, MERGED>), dim3(FWD_TAIL_GRID), dim3(G::WG), lds, st, p, (int)FWD_MAIN_GROUPS);
+      return (int)hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((ssg_fwd_tiled<G, MERGED>), dim3(grid), dim3(G::WG), lds, st, p);
   return (int)hipGetLastError();
 }

@@ -367,8 +367,8 @@ class LossStep:
     the fused step (materialise=False) four row regions in its workspace instead of two.  tile_major=False leaves the
     regions out of a materialising step's workspace: the row-major kernels run (C5: 8.4 instead of 7.3 ms per step).
     A step that finds more edge pixels than `capacity` returns NaN losses (it has used the first `capacity` only).
-    `capacity` also sizes the direct kernels' grids: the default (every pixel, never overflows) costs the C2 step 6 % and
-    the C4 step 10 % against a bound near the real count (bench.py: N + 1024; 3 x N: < 1 %) -- tools/r5_capacity_cost.py.
+    The default capacity (every pixel, never overflows) costs the C2 step ~2 % and the C4 step ~5 % against a bound near
+    the real count (bench.py: N + 1024) -- tools/r5_capacity_cost.py; the workspace grows with it.
 
     graph=True records the step's ~17 launches (memset, edge-list builder, two forward variants,
     backward, finalize) into a HIP graph on first use and replays it afterwards: nothing in the

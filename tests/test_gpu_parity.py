@@ -798,6 +798,35 @@ def test_every_tile_through_the_dense_kernels_and_no_side_stream(dev):
         engine.set_overlap(prev_ov)
 
 
+def test_direct_kernels_beyond_their_main_grid(dev):
+    """The (25,9) direct forward launches one workgroup per group of five jobs up to 40,960 groups and a looping tail kernel
+    behind them (ssg_fwd.hip: a generous capacity must not cost a workgroup per dead group).  A batch whose rows really
+    reach into the tail -- 2 x 256 x 256 at 90 % density, every row through the direct kernels (threshold 0): 47 k groups --
+    against the same step with dense tiles: SSG rows to 2e-6, losses to 1e-5."""
+    from ssl_amd import engine, synth
+    B, H, W = 2, 256, 256
+    sr, gt, _ = synth.make_batch(B, H, W, seed0=3100)
+    rng = np.random.default_rng(31)
+    m = (rng.random((B, 1, H, W)) < 0.9).astype(np.float32)
+    n = int(m.sum())
+    assert 2 * n // 5 > 40960
+    res = []
+    for thr in (0, 18):
+        prev = engine.set_dense_threshold(thr)
+        try:
+            step = engine.LossStep(B, 3, H, W, 25, 9, 0.05, 1e-10, True, 1e3, 1e3, device=dev, capacity=n + 64)
+            loss, grad = step(T(sr, dev), T(gt, dev), T(m, dev))
+            assert int(step.counts[0]) == n
+            res.append((loss.cpu().numpy().copy(), grad.cpu().numpy().copy(), step.ssg_sr[:n].cpu().numpy().copy(),
+                        step.ssg_gt[:n].cpu().numpy().copy()))
+        finally:
+            engine.set_dense_threshold(prev)
+    (l0, g0, a0, b0), (l1, g1, a1, b1) = res
+    assert maxerr(a0, a1) <= 2e-6 and maxerr(b0, b1) <= 2e-6
+    assert np.all(np.abs(l0 - l1) <= 1e-5 * np.abs(l1))
+    assert maxerr(g0, g1) <= 2e-3 * np.abs(g1).max()
+
+
 def test_stream_assignment_follows_the_last_plan(dev):
     """ssg_set_overlap(3), the default: the edge-list builder leaves {rows for the direct kernels, dense tiles} of its
     plan in host-mapped memory and the next forked pass keeps the branch expected to run longer on the caller's stream
