@@ -300,6 +300,32 @@ def cpu_baseline(cfg, sr, gt, mask, budget_s=20.0):
             "l1": r["l1"], "kl": r["kl"]}
 
 
+def reference_cpu_record(config_key):
+    """The reference's OWN ssl_pytorch (loss_util.py:182-229) + L1 + KL + backward timed by import in the build container
+    (SURVEY 8(d) 'CPU baseline beside it' (1); tests/golden/make_golden.py timegrid -> tests/golden/
+    reference_cpu_timing.json, a committed record: the reference's Python never travels to the GPU box).  Quoted beside
+    the live `cpu_baseline` (the C/OpenMP port on this box's cores); None without a record for the configuration."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "reference_cpu_timing.json")) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if config_key == "c5" and "c5_chunks" in t:
+        c = t["c5_chunks"]
+        return {"value": c["extrapolated_edge_px_per_s"], "unit": "edge-px/s", "cores": t.get("cores"), "extrapolated": True,
+                "sample": "mask chunks of %s edge px of one 3x512x512 image, t = a + b N scaled to N = 262,144 (%.0f s per step)"
+                          % ("/".join(str(k["n_edges"]) for k in c["chunks"]), c["extrapolated_full_step_s"]),
+                "where": "build container (no GPU), torch %s CPU, %s threads" % (t.get("torch"), t.get("torch_threads"))}
+    r = t.get(config_key)
+    if not r or "edge_px_per_s" not in r:
+        return None
+    return {"value": r["edge_px_per_s"], "unit": "edge-px/s", "cores": t.get("cores"), "extrapolated": False,
+            "sample": "%d edge px%s, median of 3 after warm-up: %.3f s" % (
+                r["n_edges"], " (%d images one after the other)" % r["images"] if "images" in r else "",
+                r.get("median_pass_s", r.get("median_after_warmup_s", 0.0))),
+            "where": "build container (no GPU), torch %s CPU, %s threads" % (t.get("torch"), t.get("torch_threads"))}
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/pmc_traffic.json, produced by
     tools/r*_final.sh with the guide's unit / gfx950 corrections); None if there is no entry for this kernel."""
@@ -315,7 +341,9 @@ def pmc_step_bytes(config_key):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ks = [k for k in json.load(f).get("kernels", {}).values() if k.get("config") == config_key]
-        tot = sum(k.get("hbm_bytes_per_launch", 0.0) for k in ks)
+        # (a kernel that runs more than once per step -- ssg_grad_rows: one pass per chain -- counts that often:
+        # `launches_per_step` = dispatches / steps of the kernel-trace next to the PMC pass, tools/pmc_to_json.py)
+        tot = sum(k.get("hbm_bytes_per_launch", 0.0) * k.get("launches_per_step", 1.0) for k in ks)
         return tot or None
     except (OSError, ValueError):
         return None
@@ -368,9 +396,9 @@ def pmc_issue(config_key, step_gpu_ms):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ks = [k for k in json.load(f).get("kernels", {}).values() if k.get("config") == config_key]
-        insts = sum(k.get("valu_insts_per_launch", 0.0) for k in ks)
-        lds = sum(k.get("lds_active_cycles_per_launch", 0.0) for k in ks)
-        hbm = sum(k.get("hbm_bytes_per_launch", 0.0) for k in ks)
+        insts = sum(k.get("valu_insts_per_launch", 0.0) * k.get("launches_per_step", 1.0) for k in ks)
+        lds = sum(k.get("lds_active_cycles_per_launch", 0.0) * k.get("launches_per_step", 1.0) for k in ks)
+        hbm = sum(k.get("hbm_bytes_per_launch", 0.0) * k.get("launches_per_step", 1.0) for k in ks)
         if not insts:
             return None
         valu_ms = insts * VALU_CYCLES_PER_INST / N_SIMD / CLOCK_HZ * 1e3
@@ -851,6 +879,9 @@ def main():
                                      "reference-equivalent flops and may exceed the peak -- NOT a utilisation "
                                      "(`issued` prices the instructions actually issued)",
                              "issued": pmc_issue(args.config, step_gpu_ms)}}
+            # SURVEY 8(d)'s own definition as a scalar next to `frac` (which divides by the DOMINANT KERNEL's duration):
+            # algorithmic bytes of the step x steps per second of the TIMED region / 8 TB/s
+            res["roofline"]["step_frac"] = b_alg * value / 1e9 / HBM_PEAK_GBS
             if not args.no_module and not args.no_ssg_output:
                 mm = module_time_ms(cfg, sr, gt, mask, n_edges, it if cfg["dense_mask"] else max(it, 30))
                 res["module"] = {"what": "ssl_amd.SSGLoss forward + autograd backward (drop-in path)",
@@ -870,6 +901,9 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg, sr_np, gt_np, mask_np)
                 res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+                ref = reference_cpu_record(args.config)
+                if ref:
+                    res["cpu_baseline"]["reference_ssl_pytorch"] = dict(ref, gpu_over_reference=value / ref["value"])
         print(json.dumps(res))
     if use_dist:
         dist.barrier()

@@ -551,6 +551,88 @@ def cpu_reference_timing():
     print("  ", res)
 
 
+def cpu_reference_timing_grid():
+    """SURVEY section 8(d) 'CPU baseline beside it' (1): the reference's own ssl_pytorch
+    (loss_util.py:182-229) + L1 + KL + backward, timed in the build container by import:
+      c2  all 16 images of the C2 batch, one after the other (each image runs
+          fwd(SR) + fwd(GT) + L1 + KL + backward before the next: the reference's loop keeps all
+          16 graphs alive until one backward, >= 51 GB of saved unfold tensors, which the
+          container's 62 GB without swap cannot hold; the arithmetic is the same);
+      c1  the 64x64 / 209-pixel plumbing case, directly;
+      c5  3x512x512, (49,13): mask chunks of 512 and 1024 pixels (a 4096-pixel chunk needs 4 x 20 GB of
+          unfold intermediates), fitted t = a + b*N and scaled to N = 262,144: EXTRAPOLATED.
+    1 warm-up + median of 3 (c2: 1 warm-up image + every image once per pass, 3 passes)."""
+    import json
+    torch.set_num_threads(os.cpu_count())
+    out = dict(cores=os.cpu_count(), torch_threads=torch.get_num_threads(), torch=torch.__version__,
+               what="reference ssl_pytorch fwd(SR)+fwd(GT)+L1+KL+backward by import of loss_util.py, fp32, w=1e3")
+    path = os.path.join(HERE, "reference_cpu_timing.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            old = json.load(f)
+        out["one_image_round1"] = old.get("one_image_round1", {k: old[k] for k in
+                                          ("n_edges", "seconds", "median_after_warmup_s", "edge_px_per_s") if k in old})
+
+    def timed(fn, reps=3, warm=1):
+        ts = []
+        for it in range(warm + reps):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return ts, float(np.median(ts[warm:]))
+
+    # ---- C1
+    sr, gt, mask = synth.uniform_case()
+    n1 = int(mask.sum())
+    ts, med = timed(lambda: caller_loop(sr, gt, mask, 11, 5, 1.0, True, 1e3, 1e3, torch.float32), reps=5)
+    out["c1"] = dict(n_edges=n1, seconds=ts, median_after_warmup_s=med, edge_px_per_s=n1 / med)
+    print("   c1", out["c1"], flush=True)
+
+    # ---- C2: 16 images sequentially
+    srs, gts, masks = synth.make_batch()
+    ns = [int(m.sum()) for m in masks]
+    caller_loop(srs[:1], gts[:1], masks[:1], 25, 9, 1.0, True, 1e3, 1e3, torch.float32)      # warm-up
+    passes = []
+    for p in range(3):
+        per = []
+        for i in range(len(ns)):
+            t0 = time.time()
+            caller_loop(srs[i:i + 1], gts[i:i + 1], masks[i:i + 1], 25, 9, 1.0, True, 1e3, 1e3, torch.float32)
+            per.append(time.time() - t0)
+        passes.append(per)
+        print(f"   c2 pass {p}: {sum(per):.1f}s for {sum(ns)} edge px", flush=True)
+    tot = [float(sum(p)) for p in passes]
+    med = float(np.median(tot))
+    out["c2"] = dict(images=len(ns), n_edges=int(sum(ns)), n_edges_per_image=ns, pass_seconds=tot,
+                     per_image_seconds=passes, median_pass_s=med, edge_px_per_s=sum(ns) / med,
+                     note="images one after the other, backward per image (memory: see docstring)")
+    print("   c2", {k: out["c2"][k] for k in ("n_edges", "pass_seconds", "edge_px_per_s")}, flush=True)
+
+    # ---- C5 chunks
+    gt5 = synth.natural_like(500, 512, 512)[None]
+    sr5 = synth.degrade(gt5[0], 10_500)[None]
+    fits = []
+    for nchunk in (512, 1024):
+        m = np.zeros((1, 1, 512, 512), np.float32)
+        m.reshape(-1)[256 * 512 - nchunk // 2: 256 * 512 + nchunk // 2] = 1.0   # rows in the middle of the image
+        ts, med = timed(lambda: caller_loop(sr5, gt5, m, 49, 13, 1.0, True, 1e3, 1e3, torch.float32), reps=3)
+        fits.append((nchunk, med, ts))
+        print(f"   c5 chunk {nchunk}: {ts}", flush=True)
+    (na, ta, _), (nb, tb, _) = fits
+    b = (tb - ta) / (nb - na)
+    a = ta - b * na
+    full = a + b * 512 * 512
+    out["c5_chunks"] = dict(chunks=[dict(n_edges=n, seconds=ts, median_after_warmup_s=t) for n, t, ts in fits],
+                            fit_fixed_s=a, fit_per_edge_px_s=b, n_full=512 * 512,
+                            extrapolated_full_step_s=full, extrapolated_edge_px_per_s=512 * 512 / full,
+                            extrapolated=True,
+                            note="the reference cannot run C5 whole (1.28 TB intermediate): t = a + b*N fitted on two "
+                                 "mask chunks of one 3x512x512 image, scaled linearly in N")
+    print("   c5", out["c5_chunks"], flush=True)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def f12_usm():
     """F12: the reference's USMSharp (basicsr/utils/img_process_util.py:63-83), imported by path
     and run on the CPU (fp32).  `cv2` is not installed; the module's only cv2 call on this path is
@@ -935,3 +1017,5 @@ if __name__ == "__main__":
         f17_feed_data()
     if "time" in which:
         cpu_reference_timing()
+    if "timegrid" in which:
+        cpu_reference_timing_grid()

@@ -60,26 +60,39 @@ class Generator(nn.Module):
         return self.last(F.leaky_relu(self.hr(f), 0.2))
 
 
-def _time_steps(step, flag, n=4, repeats=3):
-    """Best of `repeats` timings of n steps (a fresh box ramps its clocks during the first seconds: one sample of 4
-    steps of a 55 ms generator step has swung by 25 % between the two flags)."""
-    for _ in range(2):
-        step(flag)
-    best = float("inf")
-    for _ in range(repeats):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
+def _paired_steps(step, pairs=20):
+    """Interleaved measurement (A B A B ...): `pairs` times one step WITHOUT and one step WITH the SSL terms, each
+    bracketed by a synchronise.  Two back-to-back blocks of a 50 ms step differ by more than the 0.5 ms under test on a
+    box that is still settling its clocks (round 5's driver run recorded a negative share that way); paired steps see the
+    same clock.  Returns the medians, the median of the paired differences and its spread (quartiles)."""
+    for _ in range(3):
+        step(False)
+        step(True)
+    a, b = [], []
+    for _ in range(pairs):
+        for flag, dst in ((False, a), (True, b)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             step(flag)
-        torch.cuda.synchronize()
-        best = min(best, (time.perf_counter() - t0) / n * 1e3)
-    return best
+            torch.cuda.synchronize()
+            dst.append((time.perf_counter() - t0) * 1e3)
+    d = sorted(y - x for x, y in zip(a, b))
+    med = lambda v: sorted(v)[len(v) // 2]
+    return dict(base=med(a), ssl=med(b), diff=med(d), diff_q1=d[len(d) // 4], diff_q3=d[(3 * len(d)) // 4], pairs=pairs)
 
 
-def c3_step_share(dev, batch=4, n=4, check=None):
+def _share(t, **kw):
+    """One `extra.c*_step_share` record from _paired_steps' figures: `ssl_ms` is the median PAIRED difference (not the
+    difference of the medians), `ssl_share` = ssl_ms / median step with SSL."""
+    return dict(step_ms_without_ssl=t["base"], step_ms_with_ssl=t["ssl"], ssl_ms=t["diff"],
+                ssl_ms_quartiles=[t["diff_q1"], t["diff_q3"]], ssl_share=t["diff"] / t["ssl"], pairs=t["pairs"],
+                how="A B A B interleaved single steps, median of the paired differences", **kw)
+
+
+def c3_step_share(dev, batch=4, pairs=20, check=None):
     """BASELINE configs[2] per GPU (bs 32 over 8 GPUs = 4 GT crops of 256 x 256): one generator step of the RRDBNet-shaped
     stand-in (fp32, Adam) with pixel L1 only and with the SSG loss where the reference's per-image loop sits
-    (realesrganssl_model.py:379-430: sigma 0.004, weights 1e3).  Interleaved twice, best of three blocks each."""
+    (realesrganssl_model.py:379-430: sigma 0.004, weights 1e3).  Timed as interleaved single steps (_paired_steps)."""
     torch.manual_seed(0)
     net = Generator().to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
@@ -100,16 +113,14 @@ def c3_step_share(dev, batch=4, n=4, check=None):
         loss.backward()
         opt.step()
 
-    base, ssl = _time_steps(step, False, n), _time_steps(step, True, n)
-    base, ssl = min(base, _time_steps(step, False, n)), min(ssl, _time_steps(step, True, n))
+    t = _paired_steps(step, pairs)
     if check is not None:
         check(net, last, gt, mask)
-    return dict(step_ms_without_ssl=base, step_ms_with_ssl=ssl, ssl_ms=ssl - base, ssl_share=(ssl - base) / ssl,
-                edge_px=int(mask_np.sum()),
+    return _share(t, edge_px=int(mask_np.sum()),
                 what=f"RRDBNet-shaped x4 generator (23 RRDB, fp32, Adam), {batch} x 3x256x256 GT, SSL (25,9) sigma 0.004 w 1e3")
 
 
-def c4_step_share(dev, n=4, check=None):
+def c4_step_share(dev, pairs=20, check=None):
     """BASELINE configs[3] per GPU (bs 8 over 4 GPUs = 2 crops of 512 x 512): the tail of the LDM-SR step -- a stand-in
     decoder producing 2 x 3x512x512 from a 4x64x64 latent, 0.1 pixel L1 (ddpmssl.py:424-425) -- with and without SSL on
     the decoded image (mask_stride 3, eps 1e-20, weights 5e2: configs/StableSRISSLStage1/*.yml:32-41,268-277)."""
@@ -135,23 +146,21 @@ def c4_step_share(dev, n=4, check=None):
         loss.backward()
         opt.step()
 
-    base, ssl = _time_steps(step, False, n), _time_steps(step, True, n)
-    base, ssl = min(base, _time_steps(step, False, n)), min(ssl, _time_steps(step, True, n))
+    t = _paired_steps(step, pairs)
     if check is not None:
         check(dec)
-    return dict(step_ms_without_ssl=base, step_ms_with_ssl=ssl, ssl_ms=ssl - base, ssl_share=(ssl - base) / ssl,
-                edge_px=int(crit.last_counts[0]),
+    return _share(t, edge_px=int(crit.last_counts[0]),
                 what="stand-in decoder tail (4x64x64 latent -> 2 x 3x512x512), 0.1 pixel L1, SSL (25,9) stride 3 eps 1e-20 w 5e2")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)      # C3: bs 32 over 8 GPUs
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--pairs", type=int, default=20)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     import json
-    print(json.dumps({"c3": c3_step_share(dev, args.batch, args.steps), "c4": c4_step_share(dev, args.steps)}, indent=1))
+    print(json.dumps({"c3": c3_step_share(dev, args.batch, args.pairs), "c4": c4_step_share(dev, args.pairs)}, indent=1))
 
 
 if __name__ == "__main__":
