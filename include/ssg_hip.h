@@ -277,7 +277,13 @@ size_t ssg_grad_fix_bytes(int B, int C, int H, int W);
  * (nullable) points at two DEVICE floats {dL/dl1, dL/dkl} that scale the two
  * criteria's gradients (autograd's incoming gradients, read on device so the
  * host never synchronises); null means {1,1}.
- * loss_out: 2 floats {l1, kl} on device.  scratch: ssg_loss_scratch_bytes(B,H,W,n_rows,ks). */
+ * loss_out: 2 floats {l1, kl} on device.  scratch: ssg_loss_scratch_bytes(B,H,W,n_rows,ks).
+ * PRECONDITION of the deterministic mode (grad_fix != NULL) at k_s <= 25: the rows are SSG rows -- every entry of
+ * ssg_sr / ssg_gt in [0, 1] and every ssg_gt row summing to at most 1 (true for whatever ssg_map_forward produces,
+ * normalised or not).  The fixed-point scale of the gradient sums is then taken from the a-priori bound
+ * |dL/dD| <= 4 (|w_l1| u_1 + |w_kl| u_2) / (sigma C k_w^2 n k_s^2) instead of a maximum over the rows (no reduction
+ * pass); rows outside those ranges (foreign tensors) can exceed the bound and wrap the 64-bit sums silently -- pass
+ * grad_fix = NULL (fp32 atomics) for such input.  k_s = 49 with tile-major rows keeps the exact maximum. */
 size_t ssg_loss_scratch_bytes(int B, int H, int W, int n_rows, int ks);
 int ssg_loss_backward(const float *sr, int B, int C, int H, int W,
                       const int *edges, const int *tile_order /* nullable */,

@@ -206,7 +206,7 @@ static bool two_chains_allowed();
 struct PlanHint {
   int *host = nullptr, *dev = nullptr;
 };
-static PlanHint plan_hint() {
+static PlanHint plan_hint(bool allocate_never = false) {
   constexpr int MAXDEV = 64;
   static std::mutex mu;
   static PlanHint tab[MAXDEV];
@@ -214,6 +214,10 @@ static PlanHint plan_hint() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return PlanHint{};
   std::lock_guard<std::mutex> lk(mu);
   if (!tab[dev].host) {
+    // hipHostMalloc is not allowed while the calling stream is being captured (it fails, and in the global / thread-local
+    // capture modes invalidates the capture): the block is allocated by the first call per device made OUTSIDE capture;
+    // a first call under capture runs without a hint (gated chains, dense kernels on the caller's stream).
+    if (allocate_never) return PlanHint{};
     void *h = nullptr, *d = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return PlanHint{};
     ((int *)h)[0] = ((int *)h)[1] = -1;   // nothing seen yet
@@ -226,7 +230,12 @@ static PlanHint plan_hint() {
   return tab[dev];
 }
 namespace ssg {
-int *plan_hint_device_word() { return overlap_mode() == 3 ? plan_hint().dev : nullptr; }
+int *plan_hint_device_word(hipStream_t st) {
+  if (overlap_mode() != 3) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  return plan_hint(capturing).dev;
+}
 }
 // the two streams of a forked pass: .dense takes the dense-tile kernel, .direct the direct one
 struct StreamPair {
@@ -238,7 +247,7 @@ static StreamPair assign_streams(hipStream_t st, hipStream_t st2) {
   if (mode == 3) {
     // whole-chip costs at (25,9), MI355X: a dense tile 0.74 us through forward + backward, a direct row 38 ns
     mode = 1;
-    const PlanHint h = plan_hint();
+    const PlanHint h = plan_hint(true);   // (readers never allocate: the builder's launch does, outside capture)
     if (h.host) {
       const int n_sparse = ((volatile int *)h.host)[0], n_tiles = ((volatile int *)h.host)[1];
       if (n_sparse >= 0 && n_tiles >= 0 && (long long)n_sparse * 38 > (long long)n_tiles * 740) mode = 2;
@@ -261,7 +270,7 @@ static bool two_chains_wanted() {    // free-running (true) or gated (false)
   static const int sw = env_int("SSG_TWO_CHAINS", 1);
   if (sw != 1) return sw == 2;
   if (overlap_mode() != 3) return false;
-  const PlanHint h = plan_hint();
+  const PlanHint h = plan_hint(true);
   if (!h.host) return false;
   const int n_sparse = ((volatile int *)h.host)[0], n_tiles = ((volatile int *)h.host)[1];
   if (n_sparse < 0 || n_tiles < 0) return false;
@@ -469,15 +478,18 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   // A backward on its own (ssg_loss_backward: the deferred loop's node, the module) forks HERE and runs the same two
   // chains from the row passes on: the sparse list's pass beside the dense-tile rows' instead of behind it.
   ForkChain local;
+  // (the hint is written by the GPU asynchronously: ONE read per decision, or a flip between two reads could record a
+  // gated pair into a capturing stream)
+  const bool free_wanted = two_chains_wanted();
   if (!(chain && chain->active) && classes && p.grad && !(dbg_mask() & ((1 << 27) | (1 << 28) | (1 << 29))) &&
-      two_chains_allowed() && (two_chains_wanted() || !stream_capturing(st))) {
+      two_chains_allowed() && (free_wanted || !stream_capturing(st))) {
     SideStream *fk0 = nullptr;
     hipStream_t st20 = fork_from(st, p.ks, fk0);
     if (fk0 && st20 != st) {
       local.fk = fk0;
       local.sp = assign_streams(st, st20);
       local.active = true;
-      local.gated = !two_chains_wanted();
+      local.gated = !free_wanted;
       chain = &local;
     }
   }
@@ -1277,9 +1289,10 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   const bool zero_fix = grad_fix && grad_sr;
   // two chains (ForkChain): sizes with a dense / direct split and a side stream to put one of them on
   // (under capture only the free-running chains: a GATED pair replays badly, see stream_capturing)
+  const bool free_wanted = two_chains_wanted();   // (one read of the asynchronously written hint per decision)
   const bool two_chains = defer && grad_sr && ks <= 25 && overlap_enabled() && two_chains_allowed() &&
-                          (two_chains_wanted() || !stream_capturing((hipStream_t)stream));
-  const bool free_running = two_chains && two_chains_wanted();
+                          (free_wanted || !stream_capturing((hipStream_t)stream));
+  const bool free_running = two_chains && free_wanted;
   const size_t fix_bytes = sizeof(long long) * ((size_t)B * C * H * W + 8), rs_bytes = 2 * sizeof(double) * (size_t)capacity;
   int rc = edge_list_impl(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H,
                           W, mask_stride, lap_threshold, ks, edges, capacity, counts, rank, order, plan, escratch,

@@ -919,7 +919,7 @@ size_t edge_scratch_bytes(int B, int H, int W) {
   return chunked > banded ? chunked : banded;
 }
 
-int *plan_hint_device_word();   // ssg_api.hip: host-mapped {rows for the direct kernels, dense tiles} of the device's last plan
+int *plan_hint_device_word(hipStream_t st);   // ssg_api.hip: host-mapped {rows for the direct kernels, dense tiles} of the device's last plan
 
 static bool banded_enabled() {
   static const bool on = env_int("SSG_EDGE_BANDED", 1) != 0;   // (profiling build only: the chunked builder for every call)
@@ -966,7 +966,7 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
     int *order_out = plan ? plan + fwd_plan_order_offset(B, H, W) : order;
     hipLaunchKernelGGL(band_count, dim3(grid), dim3(256), 0, st, p, nseg, segcnt, tcnt, bits, z);
     hipLaunchKernelGGL(band_scan, dim3(1), dim3(1024), 0, st, B, H, W, nseg, segcnt, segoff, counts, capacity, bits, tcnt, toff,
-                       dense_thr, plan ? dflag : nullptr, plan, plan ? plan_hint_device_word() : nullptr);
+                       dense_thr, plan ? dflag : nullptr, plan, plan ? plan_hint_device_word(st) : nullptr);
     // (the merge flags of the groups are set by the scatter pass itself: three launches)
     hipLaunchKernelGGL(band_scatter, dim3(grid), dim3(256), 0, st, p, nseg, segoff, bits, edges, capacity, rank, toff,
                        plan ? dflag : nullptr, order_out, plan ? plan : counts);

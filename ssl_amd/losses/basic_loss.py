@@ -146,10 +146,12 @@ class SSGLoss(nn.Module):
     the (B,C,H,W) gradient for backward.  At k_s = 49 the workspace holds FOUR row regions (two
     row-major, two tile-major: ssg_loss_rows_bytes in include/ssg_hip.h): 4 * capacity * 2401 * 4
     bytes = 10 GB at capacity 512 x 512; size `capacity` accordingly for dense masks at that size.  `capacity` bounds the number of edge pixels of a call
-    without a host round trip.  Default (capacity=None): a quarter of the call's pixels, divided by
-    mask_stride (edge masks are ~7 % dense; computed per call, so a small first batch does not pin it) or the largest count
-    seen so far plus 1/8, whichever is larger.  DENSE masks (mask_stride patterns over textured
-    crops, the 100 % stress mask) need `capacity=B*H*W` -- or rely on the checks below:
+    without a host round trip.  Default (capacity=None): B*H*W / (4 * max(1, mask_stride)) -- a quarter of the call's pixels
+    (edge masks are ~7 % dense), and the stride pattern keeps 1 / stride of those; computed per call, so a small first
+    batch does not pin it -- or the largest count seen so far plus 1/8, whichever is larger.  The default therefore
+    overflows on the FIRST call for any mask that is more than 25 % dense before striding: pass `capacity=B*H*W //
+    max(1, mask_stride)` for dense strided masks and `capacity=B*H*W` for the 100 % stress mask -- or rely on the checks
+    below (one host synchronisation plus a second full step for the first call, and again after each growth):
       * the first `sync_checks` calls (default 2), and the call after any overflow, read the edge
         count back in the same step (one host synchronisation of a 4-byte copy); a call found
         truncated is RECOMPUTED at the grown capacity before forward() returns, so its losses

@@ -39,8 +39,23 @@ from .. import _lib, engine
 _ptr, _stream, _f32c = engine._ptr, engine._stream, engine._f32c
 
 _LAZY = os.environ.get("SSG_LAZY", "1") not in ("", "0")
-_handles_since_step = 0      # LazySSG handles created since the last batched step ran (the eager-cliff warning below)
-_warned_eager = False
+# The eager-cliff warning (LazySSG._compute): rows computed image by image cost several times the batched step.  It is
+# raised PER HANDLE -- when a handle that torch.cat made of >= 2 per-image parts materialises, or when a second distinct
+# handle materialises before a batched step has run -- and rate-limited PER CALL SITE (the first frame outside this
+# package), so an intended eager use (eval code reading .shape, 3-channel masks that differ) warns once where it
+# happens and a later regression somewhere else in the program still gets reported.
+_materialised_since_step = set()   # ids of the distinct handles materialised since the last batched step
+_warned_sites = {}                 # (file, line) -> number of warnings suppressed there
+_WARN_PER_SITE = 1
+
+
+def _call_site():
+    import sys
+    f = sys._getframe(2)
+    here = os.path.dirname(os.path.abspath(__file__))
+    while f is not None and os.path.dirname(os.path.abspath(f.f_code.co_filename)).startswith(os.path.dirname(here)):
+        f = f.f_back
+    return (f.f_code.co_filename, f.f_lineno) if f is not None else ("?", 0)
 
 
 def set_lazy(on):
@@ -151,25 +166,27 @@ class LazySSG(_Lazy):
 
     _len0 = 1
 
-    def __init__(self, parts, cfg):
-        global _handles_since_step
+    def __init__(self, parts, cfg, from_cat=False):
         self.parts = list(parts)
         self.cfg = tuple(cfg)
+        self.from_cat = bool(from_cat)   # made by torch.cat of per-image handles (the reference loop's batch)
         self._pairs = {}     # id(target handle) -> (target handle, (l1 mean, kl mean)) of the fused step
-        _handles_since_step += 1
 
     def _compute(self):
         from .loss_util import eager_rows
-        global _warned_eager
-        if _handles_since_step >= 2 and not _warned_eager:
-            # several handles were created and one of them is now used in a way the batched step does not cover: the
-            # rows of every image are computed one launch at a time from here on (C2: 7 ms instead of 2.9 per loop)
-            _warned_eager = True
-            warnings.warn("ssl_amd: a deferred SSG handle is being materialised inside a per-image loop (it was used in "
-                          "a way other than torch.cat / L1Loss / KLDistanceLoss on equal settings); the rows are computed "
-                          "eagerly per image from here on -- same values, several times the batched step's cost.  "
-                          "set_lazy(False) / SSG_LAZY=0 silences this by always returning tensors.", RuntimeWarning,
-                          stacklevel=3)
+        _materialised_since_step.add(id(self))
+        if (self.from_cat and len(self.parts) >= 2) or len(_materialised_since_step) >= 2:
+            # a batch of per-image handles (or a second handle of a loop) is used in a way the batched step does not
+            # cover: its rows are computed one image at a time (C2: 7 ms instead of 2.9 per loop)
+            site = _call_site()
+            seen = _warned_sites.get(site, 0)
+            _warned_sites[site] = seen + 1
+            if seen < _WARN_PER_SITE:
+                warnings.warn_explicit("ssl_amd: deferred SSG rows of %d image(s) are being computed eagerly, one image at a "
+                              "time (the handle was used in a way other than torch.cat / L1Loss / KLDistanceLoss on "
+                              "equal settings) -- same values, several times the batched step's cost.  "
+                              "set_lazy(False) / SSG_LAZY=0 returns plain tensors everywhere and silences this."
+                              % len(self.parts), RuntimeWarning, site[0], site[1])
         rows = [eager_rows(img, mask, conv, *self.cfg) for img, mask, conv in self.parts]
         return rows[0] if len(rows) == 1 else torch.cat(rows, dim=1)
 
@@ -231,7 +248,7 @@ def _h_cat(tensors, dim=0, **kw):
         return NotImplemented
     if any(t.cfg != tensors[0].cfg for t in tensors):
         return NotImplemented
-    return LazySSG([p for t in tensors for p in t.parts], tensors[0].cfg)
+    return LazySSG([p for t in tensors for p in t.parts], tensors[0].cfg, from_cat=True)
 
 
 def _h_l1(input, target, size_average=None, reduce=None, reduction='mean', **kw):
@@ -385,6 +402,5 @@ def fused_losses(pred, target, deterministic=None):
     nan = torch.full((), float("nan"), dtype=l1u.dtype, device=l1u.device)
     out = (torch.where(bad, nan, l1u), torch.where(bad, nan, klu), count * mult)
     pred._pairs[id(target)] = (target, out)
-    global _handles_since_step
-    _handles_since_step = 0
+    _materialised_since_step.clear()
     return out

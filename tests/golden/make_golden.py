@@ -22,6 +22,7 @@ Only DATA is stored (inputs, expected outputs); no reference source text.
 import importlib.util
 import os
 import sys
+sys.dont_write_bytecode = True   # importing the reference by path must not leave a __pycache__ in /root/reference (read-only by contract)
 import time
 import types
 

@@ -205,19 +205,23 @@ def test_len_bool_and_comparisons_of_a_handle(lazy_on_cpu):
     e = F.l1_loss(a, b, reduction='none')
     assert len(e) == 1 and e._t is None and len(torch.clamp(input=a, min=1e-10)) == 1 and a._t is None
     assert {a: 1}[a] == 1 and a._t is None                       # hashable by identity
-    lazy_on_cpu._warned_eager = False
+    lazy_on_cpu._warned_sites.clear()
+    lazy_on_cpu._materialised_since_step.clear()
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
-        eq = a == a.materialise()
-        assert any("materialised inside a per-image loop" in str(w.message) for w in rec)
+        eq = a == a.materialise()                                 # ONE single-image handle, used twice: intended, silent
+        assert not rec
     assert isinstance(eq, torch.Tensor) and bool(eq.all()) and not bool((a != a.materialise()).any())
     assert isinstance(a == 0, torch.Tensor)
     with pytest.raises(RuntimeError):
-        bool(b)
-    with warnings.catch_warnings(record=True) as rec:             # (one warning per process)
+        bool(b)                                                   # (b materialises: the SECOND distinct handle -> warns)
+    with warnings.catch_warnings(record=True) as rec:             # a batch made by torch.cat materialises: warns ...
         warnings.simplefilter("always")
-        mk(sr).shape
-        assert not rec
+        for _ in range(2):
+            torch.cat([mk(sr), mk(gt)], dim=1).shape              # ... once per call site
+        assert sum("computed eagerly" in str(w.message) for w in rec) == 1
+        torch.cat([mk(sr), mk(gt)], dim=1).shape                  # another call site: reported again
+        assert sum("computed eagerly" in str(w.message) for w in rec) == 2
 
 
 def test_literal_reference_loop_with_len_checks_reaches_the_batched_step(lazy_on_cpu):
