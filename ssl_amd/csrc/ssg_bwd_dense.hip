@@ -407,9 +407,25 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     return none ? 0 : TY * GQS + (a == 0 ? bb : TY - 1 + a) * PS + NPXP * g;
   };
 
-  // RG = 8, offset rows with a vertically cut window [ylo, yhi]: W = (prefix of lane `lpos`) - (prefix of lane
-  // `lneg`), each times a 0/1 factor; byte addresses for ds_bpermute
-  auto cut_rows = [&](int ylo, int yhi, int &lpos, int &lneg, float &mpos, float &mneg) {
+  auto row_shift_of = [&](int qy) {   // (= row_shift below: the storage shift of the G field of offset row qy)
+    if constexpr (!REGW) return 0;
+    else return !half ? (qy < HK ? HK - qy : 0) : (qy > KS - 1 - HK ? (KS - 1 - HK) - qy : 0);
+  };
+  // RG = 8, offset rows with a vertically cut window [ylo, yhi]: W = (prefix of lane jp) - (prefix of lane jn) of the
+  // lane's group.  The window is cut at ONE end only (k_s > 2 (k_w/2)), and then either the positive term is the lane's
+  // OWN prefix or there is no negative term -- top half: yhi = HK gives a = 0 (no negative term), ylo = -HK gives bb = j
+  // (own); bottom half (lane j holds rows 7-j..7): yhi = HK gives a = 7 - j (own), ylo = -HK gives bb = 7 (no negative
+  // term).  So ONE ds_bpermute per value serves every case: W = c_own * own + c_oth * prefix(lane l_oth)
+  // (round 6: the two-exchange form cost the kernel 14 % of its time in the 8 cut rows of 25 -- ablation
+  // profiles/r6_bwd_dense_ablation.txt).  `l_oth` is a byte address for ds_bpermute.
+  auto cut_rows = [&](int qy, int &l_oth, float &c_own, float &c_oth) {
+    const int ylo = (-HK > -qy) ? -HK : -qy, yhi = (HK < KS - 1 - qy) ? HK : KS - 1 - qy;
+    if (row_shift_of(qy) != 0) {   // the field of this row is stored shifted: every lane's own prefix is its window (see row_shift)
+      c_own = 1.f;
+      c_oth = 0.f;
+      l_oth = 0;
+      return;
+    }
     int a = r - HK - yhi, bb = r - HK - ylo;  // tile rows [a, bb] feed U-row r
     a = a < 0 ? 0 : a;
     bb = bb > TY - 1 ? TY - 1 : bb;
@@ -423,24 +439,30 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       jp = TY - 1 - a;
       jn = TY - 2 - bb;
     }
-    mpos = none ? 0.f : 1.f;
-    mneg = (none || jn < 0) ? 0.f : 1.f;
-    lpos = 4 * (base + 2 * (none ? 0 : jp));
-    lneg = 4 * (base + 2 * (jn < 0 ? 0 : jn));
+    const bool own = !none && jp == jrow;
+    const bool neg = !none && jn >= 0;
+    // (own || !neg by the case analysis above; a window cut at both ends -- impossible for k_w <= k_s -- would need both)
+    c_own = own ? 1.f : 0.f;
+    c_oth = none ? 0.f : (own ? (neg ? -1.f : 0.f) : 1.f);
+    l_oth = 4 * (base + 2 * (own ? (neg ? jn : 0) : (none ? 0 : jp)));
   };
-  auto w_regs = [&](bool full, int lpos, int lneg, float mpos, float mneg, float (&Wv)[NPX]) {
+  // the lane exchange of a cut row is ISSUED here (end of the step that produced `wout`) and consumed by w_finish behind
+  // the next step's LDS reads and pixel differences, which cover its latency
+  auto w_exchange = [&](int l_oth, float (&vx)[NPX]) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i)
+      vx[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l_oth, __builtin_bit_cast(int, wout[i < HOUT ? i : 0])));
+  };
+  auto w_finish = [&](bool full, const float (&vx)[NPX], float c_own, float c_oth, float (&Wv)[NPX]) {
     static_assert(!REGW || HOUT == NPX, "one role per lane");
     if (full) {
 #pragma unroll
       for (int i = 0; i < NPX; ++i) Wv[i] = wout[i < HOUT ? i : 0];
     } else {
 #pragma unroll
-      for (int i = 0; i < NPX; ++i) {
-        const int wi = __builtin_bit_cast(int, wout[i < HOUT ? i : 0]);
-        const float vp = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(lpos, wi));
-        const float vn = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(lneg, wi));
-        Wv[i] = mpos * vp - mneg * vn;
-      }
+      // (the rows that take the exchange are the ones cut on the wave's OWN side: W = own prefix - another lane's, and
+      // c_own == 1 in every lane -- see cut_rows; the rows cut on the other side are stored shifted, see row_shift)
+      for (int i = 0; i < NPX; ++i) Wv[i] = __builtin_fmaf(c_oth, vx[i], wout[i < HOUT ? i : 0]);
     }
   };
 
@@ -575,9 +597,22 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     load_group(qy0, 1, gbuf[1]);
     load_last(qy0);
   }
+  // REGW: the G field of an offset row whose vertical window is cut on the side AWAY from the wave's half is stored
+  // SHIFTED by whole rows, so that the lanes' plain prefixes are the cut windows' sums (no lane exchange in those rows):
+  //   top half (U-row j = prefix over tile rows 0..j), q_y < HK: rows 0 .. j-(HK-q_y) are wanted = the prefix of the field
+  //     moved DOWN by HK - q_y rows (rows pushed out of the tile are not wanted by any U-row of this half);
+  //   bottom half (lane j' = suffix over rows 7-j'..7), q_y > k_s-1-HK: rows 7-j'+(q_y-(k_s-1-HK)) .. 7 = the suffix of the
+  //     field moved UP by that many rows.
+  // A shifted offset leaves its values at other positions than the offsets around it: the two steps of a row that write
+  // the NEXT row's first offsets clear the positions they replace (x_clear), and the epilogue clears its copy.
+  auto row_shift = [&](int qy) { return row_shift_of(qy); };
+  auto shift_pos = [&](int e, int sh) {   // field position under a row shift; rows pushed out of the tile -> the dummy word
+    const int ny = e / GQS + sh;          // (the dummy word itself lies in "row" TY)
+    return (e != DUMMY && ny >= 0 && ny < TY) ? e + sh * GQS : DUMMY;
+  };
   // G[.,q] of one offset into field copy f; x_put(.., qyi, qxi) reads the registers the schedule below filled.
   // (tile-major rows: G is formed here; `q_refill` = the linear offset TMD steps ahead that refills the ring slot)
-  auto x_put = [&](auto qx_c, int qyi, float *f, int q_refill = 0) {
+  auto x_put = [&](auto qx_c, int qyi, float *f, const int (&pos)[NCH], int q_refill = 0) {
     constexpr int qxi = decltype(qx_c)::value, grp = qxi / 4, gj = qxi % 4;
     if constexpr (!DO_G) return;
 #pragma unroll
@@ -596,7 +631,7 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
         gv = grp < NG ? gbuf[grp & 1][ck][gj] : gl[ck];
       }
       if constexpr (qxi == HP) gv = (qyi == HP) ? 0.f : gv;  // centre offset: A - B == 0 exactly
-      f[epos[ck]] = gv;
+      f[pos[ck]] = gv;
     }
     if constexpr (TM) tm_load(std::integral_constant<int, qxi % TMD>{}, q_refill);
   };
@@ -616,14 +651,17 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   // Every LDS read of a step is issued at its top and touches only what earlier steps wrote.
   {  // first two offsets of the sweep (copy = parity of the offset's linear index; k_s is odd)
     float *f0 = fld + ((qy0 * KS) & 1) * FSZ, *f1 = fld + (((qy0 * KS) & 1) ^ 1) * FSZ;
-    x_put(std::integral_constant<int, 0>{}, qy0, f0, qy0 * KS + TMD);
-    x_put(std::integral_constant<int, 1>{}, qy0, f1, qy0 * KS + TMD + 1);
+    int epos0[NCH];
+#pragma unroll
+    for (int ck = 0; ck < NCH; ++ck) epos0[ck] = REGW ? shift_pos(epos[ck], row_shift(qy0)) : epos[ck];
+    x_put(std::integral_constant<int, 0>{}, qy0, f0, epos0, qy0 * KS + TMD);
+    x_put(std::integral_constant<int, 1>{}, qy0, f1, epos0, qy0 * KS + TMD + 1);
     stage_sync();
     if constexpr (DO_W) x_stage(std::integral_constant<int, (-HK > 0 ? -HK : 0)>{}, std::integral_constant<int, HK>{}, f0);
     if constexpr (LAG) {   // one offset more in flight (see the step schedule below): P(1), F(2), and W of offset 0
       if constexpr (DO_W) x_stage(std::integral_constant<int, (-HK > -1 ? -HK : -1)>{}, std::integral_constant<int, HK>{}, f1);
       stage_sync();
-      x_put(std::integral_constant<int, 2>{}, qy0, f0, qy0 * KS + TMD + 2);
+      x_put(std::integral_constant<int, 2>{}, qy0, f0, epos0, qy0 * KS + TMD + 2);
       const int ylo0 = (-HK > -qy0) ? -HK : -qy0, yhi0 = (HK < KS - 1 - qy0) ? HK : KS - 1 - qy0;
       y_read(f0, prefix_rows(ylo0, yhi0), Wv);
     }
@@ -631,8 +669,13 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     if constexpr (SPL) stage_sync();
   }
 
-#pragma unroll 1
-  for (int qyi = qy0; qyi < qy1; ++qyi) {
+  // One offset row q_y (its k_s steps unrolled).  REGW: the row exists in two instantiations -- CUT = the lane exchange
+  // in every step, !CUT = none at all -- and offset_rows() below walks the rows in runs of one class: the wave-uniform
+  // choice is made per ROW.  Per-step branches around the exchange cost the kernel 6 % of its time on top of the
+  // exchange itself (profiles/r6_bwd_dense_ablation.txt: 0.482 ms with them, 0.427 without exchange and branches,
+  // 0.507 with the exchange in every row and no branch).
+  auto offset_row = [&](auto cut_c, const int qyi) {
+    constexpr bool CUT = decltype(cut_c)::value;
     // (next row's prefetches run unconditionally on clamped rows: the offset loop stays branch-free)
     const int qyn = qyi + 1 < KS ? qyi + 1 : KS - 1;
     // (first offsets of this and the next offset row for the tile-major loads, opaque to the optimiser: loop strength
@@ -643,11 +686,13 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     load_img_row(r0 + qyi + RR < RH ? r0 + qyi + RR : RH - 1, nrow);
     const int ylo = (-HK > -qyi) ? -HK : -qyi, yhi = (HK < KS - 1 - qyi) ? HK : KS - 1 - qyi;
     const float ymask = (ylo > -HK || yhi < HK) ? 1.f : 0.f;
-    int pw = 0, lpos = 0, lneg = 0;
-    float mpos = 0.f, mneg = 0.f;
-    const bool rowfull = ylo == -HK && yhi == HK;
-    if constexpr (REGW) cut_rows(ylo, yhi, lpos, lneg, mpos, mneg);
+    int pw = 0, l_oth = 0;
+    float c_own = 0.f, c_oth = 0.f;
+    if constexpr (REGW) cut_rows(qyi, l_oth, c_own, c_oth);
     else pw = prefix_rows(ylo, yhi);
+    int eposc[NCH];   // where this row's offsets put G (REGW: under the row's shift)
+#pragma unroll
+    for (int ck = 0; ck < NCH; ++ck) eposc[ck] = REGW ? shift_pos(epos[ck], row_shift(qyi)) : epos[ck];
     int pwn = 0;   // LAG: the row's last step fetches W of the next row's first offset
     if constexpr (LAG) pwn = prefix_rows((-HK > -qyn) ? -HK : -qyn, (HK < KS - 1 - qyn) ? HK : KS - 1 - qyn);
     float *fe = fld + (qyi & 1) * FSZ, *fo = fld + ((qyi & 1) ^ 1) * FSZ;  // copies of the even / odd q_x of this row
@@ -681,9 +726,10 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       if constexpr (qxi == KS - 2) load_last(qyn);
       // ---- top: every LDS read of the step ----
       float v[HOUT + 2 * HK], fl[C], wn[C];
+      float vx[NPX];   // REGW, cut rows: the other lane's prefix (in flight until w_finish)
       if constexpr (LAG) {
       } else if constexpr (REGW) {
-        w_regs(rowfull, lpos, lneg, mpos, mneg, Wv);
+        if constexpr (CUT) w_exchange(l_oth, vx);
       } else {
         y_read(fc, pw, Wv);
       }
@@ -701,9 +747,27 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       if constexpr (LAG) y_read(fn, qxi + 1 < KS ? pw : pwn, Wn);
       // (two waves: the reads stay here, in front of the body that covers their latency -- the scheduler otherwise
       // sinks them to their first use behind it)
-      if constexpr (SPL) __builtin_amdgcn_sched_barrier(0);
+      // (the reads stay here, in front of the body that covers their latency -- the scheduler otherwise sinks them to
+      // their first use behind it (SPL), or pulls the horizontal sums that consume v[] up in front of the body (REGW:
+      // a wait for the whole read burst at the top of every step; round 6))
+      if constexpr (SPL || REGW) __builtin_amdgcn_sched_barrier(0);
       // ---- both ends of every pair (u, u+q) ----
       constexpr bool xborder = xlo > -HK || xhi < HK;
+      // the pixel differences first: they do not depend on W (REGW: they cover the cut rows' lane exchange)
+      f2 dA[NPX];
+      float dB[NPX];
+      if constexpr (REGW) {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+          const int sl = (i + qxi) % NPX;
+          dA[i] = iuA[i] - wA[sl];
+          dB[i] = iuB[i] - wB[sl];
+          // (pinned in front of the cut rows' branch: machine sinking otherwise moves them behind it, and the branch
+          // then waits for the lane exchange with nothing in between)
+          asm volatile("" : "+v"(dA[i]), "+v"(dB[i]));
+        }
+        w_finish(!CUT, vx, c_own, c_oth, Wv);
+      }
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
         const float Wi = Wv[i];
@@ -712,26 +776,28 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
           else swb[i] = __builtin_fmaf(Wi, ymask, swb[i]);
         }
         const int sl = (i + qxi) % NPX;
+        if constexpr (!REGW) {   // (the other lane maps form the differences next to their use: fewer live registers)
+          dA[i] = DO_A ? iuA[i] - wA[sl] : f2{0.f, 0.f};
+          dB[i] = DO_B ? iuB[i] - wB[sl] : 0.f;
+        }
         if constexpr (DO_B) {
-          const float dB = iuB[i] - wB[sl];
-          guB[i] = __builtin_fmaf(Wi, dB, guB[i]);
-          grB[sl] = __builtin_fmaf(-Wi, dB, grB[sl]);
+          guB[i] = __builtin_fmaf(Wi, dB[i], guB[i]);
+          grB[sl] = __builtin_fmaf(-Wi, dB[i], grB[sl]);
         }
         if constexpr (!DO_A) {
         } else if constexpr (RG == 4) {   // measured: packed 2.27 -> 2.06 ms for (49,13); 0.31 -> 0.33 ms for (25,9), which stays scalar
           const f2 Wi2 = f2{Wi, Wi};
-          const f2 dA = iuA[i] - wA[sl];
-          guA[i] = __builtin_elementwise_fma(Wi2, dA, guA[i]);
-          grA[sl] = __builtin_elementwise_fma(-Wi2, dA, grA[sl]);
+          guA[i] = __builtin_elementwise_fma(Wi2, dA[i], guA[i]);
+          grA[sl] = __builtin_elementwise_fma(-Wi2, dA[i], grA[sl]);
         } else {
-          const float d0 = iuA[i].x - wA[sl].x, d1 = iuA[i].y - wA[sl].y;
-          guA[i].x = __builtin_fmaf(Wi, d0, guA[i].x);
-          guA[i].y = __builtin_fmaf(Wi, d1, guA[i].y);
-          grA[sl].x = __builtin_fmaf(-Wi, d0, grA[sl].x);
-          grA[sl].y = __builtin_fmaf(-Wi, d1, grA[sl].y);
+          guA[i].x = __builtin_fmaf(Wi, dA[i].x, guA[i].x);
+          guA[i].y = __builtin_fmaf(Wi, dA[i].y, guA[i].y);
+          grA[sl].x = __builtin_fmaf(-Wi, dA[i].x, grA[sl].x);
+          grA[sl].y = __builtin_fmaf(-Wi, dA[i].y, grA[sl].y);
         }
       }
       // ---- next offset: horizontal sums over its column taps, vertical prefix ----
+      if constexpr (REGW) __builtin_amdgcn_sched_barrier(0);
       float out[HOUT];
       if constexpr (DO_W) {
         window_sums<HOUT, HK - nhi, HK - nlo>(v, out);
@@ -773,7 +839,18 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
           if constexpr (qxi + 1 < KS) wB[s0] = wn[2];
         }
       }
-      x_put(std::integral_constant<int, qx2>{}, qxi + 2 + LAG < KS ? qyi : qyn, fG,
+      if constexpr (REGW && qxi + 2 + LAG >= KS) {
+        // the next row's first offsets replace this row's last ones in their copies: under another shift at other
+        // positions -- the old ones are cleared first (same positions when the shifts agree: overwritten below)
+        int eposn[NCH];
+#pragma unroll
+        for (int ck = 0; ck < NCH; ++ck) {
+          fG[eposc[ck]] = 0.f;
+          eposn[ck] = shift_pos(epos[ck], row_shift(qyn));
+        }
+        x_put(std::integral_constant<int, qx2>{}, qyn, fG, eposn);
+      } else
+      x_put(std::integral_constant<int, qx2>{}, qxi + 2 + LAG < KS ? qyi : qyn, fG, eposc,
             (qxi + 2 + LAG < KS && qx2 + TMD < KS) ? rq0 + qx2 + TMD : (qxi + 2 + LAG < KS ? rq1 + qx2 + TMD - KS : rq1 + qx2 + TMD));
       // (the accumulators of the lane's own pixels pass through an empty asm: they are not read again before
       // the end of the sweep, and hipcc otherwise sinks their FMAs below all k_s steps, keeping every step's
@@ -805,6 +882,36 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     flush_row(r0 + qyi);
     store_img_row(r0 + qyi + RR, nrow);
     __builtin_amdgcn_wave_barrier();
+  };
+  if constexpr (!REGW) {
+#pragma unroll 1
+    for (int qyi = qy0; qyi < qy1; ++qyi) offset_row(std::false_type{}, qyi);
+  } else {
+    // a row is SIMPLE when every lane's W is its own prefix: full windows, and the cut rows next to them whose cut
+    // does not reach into the tile (q_y = 21 for the top half, 3 for the bottom half)
+    auto row_simple = [&](int qyi) {
+      int l_oth;
+      float c_own, c_oth;
+      cut_rows(qyi, l_oth, c_own, c_oth);
+      return __ballot(c_own != 1.f || c_oth != 0.f) == 0ull;
+    };
+    int qyi = qy0;
+#pragma unroll 1
+    while (qyi < qy1) {
+      if (row_simple(qyi)) {
+#pragma unroll 1
+        do {
+          offset_row(std::false_type{}, qyi);
+          ++qyi;
+        } while (qyi < qy1 && row_simple(qyi));
+      } else {
+#pragma unroll 1
+        do {
+          offset_row(std::true_type{}, qyi);
+          ++qyi;
+        } while (qyi < qy1 && !row_simple(qyi));
+      }
+    }
   }
   for (int rho = r0 + qy1; rho < r0 + qy1 + RR - 1; ++rho) flush_row(rho);
 
@@ -812,6 +919,11 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   float vbox[NPX];
   {
     if constexpr (DO_G) {
+      // (REGW: the sweep's last offsets may have been stored under a row shift: the copy is cleared, pads included)
+      if constexpr (REGW) {
+        for (int i = lane; i < TY * GQS; i += 64) fld[i] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+      }
 #pragma unroll
       for (int ck = 0; ck < NCH; ++ck) fld[epos[ck]] = (blockIdx.y == 0) ? p.sum_b[erow[ck]] : 0.f;
     }
@@ -827,7 +939,7 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       for (int i = 0; i < NPX; ++i) swb[i] = grb[64 * i + lane];
     }
     if constexpr (REGW) {
-      w_regs(true, 0, 0, 0.f, 0.f, vbox);
+      w_finish(true, vbox, 0.f, 0.f, vbox);
     } else {
       y_read(fld, prefix_rows(-HK, HK), vbox);
     }

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 tests=""; if [ "$1" = "-t" ]; then tests="$2"; shift 2; fi
 mkdir -p gpurun_ab/work gpurun_out; cp ssl_amd/csrc/libssg_hip*.so gpurun_ab/work/
 out=gpurun_out/r6_ab_$(echo "$@" | tr ' ' '_').txt; : > $out
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
   for t in "$@"; do
     cp gpurun_ab/$t/libssg_hip.so gpurun_ab/$t/libssg_hip_prof.so ssl_amd/csrc/
     if [ $rep = 1 ] && [ -n "$tests" ] && [ $t != work ]; then
