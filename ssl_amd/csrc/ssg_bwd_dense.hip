@@ -199,7 +199,9 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   constexpr int FSZ = G::FSZ;
   constexpr bool REGW = G::REGW;
   constexpr int DUMMY = FSZ - 1;  // last word of a copy (offsets are relative to the copy's base)
-  constexpr int NCH_LO = NCH <= 2 ? 0 : NCH / 2;  // instantiations: 2 and 4 chunks
+  // instantiations: (25,9) 2 and 4 chunks -- the plan's TILE_HUGE tiles (more than 128 edge pixels) and all others;
+  // (49,13) 2 chunks (the whole 4 x 32 tile)
+  constexpr int NCH_LO = NCH <= 2 ? 0 : NCH / 2;
   static_assert(NG % 2 == 0 && NCH <= NCHUNK, "two G slots alternate over an even number of groups");
   constexpr int TMD = 7;   // tile-major rows: offsets in flight (ring slots; k_s % TMD == 0 keeps slot = q_x % TMD)
   static_assert(!TM || (RG == 4 && TY == 4 && NCH == NCHUNK && NCH * 64 == TM_PX && KS % TMD == 0), "tile-major rows: 4 x 32 tiles, one wave");
@@ -224,7 +226,16 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   }
   const int H = p.H, W = p.W;
   const int tx_n = (W + TX - 1) / TX, ty_n = (H + TY - 1) / TY;
-  const int tile = dense_tile_id(dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot));
+  const int listed = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
+  if constexpr (TY == 8) {
+    // the tile's class by the plan (TILE_HUGE marks the tiles with more than 128 edge pixels): one instantiation per
+    // class is launched, the other leaves before its census.  (A capacity clamp can only lower a tile's count below its
+    // class' range, never raise it.)  A one-chunk instantiation for the tiles with <= 64 edge pixels (69 % of C2's) was
+    // measured: its launch and the two-chunk one each fill part of the chip for a whole sweep -- 0.446 -> 0.509 ms.
+    const int cls = (listed & TILE_HUGE) ? 4 : 2;
+    if (cls != NCH) return;
+  }
+  const int tile = dense_tile_id(listed);
   const int b = tile / (tx_n * ty_n), tr = tile - b * tx_n * ty_n;
   const int ty0 = (tr / tx_n) * TY, tx0 = (tr % tx_n) * TX;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
@@ -241,12 +252,22 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   // ---- census of the tile's edge pixels (row-major inside the tile) ----
   int n_e = 0;
   int tm_pos[NCH], tm_row[NCH];   // tile-major rows: the lane's pixels by the fixed map, no list
+  // (the rank map's loads of all chunks first -- clamped addresses, no exec-masked blocks: four serialised round trips
+  // to memory otherwise stand at the head of every wave)
+  int rk[NCHUNK];
 #pragma unroll
   for (int k = 0; k < NCHUNK; ++k) {
     const int pos = lane + 64 * k;
     const int ey = TM ? tm_pixel_row(k, lane) : pos / TX, ex = TM ? tm_pixel_col(lane) : pos - (pos / TX) * TX;
     const int y = ty0 + ey, x = tx0 + ex;
-    int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+    const int v = p.rank[((size_t)b * H + (y < H ? y : H - 1)) * W + (x < W ? x : W - 1)];
+    rk[k] = (y < H && x < W) ? v : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < NCHUNK; ++k) {
+    const int pos = lane + 64 * k;
+    const int ey = TM ? tm_pixel_row(k, lane) : pos / TX, ex = TM ? tm_pixel_col(lane) : pos - (pos / TX) * TX;
+    int r = rk[k];
     if (r >= nrows) r = -1;
     const unsigned long long bal = __ballot(r >= 0);
     if constexpr (TM) {
@@ -259,7 +280,11 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     }
     n_e += __popcll(bal);
   }
-  if (n_e <= 64 * NCH_LO || n_e > 64 * NCH) return;
+  if constexpr (TY == 8) {
+    if (n_e == 0 || n_e > 64 * NCH) return;   // (the class was checked above; an emptied tile has nothing to add)
+  } else {
+    if (n_e <= 64 * NCH_LO || n_e > 64 * NCH) return;
+  }
   if constexpr (DO_G) for (int i = lane; i < 2 * FSZ + 4; i += 64) fld[i] = 0.f;  // fields (pads stay 0) and prefix rows 0
   if constexpr (DO_W) for (int i = lane; i < RR * BRS; i += 64) grb[i] = 0.f;
   stage_sync();
@@ -701,8 +726,10 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     float *gb = grb + slr * BRS + NPX * g;
     f2 wA[NPX], grA[NPX];
     float wB[NPX], grB[NPX];
+    float vx[NPX];   // REGW, cut rows: the other lane's prefix (in flight from the end of a step to the next one's w_finish)
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
+      vx[i] = 0.f;
       wA[i] = DO_A ? f2{ib[i], ib[RWS + i]} : f2{0.f, 0.f};
       wB[i] = DO_B ? ib[2 * RWS + i] : 0.f;
       grA[i] = f2{0.f, 0.f};
@@ -726,10 +753,11 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       if constexpr (qxi == KS - 2) load_last(qyn);
       // ---- top: every LDS read of the step ----
       float v[HOUT + 2 * HK], fl[C], wn[C];
-      float vx[NPX];   // REGW, cut rows: the other lane's prefix (in flight until w_finish)
       if constexpr (LAG) {
       } else if constexpr (REGW) {
-        if constexpr (CUT) w_exchange(l_oth, vx);
+        // (cut rows: the exchange for this step was issued at the end of the previous one, right behind the prefix --
+        // only the row's first step issues its own)
+        if constexpr (CUT && qxi == 0) w_exchange(l_oth, vx);
       } else {
         y_read(fc, pw, Wv);
       }
@@ -817,6 +845,9 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       } else if constexpr (REGW) {
 #pragma unroll
         for (int i = 0; i < HOUT; ++i) wout[i] = out[i];
+        // cut rows: the next step's lane exchange starts here -- the step's LDS writes, the next step's reads and its
+        // pixel differences run while it is in flight
+        if constexpr (CUT && qxi + 1 < KS) w_exchange(l_oth, vx);
       } else {
 #pragma unroll
         for (int i = 0; i < HOUT; ++i) {

@@ -411,8 +411,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int wvu = __builtin_amdgcn_readfirstlane(wv);
   const int run_lo = wvu == 0 ? 0 : wvu == 1 ? RUN1 : wvu == 2 ? SB : RUN3;
   const int run_hi = wvu == 0 ? RUN1 : wvu == 1 ? SB : wvu == 2 ? RUN3 : KS;
-  auto do_row = [&](const int qyi, auto shared_c) {
+  // NACT (pipelined two-chunk instantiation of the 8 x 32 tiles only; -1 = decided per step from n_e): chunks of the edge
+  // list that hold pixels -- the offset rows exist once per value and the (workgroup-uniform) choice is made ONCE, in front
+  // of the row loop: the two `chunk present?` branches per offset step cost more than they look (the dense backward's
+  // per-step branches around its lane exchange: 6 % of that kernel, profiles/r6_bwd_dense_ablation.txt)
+  auto do_row = [&](const int qyi, auto shared_c, auto nact_c) {
     constexpr bool shared_row = decltype(shared_c)::value;
+    constexpr int NACT = decltype(nact_c)::value;
     // D[n,q] = sum_{k in K(q)} E_q[x+k] + sum_{k not in K(q)} |I[x+k]|^2 with K(q) = rows [ylo,yhi] x columns
     // [xlo,xhi] of the window.  Rows: wave-uniform 0/1 weights.  Columns: the lane adds the |I|^2 of the
     // columns that left (compile-time set) to its horizontal sums, so H' rows carry E inside and |I|^2 outside
@@ -661,8 +666,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           }
       };
 #pragma unroll
-      for (int ck = 0; ck < NCHUNK; ++ck) {
-        if (ck * 64 < n_e_stage) {
+      for (int ck = 0; ck < (NACT >= 0 ? NACT : NCHUNK); ++ck) {
+        if (NACT >= 0 || ck * 64 < n_e_stage) {
           if constexpr (PIPE && !SPLIT) {
             // consume the taps gathered a step ago (offset qxi - 1), then gather this step's behind its H stores
             if constexpr (qxi > 0) edge_emit(std::integral_constant<int, qxi - 1>{}, ck, tap_sum<KW>(hvp[ck], wgt, av[ck]));
@@ -688,9 +693,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   };
   if (!SSG_DBG(p, 64)) {
-#pragma unroll 1
-    for (int qyi = wv; qyi < KS - REM; qyi += NW) do_row(qyi, std::false_type{});
-    if constexpr (REM > 0) do_row(KS - 1, std::true_type{});
+#define SSG_ALL_ROWS(NACT_)                                                                                    \
+  do {                                                                                                         \
+    _Pragma("unroll 1") for (int qyi = wv; qyi < KS - REM; qyi += NW)                                          \
+        do_row(qyi, std::false_type{}, std::integral_constant<int, NACT_>{});                                  \
+    if constexpr (REM > 0) do_row(KS - 1, std::true_type{}, std::integral_constant<int, NACT_>{});             \
+  } while (0)
+    if constexpr (PIPE && NCHUNK == 2 && !RAW) {   // (the raw-distance instantiation spills with two row bodies: per-step test)
+      if (n_e_stage > 64) SSG_ALL_ROWS(2);
+      else if (n_e_stage > 0) SSG_ALL_ROWS(1);
+#ifdef SSG_PROFILE
+      else SSG_ALL_ROWS(0);   // (ablation: no edge stage)
+#endif
+    } else {
+      SSG_ALL_ROWS(-1);
+    }
+#undef SSG_ALL_ROWS
   }
 
   // ---- row sums over the four waves, then rescale the rows this workgroup wrote ----
