@@ -219,6 +219,42 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int ty0 = (tr / tx_n) * DT_Y, tx0 = (tr % tx_n) * DT_X;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
 
+  // ---- image region: C x RH x RWD, reflect by index mirroring (clamped: far corners of tiles that overhang a small
+  // image are never used, but must stay in bounds).  16 lanes per region row, lane lx takes columns lx, lx + 16, ...
+  // (neighbouring lanes read neighbouring pixels).  ALL row passes are loaded here, in front of the census -- its rank
+  // load and ballots run while they are in flight -- and stored behind it (round 6; before: two passes at a time
+  // behind the census, ~5 L2 round trips in a row at the head of every workgroup) ----
+  constexpr int CPLF = (RWD + 15) / 16, RPP = NT / 16, NPASS = (C * RH + RPP - 1) / RPP;
+  const int lx = tid % 16, lr = tid / 16;
+  // (k_w 9: the thread's rank-map entry FIRST -- loads return in order, so the census below waits for this one only)
+  int rank_px = -1;
+  if constexpr (HPAIR) {
+    const int y = ty0 + tid / DT_X, x = tx0 + tid % DT_X;
+    const int v = p.rank[((size_t)b * H + (y < H ? y : H - 1)) * W + (x < W ? x : W - 1)];
+    rank_px = (y < H && x < W) ? v : -1;
+  }
+  float rv[NPASS][CPLF];
+  int rdst[NPASS];
+  {
+    const float *src = p.img[which] + (size_t)b * C * H * W;
+#pragma unroll
+    for (int h = 0; h < NPASS; ++h) {
+      const int R = h * RPP + lr;
+      const bool on = R < C * RH;
+      const int Rc = on ? R : 0;
+      const int c = Rc / RH, ry = Rc - c * RH;
+      int gy = reflect_idx(ty0 - HALO + ry, H);
+      gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+      const float *srow = src + ((size_t)c * H + gy) * W;
+      rdst[h] = on ? (c * RH + ry) * RS : -1;
+#pragma unroll
+      for (int k = 0; k < CPLF; ++k) {
+        int gx = reflect_idx(tx0 - HALO + lx + 16 * k, W);
+        gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+        rv[h][k] = srow[gx];
+      }
+    }
+  }
   // ---- census of the tile's edge pixels ----
   // List slot e = (chunk of 64, lane) decides which lanes gather together from the H buffers.  k_w 13 (full tiles):
   // row-major, 32 consecutive centres of a row per half-wave, conflict-free.  k_w 9 (a few dozen pixels anywhere in the
@@ -230,8 +266,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     static_assert(DT_Y * DT_X == NT, "one thread per tile pixel");
     int *wcnt = misc + 16, *bstart = wcnt + NW * 32;  // [NW][32] pixels per (wave, bank); starts in the sorted list
     const int ey = tid / DT_X, ex = tid % DT_X;
-    const int y = ty0 + ey, x = tx0 + ex;
-    int r = (y < H && x < W) ? p.rank[((size_t)b * H + y) * W + x] : -1;
+    int r = rank_px;
     if (r >= nrows) r = -1;
     elist[3 * tid + 2] = -1;
     const int bank = (DT_HS * ey + dense_h_col(ex, L, HG, true)) & 31;
@@ -290,42 +325,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     if (tid == 0) misc[NW] = NE_MAX;
   }
-  // ---- image region: C x RH x RWD, reflect by index mirroring (clamped: far corners of
-  // tiles that overhang a small image are never used, but must stay in bounds) ----
-  {
-    const float *src = p.img[which] + (size_t)b * C * H * W;
-    // 16 lanes per region row, lane lx takes columns lx, lx + 16, ... (neighbouring lanes read neighbouring pixels);
-    // two row passes are loaded before the first is stored, so that a workgroup pays the L2 latency ~6 instead of
-    // ~11 times in a row
-    constexpr int CPLF = (RWD + 15) / 16, RPP = NT / 16;
-    const int lx = tid % 16, lr = tid / 16;
-    for (int R0 = 0; R0 < C * RH; R0 += 2 * RPP) {
-      float v[2][CPLF];
-      int dst[2];
+  // ---- image region, second half: the values loaded in front of the census go to LDS ----
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int R = R0 + h * RPP + lr;
-        const bool on = R < C * RH;
-        const int Rc = on ? R : 0;
-        const int c = Rc / RH, ry = Rc - c * RH;
-        int gy = reflect_idx(ty0 - HALO + ry, H);
-        gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
-        const float *srow = src + ((size_t)c * H + gy) * W;
-        dst[h] = on ? (c * RH + ry) * RS : -1;
+  for (int h = 0; h < NPASS; ++h)
 #pragma unroll
-        for (int k = 0; k < CPLF; ++k) {
-          int gx = reflect_idx(tx0 - HALO + lx + 16 * k, W);
-          gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-          v[h][k] = srow[gx];
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < CPLF; ++k)
-          if (dst[h] >= 0 && lx + 16 * k < RWD) reg[dst[h] + lx + 16 * k] = v[h][k];
-    }
-  }
+    for (int k = 0; k < CPLF; ++k)
+      if (rdst[h] >= 0 && lx + 16 * k < RWD) reg[rdst[h] + lx + 16 * k] = rv[h][k];
   __syncthreads();
   const int n_e = misc[NW];  // list slots (k_w 9: with holes, row -1)
   for (int i = tid; i < UH * UW; i += NT) {
@@ -476,18 +481,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       constexpr int xlo = (-HK > -qxi) ? -HK : -qxi, xhi = (HK < KS - 1 - qxi) ? HK : KS - 1 - qxi;
       // E_q on the lane's L pixels, E[j] = (pixel j, pixel j + L/2); pixel i of step qxi lives in window slot
       // (i + qxi) % L -- a compile-time function of the step
+      // (channel-major: consecutive packed operations belong to different pixel pairs -- with the pair loop outside,
+      // every v_pk_fma waited for the one before it, an s_nop each: 14 idle issue slots of ~125 per step)
       f2 E[HL];
 #pragma unroll
-      for (int j = 0; j < HL; ++j) {
-        const int a = (j + qxi) % L;  // slot of pixel j; pixel j + L/2 sits in slot (a + L/2) % L
-        f2 t = f2{0.f, 0.f};
+      for (int c = 0; c < C; ++c) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
+        for (int j = 0; j < HL; ++j) {
+          const int a = (j + qxi) % L;  // slot of pixel j; pixel j + L/2 sits in slot (a + L/2) % L
           const f2 wv2 = a < HL ? w[c][a] : w[c][a - HL].yx;
           const f2 d = iu[c][j] - wv2;
-          t = __builtin_elementwise_fma(d, d, t);
+          E[j] = c == 0 ? d * d : __builtin_elementwise_fma(d, d, E[j]);
         }
-        E[j] = t;
       }
       // horizontal sums for the lane's L centre columns k (window = pixels k .. k+KW-1 of the row: the lane's own
       // from k to L-1, then the next lane's of the quad): E on taps [xlo, xhi], |I|^2 on the others.
