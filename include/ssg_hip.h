@@ -155,7 +155,7 @@ int ssg_compute_similarity_backward(const float *image, const float *grads,
 size_t ssg_edge_scratch_bytes(int B, int H, int W);
 size_t ssg_forward_plan_bytes(int B, int H, int W, int capacity);
 /* Threshold (edge pixels per 8x32 tile) from which the forward routes a tile to the
- * shared-term kernel; 0 = never.  Default 18.  Results are the same either way (parity-tested
+ * shared-term kernel; 0 = never.  Default 16.  Results are the same either way (parity-tested
  * with every tile routed through it and with none).  Process-wide; takes effect at the
  * next ssg_edge_list().  Returns the previous value.  No reference counterpart: the
  * reference has one code path. */

@@ -87,13 +87,16 @@ using namespace ssg;
 
 // Edge pixels per dense tile (8 x 32 for k_s 25, 4 x 32 for k_s 49) from which the shared-term kernels take the tile
 // (0 = never).  The marginal costs of the two paths are equal between 16 and 28 pixels per tile; below ~16 the direct
-// kernels win.  Default 18.  Round-4 sweeps (tools/r4_thr_sweep2.sh, r4_thr_sweep3.sh; same box): 20 against 28: C2
+// kernels win.  Round-4 sweeps (tools/r4_thr_sweep2.sh, r4_thr_sweep3.sh; same box): 20 against 28: C2
 // 1.308 vs 1.318 ms, stride-3 C4 0.540 vs 0.560, Bernoulli 4 % 0.513 vs 0.512, C5 7.78 vs 7.78; again at the end of the
 // round, after the direct forward had lost 9 % of its instructions (profiles/r4_dense_threshold_18_vs_20.txt, three
 // alternations): 18 against 20: C2 1.2771 vs 1.2849, fused 1.2225 vs 1.2309, C4 0.5024 vs 0.5196, Bernoulli 4 % 0.4925
-// vs 0.4868, 1 % equal (16 costs the Bernoulli masks 3 %, 24 and above cost C4 4 %).
+// vs 0.4868, 1 % equal (16 costs the Bernoulli masks 3 %, 24 and above cost C4 4 %).  Round 6, after the dense-tile
+// kernels lost 6-7 % of their time (profiles/r6_dense_threshold_sweep.txt, three alternations): 16 against 18: C2 1.1936
+// vs 1.2034, C4 0.446 vs 0.444, Bernoulli 4 % 0.456 vs 0.459, 1 % equal; 14: 1.1987 / 0.439; 12: 1.208 / 0.428 (C4's
+// best); 10 costs Bernoulli 4 % 20 %.  Default 16.
 // ssg_set_dense_threshold(n) overrides it (profiling build: also the environment variable SSG_DENSE_THR at first use).
-constexpr int DENSE_THR_DEFAULT = 18;
+constexpr int DENSE_THR_DEFAULT = 16;
 static std::atomic<int> g_dense_thr{-1};   // (atomic: the ABI may be called from several host threads)
 static int dense_threshold() {
   int v = g_dense_thr.load(std::memory_order_relaxed);

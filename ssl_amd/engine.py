@@ -142,7 +142,7 @@ def set_overlap(mode):
 
 def set_dense_threshold(edge_pixels_per_tile):
     """Route 8x32-pixel tiles holding at least this many edge pixels through the shared-term ("dense") forward
-    kernel (0 = never; default 18).  Same results either way.  Returns the previous value."""
+    kernel (0 = never; default 16).  Same results either way.  Returns the previous value."""
     return _lib.lib().ssg_set_dense_threshold(int(edge_pixels_per_tile))
 
 
