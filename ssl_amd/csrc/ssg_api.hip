@@ -175,7 +175,7 @@ static constexpr int dbg_mask() { return 0; }
 // 9.15 -> 9.64 ms -- so the fork is taken for k_s <= 25 only.
 struct SideStream {
   hipStream_t side = nullptr;
-  hipEvent_t forked = nullptr, joined = nullptr, gate = nullptr;
+  hipEvent_t forked = nullptr, joined = nullptr, gate = nullptr, gate2 = nullptr;
 };
 static std::atomic<int> g_overlap{-1};
 // 0 off, 1 dense-tile kernel on the caller's stream, 2 direct kernel on the caller's stream, 3 (default) whichever of the
@@ -259,6 +259,15 @@ static StreamPair assign_streams(hipStream_t st, hipStream_t st2) {
   t_last_assignment = st2 == st ? 0 : mode;
   return mode == 2 ? StreamPair{st2, st} : StreamPair{st, st2};
 }
+// Gated chains, round 6: the direct backward is released when the dense FORWARD is through (not, as in round 5, the dense
+// chain's row pass): it then runs beside that memory-bound row pass -- C2 1.1996 -> 1.178 ms, three alternations
+// (profiles/r6_schedule_ab.txt; holding the direct FORWARD until the dense forward is through as well: 1.184 alone,
+// 1.20 together).  The loss finalize follows the direct backward on its stream, behind a second event for the dense
+// chain's row pass.  (profiling build: SSG_SCHED=1 restores the round-5 gate.)
+static int sched_mode() {
+  static const int m = env_int("SSG_SCHED", 0);
+  return m;
+}
 static bool two_chains_allowed() {   // (profiling build: SSG_TWO_CHAINS=-1 restores fork / join around forward and backward each)
   static const bool on = env_int("SSG_TWO_CHAINS", 1) >= 0;
   return on;
@@ -309,7 +318,8 @@ static SideStream *side_stream() {
     if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s.forked, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s.joined, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.gate, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s.gate, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.gate2, hipEventDisableTiming) != hipSuccess) {
       s.side = nullptr;
       return nullptr;
     }
@@ -513,9 +523,11 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
   if (dbg_mask() & (1 << 29)) {
   } else if (classes) {
     const unsigned gg = grow_grid(p.n_host);
+    const bool early = chained && chain->gated && sd == st && ss != st && !(sched_mode() & 1);
+    if (early) rc = (int)hipEventRecord(chain->fk->gate, sd);   // (behind the dense forward, in front of its row pass)
     GrowParams gd = g;   // the dense-tile rows
     gd.only = 1;
-    rc = launch_grad_rows(gd, p.ks, p.kw, sd);
+    if (!rc) rc = launch_grad_rows(gd, p.ks, p.kw, sd);
     GrowParams gs = g;   // the plan's sparse list; its criteria sums behind the first pass's
     gs.only = 2;
     gs.grid_cap = 4096;
@@ -593,7 +605,8 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
     d.upstream = p.upstream;
   }
   if (chained) {   // two-chain step: each backward kernel behind its own chain's row pass; then the one join
-    if (chain->gated && sd == st && ss != st) {
+    const bool early = chain->gated && sd == st && ss != st && !(sched_mode() & 1);
+    if (chain->gated && sd == st && ss != st && !early) {
       rc = (int)hipEventRecord(chain->fk->gate, sd);
       if (!rc) rc = (int)hipStreamWaitEvent(ss, chain->fk->gate, 0);
       if (!rc && fin) {   // (both passes' criteria sums are complete behind the gate)
@@ -601,6 +614,11 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
                                   fin->loss_out, fin->nan_on_overflow, ss, fin->set_size);
         if (!rc && fin_done) *fin_done = true;
       }
+      if (rc) return leave(rc);
+    }
+    if (early) {   // the direct backward waits for the dense FORWARD only; the finalize, behind it, for the dense row pass
+      rc = (int)hipStreamWaitEvent(ss, chain->fk->gate, 0);
+      if (!rc) rc = (int)hipEventRecord(chain->fk->gate2, sd);
       if (rc) return leave(rc);
     }
     rc = launch_bwd_dense(d, p.ks, p.kw, p.C, sd);
@@ -612,6 +630,12 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
       s.n_dev = plan;  // n_sparse
       s.partials = nullptr;
       rc = launch_bwd(s, ss);
+    }
+    if (!rc && early && fin) {
+      rc = (int)hipStreamWaitEvent(ss, chain->fk->gate2, 0);
+      if (!rc) rc = launch_loss_finalize(fin->partials, fin->nparts, fin->n_dev, fin->n_host, fin->P, fin->w_l1, fin->w_kl,
+                                         fin->loss_out, fin->nan_on_overflow, ss, fin->set_size);
+      if (!rc && fin_done) *fin_done = true;
     }
     return leave(rc);
   }
