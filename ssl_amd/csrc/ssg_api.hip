@@ -232,6 +232,14 @@ static PlanHint plan_hint(bool allocate_never = false) {
   }
   return tab[dev];
 }
+// rows the last plan built on this device left to the direct kernels (-> FwdParams / BwdParams::rows_hint); 0 = unknown
+static int hint_sparse_rows() {
+  if (overlap_mode() != 3) return 0;
+  const PlanHint h = plan_hint(true);
+  if (!h.host) return 0;
+  const int n = ((volatile int *)h.host)[0];
+  return n > 0 ? n : 0;
+}
 namespace ssg {
 int *plan_hint_device_word(hipStream_t st) {
   if (overlap_mode() != 3) return nullptr;
@@ -629,6 +637,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
       s.order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
       s.n_dev = plan;  // n_sparse
       s.partials = nullptr;
+      s.rows_hint = hint_sparse_rows();
       rc = launch_bwd(s, ss);
     }
     if (!rc && early && fin) {
@@ -659,6 +668,7 @@ static int split_backward(BwdParams p, const int *rank, const int *plan, void *s
     s.order = plan + fwd_plan_order_offset(p.B, p.H, p.W);
     s.n_dev = plan;  // n_sparse
     s.partials = nullptr;
+    s.rows_hint = hint_sparse_rows();
     rc = launch_bwd(s, sp.direct);
   }
 
@@ -1034,6 +1044,7 @@ static int map_forward_impl(const float *img, const float *img2, int B, int C, i
     int rc = (dbg_mask() & (1 << 25)) ? 0 : launch_fwd_dense(d, ks, kw, C, sp.dense);
     p.order = fwd_plan + fwd_plan_order_offset(B, H, W);
     p.n_dev = fwd_plan;  // n_sparse
+    p.rows_hint = hint_sparse_rows();
     if (!rc && !(dbg_mask() & (1 << 26))) rc = launch_fwd(p, sp.direct);
     if (!rc && chain && fk && st2 != st) {   // two-chain step: the backward's kernels follow on the same two streams
       chain->fk = fk;

@@ -87,7 +87,12 @@ __device__ __forceinline__ int bwd_tiled_group(const BwdParams &p, const int vb)
   float *at = (float *)(sh_edge + JOBS * 4);  // [JOBS][C][KW][KW] centre windows
   float *gwin = at + JOBS * C * KW * KW;      // [JOBS][KW][KW] window gradients of the current channel
 
-  const int tid = threadIdx.x;
+  // (opaque to the optimiser: inside the tail kernel's group loop the lane constants derived from it would otherwise be
+  // hoisted out of the loop and held across the whole body -- 256 VGPRs + 31 AGPRs at (25,9), scratch at (49,13); the
+  // one-group kernels lose nothing by it)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  In tile order, job groups
   // g and g+1 update overlapping gradient pixels: give every XCD one contiguous range of groups so
@@ -869,11 +874,17 @@ static int launch_bwd_tiled(const BwdParams &p, hipStream_t st) {
   if (p.n_host == 0) return 0;
   // (a bound on the rows far above BWD_MAIN_GROUPS x JOBS: one workgroup per group up to there, the looping tail behind --
   //  not where the workgroups' criteria sums have a slot each, GRAD_LOSS on the direct-only path)
-  if (grid > BWD_MAIN_GROUPS && !p.partials) {
+  unsigned main_groups = BWD_MAIN_GROUPS;   // (with a hint of the rows to expect: 1.25 x that, see launch_fwd_tiled)
+  if (p.rows_hint > 0) {
+    const long want = ((long)p.rows_hint * 5 / 4 + G::JOBS - 1) / G::JOBS + 32;
+    const long capped = want < 512 ? 512 : (want > (long)BWD_MAIN_GROUPS ? (long)BWD_MAIN_GROUPS : want);
+    main_groups = (unsigned)((capped + 7) / 8 * 8);
+  }
+  if (grid > main_groups && !p.partials) {
     static std::atomic<unsigned long long> lds_set_tail{0};
     if (const int rc = ensure_dynamic_lds(ssg_bwd_tiled_tail<G, KHC>, 160 * 1024, lds_set_tail)) return rc;
-    hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(BWD_MAIN_GROUPS), dim3(G::WG), lds, st, p);
-    hipLaunchKernelGGL((ssg_bwd_tiled_tail<G, KHC>), dim3(BWD_TAIL_GRID), dim3(G::WG), lds, st, p, (int)BWD_MAIN_GROUPS);
+    hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(main_groups), dim3(G::WG), lds, st, p);
+    hipLaunchKernelGGL((ssg_bwd_tiled_tail<G, KHC>), dim3(BWD_TAIL_GRID), dim3(G::WG), lds, st, p, (int)main_groups);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(grid), dim3(G::WG), lds, st, p);

@@ -700,7 +700,10 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   // exchange itself (profiles/r6_bwd_dense_ablation.txt: 0.482 ms with them, 0.427 without exchange and branches,
   // 0.507 with the exchange in every row and no branch).
   auto offset_row = [&](auto cut_c, const int qyi) {
-    constexpr bool CUT = decltype(cut_c)::value;
+    // (cut_c: 0 = no exchange, 1 = in every step, 2 = ONE row body with a wave-uniform test per step -- the four-chunk
+    // instantiation of the TILE_HUGE tiles, which spills with two row bodies)
+    constexpr int CUTM = decltype(cut_c)::value;
+    constexpr bool CUT = CUTM == 1;
     // (next row's prefetches run unconditionally on clamped rows: the offset loop stays branch-free)
     const int qyn = qyi + 1 < KS ? qyi + 1 : KS - 1;
     // (first offsets of this and the next offset row for the tile-major loads, opaque to the optimiser: loop strength
@@ -715,6 +718,7 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
     float c_own = 0.f, c_oth = 0.f;
     if constexpr (REGW) cut_rows(qyi, l_oth, c_own, c_oth);
     else pw = prefix_rows(ylo, yhi);
+    const bool cut_now = CUTM == 2 && __ballot(c_own != 1.f || c_oth != 0.f) != 0ull;
     int eposc[NCH];   // where this row's offsets put G (REGW: under the row's shift)
 #pragma unroll
     for (int ck = 0; ck < NCH; ++ck) eposc[ck] = REGW ? shift_pos(epos[ck], row_shift(qyi)) : epos[ck];
@@ -758,6 +762,9 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
         // (cut rows: the exchange for this step was issued at the end of the previous one, right behind the prefix --
         // only the row's first step issues its own)
         if constexpr (CUT && qxi == 0) w_exchange(l_oth, vx);
+        if constexpr (CUTM == 2) {
+          if (cut_now) w_exchange(l_oth, vx);
+        }
       } else {
         y_read(fc, pw, Wv);
       }
@@ -794,7 +801,7 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
           // then waits for the lane exchange with nothing in between)
           asm volatile("" : "+v"(dA[i]), "+v"(dB[i]));
         }
-        w_finish(!CUT, vx, c_own, c_oth, Wv);
+        w_finish(CUTM == 2 ? !cut_now : !CUT, vx, c_own, c_oth, Wv);
       }
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
@@ -916,7 +923,10 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
   };
   if constexpr (!REGW) {
 #pragma unroll 1
-    for (int qyi = qy0; qyi < qy1; ++qyi) offset_row(std::false_type{}, qyi);
+    for (int qyi = qy0; qyi < qy1; ++qyi) offset_row(std::integral_constant<int, 0>{}, qyi);
+  } else if constexpr (NCH > 2) {
+#pragma unroll 1
+    for (int qyi = qy0; qyi < qy1; ++qyi) offset_row(std::integral_constant<int, 2>{}, qyi);
   } else {
     // a row is SIMPLE when every lane's W is its own prefix: full windows, and the cut rows next to them whose cut
     // does not reach into the tile (q_y = 21 for the top half, 3 for the bottom half)
@@ -932,13 +942,13 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       if (row_simple(qyi)) {
 #pragma unroll 1
         do {
-          offset_row(std::false_type{}, qyi);
+          offset_row(std::integral_constant<int, 0>{}, qyi);
           ++qyi;
         } while (qyi < qy1 && row_simple(qyi));
       } else {
 #pragma unroll 1
         do {
-          offset_row(std::true_type{}, qyi);
+          offset_row(std::integral_constant<int, 1>{}, qyi);
           ++qyi;
         } while (qyi < qy1 && !row_simple(qyi));
       }

@@ -168,6 +168,10 @@ struct FwdParams {
   int ks, kw;  // used by the generic kernel only
   int dbg;     // profiling ablations (0 in production): bit0 skip fill, bit1 skip compute, bit2 skip epilogue/store
   int small;   // direct forward, set by its launcher: which variants of a (25,9) launch run (ssg_fwd.hip, small_call)
+  // host-side only: rows the direct kernels are EXPECTED to get (0 = unknown) -- the sparse-row count of the last plan
+  // built on the device (ssg_api.hip: PlanHint).  Sizes the main grid; the looping tail kernel behind it takes whatever
+  // the hint missed, so a stale hint costs time, never rows.
+  int rows_hint;
 };
 
 // How the backward kernel obtains G = dL/dD for a job.
@@ -202,6 +206,7 @@ struct BwdParams {
   float *partials;  // GRAD_LOSS: (gridDim.x, 2) per-workgroup sums of |a-b| and t'(log t' - log s')
   int ks, kw;       // generic kernel only
   int dbg;          // profiling ablations (0 in production): bit0 skip prologue math, bit1 skip pass A, bit2 skip pass B, bit3 skip atomics
+  int rows_hint;    // host-side only: see FwdParams::rows_hint
 };
 
 // dL/dS of the two criteria at one element (a = s_sr, b = s_gt), and the

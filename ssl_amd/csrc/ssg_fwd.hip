@@ -71,10 +71,9 @@ __device__ __forceinline__ int fwd_tiled_group(const FwdParams &p, int grp) {
   int *sh_edge = (int *)(red + WG);                                // [JOBS][6]: b, y, x, row, which, pad
 
   int tid_ = threadIdx.x;
-  // (inside the k_s = 49 group loop: opaque to the optimiser, which would otherwise hoist the lane constants derived
-  // from it out of the loop and hold them across the whole body -- spills.  The k_s <= 25 tail kernel loops too, rarely:
-  // its registers are its own business)
-  if constexpr (G::KS >= 49) asm volatile("" : "+v"(tid_));
+  // (inside a group loop -- the k_s = 49 kernel's, and every size's tail kernel: opaque to the optimiser, which would
+  // otherwise hoist the lane constants derived from it out of the loop and hold them across the whole body)
+  asm volatile("" : "+v"(tid_));
   const int tid = tid_;
   const int nrows = rows_to_do(p.n_dev, p.n_host);
   // job numbering: row order -> q = row * nimg + image; tile order -> image-major, every image's
@@ -522,11 +521,20 @@ static int launch_fwd_tiled(const FwdParams &p, hipStream_t st) {
   const long ngroups = (njobs + G::JOBS - 1) / G::JOBS;
   unsigned grid = (unsigned)((ngroups + fwd_groups_per_wg<G>() - 1) / fwd_groups_per_wg<G>());
   if constexpr (fwd_groups_per_wg<G>() == 1) {
-    if (grid > FWD_MAIN_GROUPS) {   // (a generous capacity: the groups behind FWD_MAIN_GROUPS go to the looping tail)
+    // the main grid: one workgroup per group up to FWD_MAIN_GROUPS -- or, with a hint of the rows to expect (the last
+    // plan's), 1.25 x that: workgroups that start only to leave are dispatched at ~500 per us, which a short launch
+    // (BASELINE's C4: 3.4 k direct rows under a capacity of every pixel) does not hide
+    unsigned main_groups = FWD_MAIN_GROUPS;
+    if (p.rows_hint > 0) {
+      const long want = (((long)p.rows_hint * 5 / 4 + G::JOBS - 1) / G::JOBS + 32) * p.nimg;
+      const long capped = want < 512 ? 512 : (want > (long)FWD_MAIN_GROUPS ? (long)FWD_MAIN_GROUPS : want);
+      main_groups = (unsigned)((capped + 7) / 8 * 8);
+    }
+    if (grid > main_groups) {   // (a generous capacity: the groups behind the main grid go to the looping tail)
       static std::atomic<unsigned long long> lds_set_tail{0};
       if (const int rc = ensure_dynamic_lds(ssg_fwd_tiled_tail<G, MERGED>, 160 * 1024, lds_set_tail)) return rc;
-      hipLaunchKernelGGL((ssg_fwd_tiled<G, MERGED>), dim3(FWD_MAIN_GROUPS), dim3(G::WG), lds, st, p);
-      hipLaunchKernelGGL((ssg_fwd_tiled_tail<G, MERGED>), dim3(FWD_TAIL_GRID), dim3(G::WG), lds, st, p, (int)FWD_MAIN_GROUPS);
+      hipLaunchKernelGGL((ssg_fwd_tiled<G, MERGED>), dim3(main_groups), dim3(G::WG), lds, st, p);
+      hipLaunchKernelGGL((ssg_fwd_tiled_tail<G, MERGED>), dim3(FWD_TAIL_GRID), dim3(G::WG), lds, st, p, (int)main_groups);
       return (int)hipGetLastError();
     }
   }
@@ -548,10 +556,13 @@ static int launch_fwd_pair(FwdParams p, hipStream_t st) {
     // regular ones -- the device-side count picks -- while the bound is within 8x of it (a generous capacity), not at all
     // beyond (C2's 155 k jobs: no third launch)
     static const int mode = env_int("SSG_FWD_SMALL", 1) != 0;   // (profiling build: SSG_FWD_SMALL=0 = never, A/B measurements)
-    const long bound = (long)p.n_host * p.nimg;
+    // (with a hint of the rows to expect the host's bound is cut to twice that: a generous capacity then keeps the
+    // small-call variant in the launch, and the device-side count still picks)
+    long bound = (long)p.n_host * p.nimg;
+    if (p.rows_hint > 0 && 2L * p.rows_hint * p.nimg + 1024 < bound) bound = 2L * p.rows_hint * p.nimg + 1024;
     if (mode && bound <= 8L * SMALL_CALL_JOBS) {
       using GS3 = Geo<25, 9, 3, 256>;
-      p.small = bound <= SMALL_CALL_JOBS ? 1 : 2;
+      p.small = (long)p.n_host * p.nimg <= SMALL_CALL_JOBS ? 1 : 2;   // (alone only when the HOST's bound says so)
       const int rc = launch_fwd_tiled<GS3, false>(p, st);
       if (rc || p.small == 1) return rc;
     }
