@@ -59,6 +59,10 @@ CONFIGS = {
     "c4": dict(ks=25, kw=9, sigma=0.004, batch=2, H=512, W=512, dense_mask=False, eps=1e-20, stride=3, w=5e2, seed0=2000,
                name="C4: 2 x 3x512x512 per GPU, Laplacian mask x stride-3 pattern, k_s=25 k_w=9 sigma=0.004 eps=1e-20, "
                     "L1+KL w=5e2, SSGs materialised"),
+    # the sparse regime (round 6, review item 5): 4 x 3x256x256, Bernoulli 1 % mask (2,627 edge pixels, no dense tile) --
+    # direct kernels only, a step of ~10 dependent launches; the same generator stream as tools/sweep.py / sparse_step.py
+    "b1": dict(ks=25, kw=9, sigma=1.0, batch=4, H=256, W=256, dense_mask=False, bernoulli=0.01,
+               name="B1: 4 x 3x256x256 per GPU, Bernoulli 1 % mask, k_s=25 k_w=9 sigma=1.0, L1+KL w=1e3, SSGs materialised"),
 }
 EPS, C = 1e-10, 3
 W_L1 = W_KL = 1e3
@@ -646,6 +650,15 @@ def make_inputs(cfg, rank, world, scaling):
         sr = np.stack([synth.degrade(gt[i], 7 + rank * B + i) for i in range(B)])
         return sr, gt, np.ones((B, 1, H, W), np.float32)
     seed0 = cfg.get("seed0", 100)
+    if cfg.get("bernoulli"):
+        sr, gt, _ = synth.make_batch(B, H, W, seed0=seed0 + B * rank)
+        rng = np.random.default_rng(rank)
+        mask = None
+        for d in (0.01, 0.04):          # (tools/sweep.py's stream: the 1 % mask is its first draw)
+            mm = (rng.random((B, 1, H, W)) < d).astype(np.float32)
+            if mask is None and d == cfg["bernoulli"]:
+                mask = mm
+        return sr, gt, mask
     if scaling == "strong":
         lo, hi = shard_images(B, rank, world)
         sr, gt, mask = synth.make_batch(B, H, W, seed0=seed0)
@@ -893,6 +906,7 @@ def main():
                                 "c2_fused": extra_line("c2", True, dev, 30, 5),
                                 "c5_fused": extra_line("c5", True, dev, 10, 3),
                                 "c4": extra_line("c4", False, dev, 50, 10),
+                                "b1": extra_line("b1", False, dev, 100, 20),
                                 "c2_maskgen": extra_line("c2", False, dev, 30, 5, maskgen=True),
                                 "ref_api": ref_api_lines(cfg, sr, gt, mask, n_edges, elapsed / args.steps * 1e3),
                                 "ref_api_dm": ref_api_dm_line(dev),
