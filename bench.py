@@ -853,7 +853,7 @@ def main():
                 moved = pmc_step_bytes(key)
                 res["roofline"] = {"bound": "hbm", "alg_bytes_per_edge_px": b_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS, "traffic": moved,
-                                   "kernel": "whole step (per-kernel durations: profiles/r5_bench_%s_kernel_stats.csv)" % (key or "c2"),
+                                   "kernel": "whole step (per-kernel durations: profiles/r6_bench_%s_kernel_stats.csv)" % (key or "c2"),
                                    "step": {"gpu_ms": step_gpu_ms, "achieved": ach_step, "frac": ach_step / HBM_PEAK_GBS,
                                             "traffic": moved,
                                             "traffic_GBps": None if not moved else moved / (step_gpu_ms * 1e-3) / 1e9,

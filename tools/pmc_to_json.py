@@ -14,9 +14,9 @@ configuration's ssg kernels) -- ssg_grad_rows runs once per chain, i.e. twice pe
 (`roofline.step.traffic`, `valu.issued`) weight every kernel with it."""
 import collections, json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "profiles", "r5_pmc_summary.txt")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "profiles", "r6_pmc_summary.txt")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, --kernel-trace only, "
-                 "--no-overlap) over bench.py --config {c2,c4,c5} --steps 3 (tools/r5_final.sh -> " + os.path.relpath(src, root) +
+                 "--no-overlap) over bench.py --config {c2,c4,c5} --steps 3 (tools/r*_final.sh -> " + os.path.relpath(src, root) +
                  ", per-dispatch means); units and gfx950 corrections per MI355X_MICROARCH.md (HBM section): counters "
                  "are KiB, FETCH_SIZE counts 128-byte read requests as 64 bytes for wide coalesced streams (x2; an upper "
                  "bound for scattered reads), WRITE_SIZE is uncalibrated for partial-line stores",

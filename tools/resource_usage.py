@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """VGPR / AGPR / SGPR / scratch / static LDS / occupancy of every kernel in ssl_amd/csrc as the compiler reports them
-(hipcc -Rpass-analysis=kernel-resource-usage, gfx950, the Makefile's flags) -> profiles/r5_resource_usage.txt.
+(hipcc -Rpass-analysis=kernel-resource-usage, gfx950, the Makefile's flags) -> profiles/r6_resource_usage.txt.
 Runs without a GPU (about a minute).  DESIGN.md section 4's register figures are read off this file.
    python tools/resource_usage.py [out.txt]"""
 import os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "ssl_amd", "csrc")
-OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r5_resource_usage.txt")
+OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r6_resource_usage.txt")
 FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function".split()
 EXTRA = {"ssg_dense": ["-fno-slp-vectorize"], "ssg_bwd_dense": ["-fno-slp-vectorize"], "ssg_degrade": ["-ffp-contract=off"]}
 FILES = ["ssg_fwd", "ssg_dense", "ssg_bwd", "ssg_bwd_dense", "ssg_grow", "ssg_edges", "ssg_datapath", "ssg_degrade"]

@@ -60,7 +60,7 @@ class Generator(nn.Module):
         return self.last(F.leaky_relu(self.hr(f), 0.2))
 
 
-def _paired_steps(step, pairs=20):
+def _paired_steps(step, pairs=20, timer=None):
     """Interleaved measurement (A B A B ...): `pairs` times one step WITHOUT and one step WITH the SSL terms, each
     bracketed by a synchronise.  Two back-to-back blocks of a 50 ms step differ by more than the 0.5 ms under test on a
     box that is still settling its clocks (round 5's driver run recorded a negative share that way); paired steps see the
@@ -69,6 +69,8 @@ def _paired_steps(step, pairs=20):
         step(False)
         step(True)
     a, b = [], []
+    if timer is not None:
+        timer.on = True
     for _ in range(pairs):
         for flag, dst in ((False, a), (True, b)):
             torch.cuda.synchronize()
@@ -76,17 +78,47 @@ def _paired_steps(step, pairs=20):
             step(flag)
             torch.cuda.synchronize()
             dst.append((time.perf_counter() - t0) * 1e3)
+    if timer is not None:
+        timer.on = False
     d = sorted(y - x for x, y in zip(a, b))
     med = lambda v: sorted(v)[len(v) // 2]
     return dict(base=med(a), ssl=med(b), diff=med(d), diff_q1=d[len(d) // 4], diff_q3=d[(3 * len(d)) // 4], pairs=pairs)
 
 
-def _share(t, **kw):
-    """One `extra.c*_step_share` record from _paired_steps' figures: `ssl_ms` is the median PAIRED difference (not the
-    difference of the medians), `ssl_share` = ssl_ms / median step with SSL."""
-    return dict(step_ms_without_ssl=t["base"], step_ms_with_ssl=t["ssl"], ssl_ms=t["diff"],
-                ssl_ms_quartiles=[t["diff_q1"], t["diff_q3"]], ssl_share=t["diff"] / t["ssl"], pairs=t["pairs"],
-                how="A B A B interleaved single steps, median of the paired differences", **kw)
+class _LossTimer:
+    """HIP events around the loss module's call inside the step (the module runs the engine's forward AND backward
+    kernels in its forward and keeps the gradient: its autograd backward is one scaling): the stream time of the SSL
+    kernels of every timed step, whatever the generator's 50 ms do to the wall clock."""
+
+    def __init__(self):
+        self.pairs, self.on = [], False
+
+    def __call__(self, crit, *a):
+        if not self.on:
+            return crit(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = crit(*a)
+        e1.record()
+        self.pairs.append((e0, e1))
+        return out
+
+    def median_ms(self):
+        v = sorted(a.elapsed_time(b) for a, b in self.pairs)
+        return v[len(v) // 2] if v else None
+
+
+def _share(t, timer=None, **kw):
+    """One `extra.c*_step_share` record.  `ssl_ms` = the loss module's own stream time inside the step (HIP events around
+    its call, median over the timed steps: never negative, independent of the clocks during the generator's part);
+    `ssl_ms_paired_diff` = the median of the A B A B paired wall-clock differences with its quartiles (a 0.4 ms effect
+    under a +-0.5 ms step-to-step spread: reported, not relied on); `ssl_share` = ssl_ms / median step with SSL."""
+    inner = timer.median_ms() if timer is not None else None
+    ssl_ms = inner if inner is not None else t["diff"]
+    return dict(step_ms_without_ssl=t["base"], step_ms_with_ssl=t["ssl"], ssl_ms=ssl_ms, ssl_share=ssl_ms / t["ssl"],
+                ssl_ms_paired_diff=t["diff"], ssl_ms_paired_diff_quartiles=[t["diff_q1"], t["diff_q3"]], pairs=t["pairs"],
+                how="ssl_ms: HIP events around the loss module's call in every timed step (median); paired_diff: A B A B "
+                    "interleaved single steps, median of the paired wall-clock differences", **kw)
 
 
 def c3_step_share(dev, batch=4, pairs=20, check=None):
@@ -100,23 +132,23 @@ def c3_step_share(dev, batch=4, pairs=20, check=None):
     gt, mask = torch.as_tensor(gt_np, device=dev), torch.as_tensor(mask_np, device=dev)
     lq = F.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
     crit = SSGLoss(25, 9, 0.004, True, 1e3, 1e3)
-    last = {}
+    last, timer = {}, _LossTimer()
 
     def step(with_ssl):
         opt.zero_grad(set_to_none=True)
         sr = net(lq)
         loss = F.l1_loss(sr, gt)
         if with_ssl:
-            l1, kl = crit(sr, gt, mask)
+            l1, kl = timer(crit, sr, gt, mask)
             loss = loss + l1 + kl
             last.update(sr=sr.detach(), l1=l1.detach(), kl=kl.detach())
         loss.backward()
         opt.step()
 
-    t = _paired_steps(step, pairs)
+    t = _paired_steps(step, pairs, timer)
     if check is not None:
         check(net, last, gt, mask)
-    return _share(t, edge_px=int(mask_np.sum()),
+    return _share(t, timer, edge_px=int(mask_np.sum()),
                 what=f"RRDBNet-shaped x4 generator (23 RRDB, fp32, Adam), {batch} x 3x256x256 GT, SSL (25,9) sigma 0.004 w 1e3")
 
 
@@ -135,21 +167,22 @@ def c4_step_share(dev, pairs=20, check=None):
     gt, m = torch.as_tensor(gt_np, device=dev), torch.as_tensor(m_np, device=dev)
     z = torch.randn(2, 4, 64, 64, device=dev)
     crit = SSGLoss(25, 9, 0.004, True, 5e2, 5e2, mask_stride=3, eps=1e-20)
+    timer = _LossTimer()
 
     def step(with_ssl):
         opt.zero_grad(set_to_none=True)
         img = dec(z)
         loss = 0.1 * F.l1_loss(img, gt)
         if with_ssl:
-            l1, kl = crit(img, gt, m)
+            l1, kl = timer(crit, img, gt, m)
             loss = loss + l1 + kl
         loss.backward()
         opt.step()
 
-    t = _paired_steps(step, pairs)
+    t = _paired_steps(step, pairs, timer)
     if check is not None:
         check(dec)
-    return _share(t, edge_px=int(crit.last_counts[0]),
+    return _share(t, timer, edge_px=int(crit.last_counts[0]),
                 what="stand-in decoder tail (4x64x64 latent -> 2 x 3x512x512), 0.1 pixel L1, SSL (25,9) stride 3 eps 1e-20 w 5e2")
 
 
