@@ -880,7 +880,7 @@ static int launch_bwd_tiled(const BwdParams &p, hipStream_t st) {
     const long capped = want < 512 ? 512 : (want > (long)BWD_MAIN_GROUPS ? (long)BWD_MAIN_GROUPS : want);
     main_groups = (unsigned)((capped + 7) / 8 * 8);
   }
-  if (grid > main_groups && !p.partials) {
+  if ((grid > main_groups + 4096 || grid > BWD_MAIN_GROUPS) && !p.partials) {   // (a tail launch costs ~5 us: see launch_fwd_tiled)
     static std::atomic<unsigned long long> lds_set_tail{0};
     if (const int rc = ensure_dynamic_lds(ssg_bwd_tiled_tail<G, KHC>, 160 * 1024, lds_set_tail)) return rc;
     hipLaunchKernelGGL((ssg_bwd_tiled<G, KHC>), dim3(main_groups), dim3(G::WG), lds, st, p);
