@@ -791,7 +791,8 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
       // the pixel differences first: they do not depend on W (REGW: they cover the cut rows' lane exchange)
       f2 dA[NPX];
       float dB[NPX];
-      if constexpr (REGW) {
+      constexpr bool DIFF_FIRST = REGW && NCH <= 2;   // (the four-chunk instantiation is at its register budget: differences next to their use)
+      if constexpr (DIFF_FIRST) {
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
           const int sl = (i + qxi) % NPX;
@@ -802,6 +803,8 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
           asm volatile("" : "+v"(dA[i]), "+v"(dB[i]));
         }
         w_finish(CUTM == 2 ? !cut_now : !CUT, vx, c_own, c_oth, Wv);
+      } else if constexpr (REGW) {
+        w_finish(CUTM == 2 ? !cut_now : !CUT, vx, c_own, c_oth, Wv);
       }
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
@@ -811,7 +814,7 @@ __device__ __forceinline__ void bwd_dense_body(const DenseBwdParams &p) {
           else swb[i] = __builtin_fmaf(Wi, ymask, swb[i]);
         }
         const int sl = (i + qxi) % NPX;
-        if constexpr (!REGW) {   // (the other lane maps form the differences next to their use: fewer live registers)
+        if constexpr (!DIFF_FIRST) {   // (the other lane maps form the differences next to their use: fewer live registers)
           dA[i] = DO_A ? iuA[i] - wA[sl] : f2{0.f, 0.f};
           dB[i] = DO_B ? iuB[i] - wB[sl] : 0.f;
         }

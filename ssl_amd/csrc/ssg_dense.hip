@@ -483,15 +483,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // (i + qxi) % L -- a compile-time function of the step
       // (channel-major: consecutive packed operations belong to different pixel pairs -- with the pair loop outside,
       // every v_pk_fma waited for the one before it, an s_nop each: 14 idle issue slots of ~125 per step)
+      // (the four-chunk instantiations are at their register budget: pair-major there, as before)
       f2 E[HL];
+      if constexpr (NCHUNK <= 2) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int j = 0; j < HL; ++j) {
+            const int a = (j + qxi) % L;  // slot of pixel j; pixel j + L/2 sits in slot (a + L/2) % L
+            const f2 wv2 = a < HL ? w[c][a] : w[c][a - HL].yx;
+            const f2 d = iu[c][j] - wv2;
+            E[j] = c == 0 ? d * d : __builtin_elementwise_fma(d, d, E[j]);
+          }
+        }
+      } else {
 #pragma unroll
         for (int j = 0; j < HL; ++j) {
-          const int a = (j + qxi) % L;  // slot of pixel j; pixel j + L/2 sits in slot (a + L/2) % L
-          const f2 wv2 = a < HL ? w[c][a] : w[c][a - HL].yx;
-          const f2 d = iu[c][j] - wv2;
-          E[j] = c == 0 ? d * d : __builtin_elementwise_fma(d, d, E[j]);
+          const int a = (j + qxi) % L;
+          f2 t = f2{0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const f2 wv2 = a < HL ? w[c][a] : w[c][a - HL].yx;
+            const f2 d = iu[c][j] - wv2;
+            t = __builtin_elementwise_fma(d, d, t);
+          }
+          E[j] = t;
         }
       }
       // horizontal sums for the lane's L centre columns k (window = pixels k .. k+KW-1 of the row: the lane's own
