@@ -558,11 +558,12 @@ static int launch_fwd_pair(FwdParams p, hipStream_t st) {
     // regular ones -- the device-side count picks -- while the bound is within 8x of it (a generous capacity), not at all
     // beyond (C2's 155 k jobs: no third launch)
     static const int mode = env_int("SSG_FWD_SMALL", 1) != 0;   // (profiling build: SSG_FWD_SMALL=0 = never, A/B measurements)
-    // (with a hint of the rows to expect the host's bound is cut to twice that: a generous capacity then keeps the
-    // small-call variant in the launch, and the device-side count still picks)
-    long bound = (long)p.n_host * p.nimg;
-    if (p.rows_hint > 0 && 2L * p.rows_hint * p.nimg + 1024 < bound) bound = 2L * p.rows_hint * p.nimg + 1024;
-    if (mode && bound <= 8L * SMALL_CALL_JOBS) {
+    // (with a hint of the rows to expect the variant is launched when THAT says "small" -- within 1.25 x, the device-side count
+    // still picks -- whatever the host's bound: a generous capacity keeps it, a C2-sized call under a tight capacity does
+    // not pay for its empty grid)
+    const long bound = (long)p.n_host * p.nimg;
+    const bool want = p.rows_hint > 0 ? 4L * p.rows_hint * p.nimg <= 5L * SMALL_CALL_JOBS : bound <= 8L * SMALL_CALL_JOBS;
+    if (mode && want) {
       using GS3 = Geo<25, 9, 3, 256>;
       p.small = (long)p.n_host * p.nimg <= SMALL_CALL_JOBS ? 1 : 2;   // (alone only when the HOST's bound says so)
       const int rc = launch_fwd_tiled<GS3, false>(p, st);
