@@ -13,9 +13,10 @@ step(sr, gt, mask); torch.cuda.synchronize()
 p = engine._ptr
 st = torch.cuda.current_stream().cuda_stream
 el = engine.edge_list(mask=mask, capacity=n + 1024, ks=25)
+rsc = torch.empty(2 * (n + 1024), dtype=torch.float64, device=dev) if "--deferred" in sys.argv else None
 def fwd():
     _lib.check(L.ssg_map_forward(p(sr), p(gt), 16, 3, 256, 256, p(el.edges), p(el.order), p(el.rank), p(el.plan), p(el.counts),
-                                 n, 25, 9, 1.0, 1e-10, 1, p(step.ssg_sr), p(step.ssg_gt), None, st))
+                                 n, 25, 9, 1.0, 1e-10, 1, p(step.ssg_sr), p(step.ssg_gt), p(rsc), st))
 base = 1 << 26   # skip the direct forward launches
 for name, bits in (("full", 0), ("no stores", 1), ("no edge stage", 2), ("no rescale", 8), ("no stores+no rescale", 9),
                    ("no edge, no rescale", 10), ("no main loop", 64)):
