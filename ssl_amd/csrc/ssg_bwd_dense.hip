@@ -68,32 +68,18 @@ __device__ __forceinline__ void window_sums(const float (&v)[NV], float (&out)[N
 }
 
 
-// Inclusive prefix over 8 tile rows held 2 lanes apart in a 16-lane DPP row, for 5 values at once: 15 in-place DPP
-// adds (a lane whose source lies outside its row keeps its value).  The leading s_nop covers the VALU-write ->
-// DPP-read wait states the assembler does not insert for inline asm; inside the block 4 instructions separate a
-// register's write from its next DPP read.
+// Inclusive prefix over 8 tile rows held 2 lanes apart in a 16-lane DPP row, for 5 values at once: 15 `v_add_f32_dpp`
+// (row_shr 2 / 4 / 8 with bound_ctrl: a lane whose source lies outside its row adds 0).  Written with the DPP intrinsic
+// -- hipcc folds move and addition into one instruction and places the wait states itself (round 6; the hand-written
+// asm block of rounds 3-5 with its two s_nop measured the same: 0.413 ms either way).
 __device__ __forceinline__ void dpp_prefix8x5(float (&v)[5]) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
+#pragma unroll
+  for (int i = 0; i < 5; ++i) v[i] += dpp_row_shr<2>(v[i]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) v[i] += dpp_row_shr<4>(v[i]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) v[i] += dpp_row_shr<8>(v[i]);
 }
-
 // Nothing moves across an offset step: without it hipcc hoists the address arithmetic and the LDS loads of all
 // k_s unrolled steps to the top of the offset row (1,100 live values, 650 spilled).
 __device__ __forceinline__ void step_fence() {
