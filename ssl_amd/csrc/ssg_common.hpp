@@ -317,9 +317,17 @@ __device__ __forceinline__ float loss_grad_bound(float sigma, int C, int kw, flo
   const float u1 = upstream ? fabsf(upstream[0]) : 1.f, u2 = upstream ? fabsf(upstream[1]) : 1.f;
   return 4.f * kfac * (fabsf(w_l1) * u1 + fabsf(w_kl) * u2) * invM;
 }
+// round(v * scale) as a 64-bit integer, round-half-even like __float2ll_rn(v * scale) (the product is exact: scale is a
+// power of two), through the double "magic number": x + 1.5 * 2^52 leaves the integer in the low mantissa bits for
+// |x| < 2^51 -- a contribution is below 2^36 * a few dozen terms.  Four instructions (two of them fp64) instead of the
+// twelve of the fp32 -> i64 conversion sequence: the conversion was 2-3 % of both backward kernels' instructions.
+__device__ __forceinline__ long long fix_round(float v, float scale) {
+  const double x = __builtin_fma((double)v, (double)scale, 6755399441055744.0);   // 1.5 * 2^52
+  return __double_as_longlong(x) - 0x4338000000000000LL;
+}
 __device__ __forceinline__ void grad_add(float *grad, long long *gfix, size_t idx, float v, float scale) {
   if (gfix)
-    atomicAdd((unsigned long long *)gfix + idx, (unsigned long long)__float2ll_rn(v * scale));
+    atomicAdd((unsigned long long *)gfix + idx, (unsigned long long)fix_round(v, scale));
   else
     unsafeAtomicAdd(grad + idx, v);
 }
