@@ -827,6 +827,39 @@ def test_direct_kernels_beyond_their_main_grid(dev):
     assert maxerr(g0, g1) <= 2e-3 * np.abs(g1).max()
 
 
+def test_direct_kernels_main_grid_from_a_stale_plan_hint(dev):
+    """Round 6: the main grids of the (25,9) direct kernels follow the sparse-row count of the LAST plan built on the device
+    (1.25 x, host-mapped hint, no synchronisation) when the host's bound exceeds them by more than 4,096 groups, and a
+    looping tail kernel takes the groups behind -- a stale hint may cost time, never rows.  A step with ~30 k direct rows
+    under a generous capacity right after a step with a few dozen (main grid of 512 groups, ~5.5 k groups in the tails)
+    against the same step again (hint now exact): bit-identical rows, losses and deterministic gradient."""
+    from ssl_amd import engine, synth
+    B, H, W = 2, 256, 256
+    sr, gt, _ = synth.make_batch(B, H, W, seed0=3200)
+    rng = np.random.default_rng(32)
+    tiny = np.zeros((B, 1, H, W), np.float32)
+    tiny[:, 0, 10, 10:40:3] = 1.0
+    big = (rng.random((B, 1, H, W)) < 0.23).astype(np.float32)
+    prev = engine.set_dense_threshold(0)        # every row through the direct kernels
+    try:
+        small = engine.LossStep(B, 3, H, W, 25, 9, 0.05, 1e-10, True, 1e3, 1e3, device=dev, capacity=B * H * W)
+        step = engine.LossStep(B, 3, H, W, 25, 9, 0.05, 1e-10, True, 1e3, 1e3, device=dev, capacity=B * H * W)
+        res = []
+        for stale in (True, False):
+            if stale:
+                small(T(sr, dev), T(gt, dev), T(tiny, dev))     # leaves a hint of 20 rows
+                torch.cuda.synchronize()
+            loss, grad = step(T(sr, dev), T(gt, dev), T(big, dev))
+            torch.cuda.synchronize()
+            n = int(step.counts[0])
+            assert n == int(big.sum()) and n > 5 * (512 + 4096)
+            res.append((loss.clone(), grad.clone(), step.ssg_sr[:n].clone(), step.ssg_gt[:n].clone()))
+        for a, b in zip(*res):
+            assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    finally:
+        engine.set_dense_threshold(prev)
+
+
 def test_stream_assignment_follows_the_last_plan(dev):
     """ssg_set_overlap(3), the default: the edge-list builder leaves {rows for the direct kernels, dense tiles} of its
     plan in host-mapped memory and the next forked pass keeps the branch expected to run longer on the caller's stream
