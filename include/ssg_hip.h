@@ -60,6 +60,7 @@ typedef void *ssg_stream_t; /* hipStream_t */
 /* 5 (round 5): + ssg_set_overlap (modes 0-3, default 3 = per pass from the last plan's shape), ssg_last_overlap_assignment;
  * the product library no longer reads ANY environment variable (SSG_DENSE_THR, SSG_OVERLAP, SSG_OP_PLAN_FROM ... are
  * honoured by the profiling build only); the one-wave tile-major dense backward is gone. */
+/* 6 (round 6): + ssg_set_tiny_step; default dense threshold 16. */
 int ssg_abi_version(void);
 const char *ssg_status_string(int status);
 /* Device-side refusals that no return value can carry (everything is asynchronous): waits for `stream`, then returns
@@ -178,6 +179,15 @@ int ssg_set_dense_threshold(int edge_pixels_per_tile);
 int ssg_set_overlap(int mode);
 /* Diagnostics: the assignment the calling thread's last forked pass used (0 not forked, 1, 2 as above). */
 int ssg_last_overlap_assignment(void);
+/* Small fused steps.  ssg_loss_fwd_bwd / ssg_loss_step at (k_s, k_w, C) = (11, 5, 3) -- BASELINE's configs[0], the
+ * reference's own CPU-runnable case (loss_util.py:185-229 on a 64 x 64 crop) -- with B*H*W <= 16,384 pixels and
+ * capacity <= 4,096 rows run as TWO launches: one workgroup builds the edge list and clears the sums, then one workgroup
+ * per edge pixel computes both SSG rows, the criteria and the row's gradient, and the last one through folds the step
+ * (ssg_tiny.hip; C1: 59 -> about 20 us).  Same outputs, workspace and error behaviour as the general path; results equal
+ * to rounding (other summation orders), bit-reproducible in deterministic mode.  The workspace then holds the edge list and
+ * the rank map but no tile order.  on = 0 keeps every call on the general path (default 1).  Process-wide; returns the
+ * previous setting.  No reference counterpart. */
+int ssg_set_tiny_step(int on);
 int ssg_edge_list(const void *mask, int mask_kind, int mask_channels, int B,
                   int H, int W, int mask_stride, float lap_threshold,
                   int plan_ks /* k_s the fwd_plan is built for (tile rows: 8, or 4 for k_s = 49); 0 = 25.

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "ssg_set_dense_threshold": (_i, [_i]),
     "ssg_set_overlap": (_i, [_i]),
     "ssg_last_overlap_assignment": (_i, []),
+    "ssg_set_tiny_step": (_i, [_i]),
     "ssg_edge_list": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssg_edge_mask_laplacian": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "ssg_map_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp,

@@ -81,6 +81,12 @@ int launch_usm_sharp(const float *img, float *out, int B, int C, int H, int W, i
 int launch_grad_fix_flush(long long *gfix, float *grad, size_t n, int assign, hipStream_t st, const LossFinalize *fin = nullptr);
 int launch_grad_fix_bound(const BwdParams &p, hipStream_t st);
 int launch_grad_fix_reduce(const float *part, int n, long long *gfix, size_t n_fix, hipStream_t st);
+bool tiny_edge_list_ok(int B, int H, int W);
+int launch_tiny_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
+                          int *edges, int capacity, int *counts, int *rank, void *zero_a, size_t zero_a_bytes,
+                          void *zero_b, size_t zero_b_bytes, void *zero_c, size_t zero_c_bytes, hipStream_t st);
+bool tiny_step_supported(int ks, int kw, int C, int capacity);
+int launch_tiny_step(const TinyParams &p, int C, hipStream_t st);
 }  // namespace ssg
 
 using namespace ssg;
@@ -108,6 +114,9 @@ static int dense_threshold() {
   return v;
 }
 
+// Small (11,5) steps in two launches (ssg_tiny.hip); on by default, ssg_set_tiny_step(0) keeps every call on the general path.
+static std::atomic<int> g_tiny_step{1};
+extern "C" int ssg_set_tiny_step(int on) { return g_tiny_step.exchange(on != 0 ? 1 : 0, std::memory_order_relaxed); }
 extern "C" int ssg_set_operator_plan_threshold(int positions);
 extern "C" int ssg_set_dense_threshold(int edge_pixels_per_tile) {
   const int prev = dense_threshold();
@@ -815,7 +824,7 @@ static bool split_ok(int ks, int kw, int C, const int *rank, const int *plan, co
 
 extern "C" {
 
-int ssg_abi_version(void) { return 5; }
+int ssg_abi_version(void) { return 6; }
 
 const char *ssg_status_string(int status) {
   switch (status) {
@@ -1309,6 +1318,43 @@ static int loss_fwd_bwd_impl(const float *sr, const float *gt, const void *mask,
   }
   int *edges = (int *)(ws + lw.edges);
   int *rank = (int *)(ws + lw.rank);
+  // small (11,5) steps: one workgroup builds the edge list, one workgroup per edge pixel does the rest (ssg_tiny.hip)
+  if (g_tiny_step.load(std::memory_order_relaxed) && tiny_step_supported(ks, kw, C, capacity) && tiny_edge_list_ok(B, H, W) &&
+      B > 0 && H > ks / 2 && W > ks / 2 && mask_kind >= 0 && mask_kind <= 2 && (mask_kind == 2 || mask_channels > 0)) {
+    const bool fixed = grad_fix && grad_sr;
+    int *ticket = (int *)(ws + lw.escratch);
+    int rc = launch_tiny_edge_list(mask_kind == 2 ? (const void *)gt : mask, mask_kind, mask_kind == 2 ? 3 : mask_channels, B, H, W,
+                                   mask_stride, lap_threshold, edges, capacity, counts, rank, ticket, 16,
+                                   fixed ? grad_fix : nullptr, sizeof(long long) * ((size_t)B * C * H * W + 8),
+                                   (grad_is_output && grad_sr && !fixed) ? (void *)grad_sr : nullptr,
+                                   sizeof(float) * (size_t)B * C * H * W, (hipStream_t)stream);
+    if (rc) return rc;
+    TinyParams t{};
+    t.img[0] = sr;
+    t.img[1] = gt;
+    t.out[0] = fused ? nullptr : ssg_sr;
+    t.out[1] = fused ? nullptr : ssg_gt;
+    t.edges = edges;
+    t.n_dev = counts;
+    t.n_host = capacity;
+    t.B = B;
+    t.H = H;
+    t.W = W;
+    t.sigma = sigma;
+    t.eps = eps;
+    t.generalization = generalization;
+    t.w_l1 = w_l1;
+    t.w_kl = w_kl;
+    t.grad = grad_sr;
+    t.gfix = fixed ? (long long *)grad_fix : nullptr;
+    t.assign = grad_is_output ? 1 : 0;
+    t.partials = (float *)(ws + lw.lscratch);
+    t.loss_out = loss_out;
+    t.ticket = ticket;
+    t.nan_on_overflow = 1;
+    t.dbg = env_int("SSG_TINY_DBG", 0);
+    return launch_tiny_step(t, C, (hipStream_t)stream);
+  }
   int *order = (int *)(ws + lw.order);
   int *plan = (int *)(ws + lw.plan);
   void *escratch = ws + lw.escratch;

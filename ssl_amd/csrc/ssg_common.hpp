@@ -479,6 +479,27 @@ struct DenseBwdParams {
   int *status;         // nullable: library-owned device status word (ssg_device_status)
 };
 
+// ssg_tiny_step (ssg_tiny.hip): the fused loss step of small (11,5) calls
+struct TinyParams {
+  const float *img[2];   // sr, gt (B,C,H,W)
+  float *out[2];         // SSG rows (n, P) each
+  const int *edges;      // (n,3)
+  const int *n_dev;      // counts[0]
+  int n_host;            // capacity
+  int B, H, W;
+  float sigma, eps;
+  int generalization;
+  float w_l1, w_kl;
+  float *grad;           // nullable: loss only
+  long long *gfix;       // nullable: fp32 atomics
+  int assign;            // the gradient is an output: grad = sums
+  float *partials;       // (capacity, 2)
+  float *loss_out;
+  int *ticket;           // zeroed by tiny_edge_list
+  int nan_on_overflow;
+  int dbg;               // profiling ablations (0 in production): 1 no forward sums, 2 no backward, 4 no atomics, 8 no fold, 16 no rows
+};
+
 __device__ __forceinline__ int rows_to_do(const int *n_dev, int n_host) {
   int n = n_host;
   if (n_dev) {

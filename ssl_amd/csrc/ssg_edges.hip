@@ -1013,6 +1013,98 @@ int launch_edge_list(const void *mask, int kind, int mask_channels, int B, int H
   return (int)hipGetLastError();
 }
 
+// ---- small calls: the whole edge list by ONE workgroup, one launch (round 6) ----
+// BASELINE's C1 (1 x 3 x 64 x 64, 209 edge pixels) spends 3 x 5 us of its 59 us step in the three launches of the banded
+// builder.  Up to TINY_LIST_PIXELS pixels one 1,024-lane workgroup does it all: clears the caller's ranges (the
+// fixed-point gradient sums, the gradient, the step's ticket word), evaluates the predicate of TINY_PPT consecutive
+// pixels per lane (image-major, row-major: a lane's pixels are consecutive in the reference's torch.nonzero order,
+// similaritywrapper.py:64-67), scans the counts and writes rows, rank map and counts exactly as the other builders do
+// (counts[0] = counts[1+B] = N found, counts[1+b] = first row of image b; rows at and beyond `capacity` are dropped, their
+// rank is -1).  No tile order, no plan: its caller (ssg_tiny.hip) works row by row.
+constexpr int TINY_LIST_PIXELS = 16384, TINY_PPT_MAX = TINY_LIST_PIXELS / 1024;
+static_assert(TINY_PPT_MAX <= 32, "a lane keeps its pixels' predicate bits in one word");
+struct TinyZero {
+  void *ptr[3];
+  size_t bytes[3];   // multiples of 4
+};
+__global__ __launch_bounds__(1024) void tiny_edge_list(EdgeParams p, int *edges, int capacity, int *counts, int *rank,
+                                                       TinyZero z) {
+  __shared__ int wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // (workgroups 1 .. gridDim-1 clear the ranges beside the one that builds the list; launched alone, workgroup 0 does both)
+  if (blockIdx.x > 0 || gridDim.x == 1) {
+    const size_t t0 = gridDim.x == 1 ? tid : (size_t)(blockIdx.x - 1) * 1024 + tid, nt = gridDim.x == 1 ? 1024 : (size_t)(gridDim.x - 1) * 1024;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (!z.ptr[k]) continue;
+      const size_t n16 = (((size_t)z.ptr[k] & 15) == 0) ? z.bytes[k] / 16 : 0;
+      uint4 *q = (uint4 *)z.ptr[k];
+      for (size_t i = t0; i < n16; i += nt) q[i] = make_uint4(0, 0, 0, 0);
+      unsigned *w = (unsigned *)z.ptr[k];
+      for (size_t i = 4 * n16 + t0; i < z.bytes[k] / 4; i += nt) w[i] = 0u;
+    }
+    if (blockIdx.x > 0) return;
+  }
+  const int HW = p.H * p.W, npix = p.B * HW;
+  const int ppt = (npix + 1023) / 1024;            // <= TINY_PPT_MAX (the launcher's condition)
+  const int i0 = tid * ppt;
+  unsigned bits = 0;
+  for (int k = 0; k < ppt; ++k) {
+    const int i = i0 + k;
+    if (i < npix) {
+      const int b = i / HW, r = i - b * HW, y = r / p.W, x = r - y * p.W;
+      if (edge_pred(p, b, y, x)) bits |= 1u << k;
+    }
+  }
+  const int c = __popc(bits);
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wtot[wv] = incl;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int t = wtot[k];
+    before += k < wv ? t : 0;
+    total += t;
+  }
+  int pos = before + incl - c;
+  for (int k = 0; k < ppt; ++k) {
+    const int i = i0 + k;
+    if (i >= npix) break;
+    const int b = i / HW, r = i - b * HW;
+    if (r == 0) counts[1 + b] = pos;
+    const bool on = (bits >> k) & 1u, kept = on && pos < capacity;
+    if (kept) {
+      const int y = r / p.W, x = r - y * p.W;
+      edges[3 * (size_t)pos + 0] = b;
+      edges[3 * (size_t)pos + 1] = y;
+      edges[3 * (size_t)pos + 2] = x;
+    }
+    if (rank) rank[i] = kept ? pos : -1;
+    if (on) ++pos;
+  }
+  if (tid == 0) counts[0] = counts[1 + p.B] = total;
+}
+
+bool tiny_edge_list_ok(int B, int H, int W) { return (long)B * H * W <= TINY_LIST_PIXELS; }
+
+int launch_tiny_edge_list(const void *mask, int kind, int mask_channels, int B, int H, int W, int stride, float thr,
+                          int *edges, int capacity, int *counts, int *rank, void *zero_a, size_t zero_a_bytes,
+                          void *zero_b, size_t zero_b_bytes, void *zero_c, size_t zero_c_bytes, hipStream_t st) {
+  if (!tiny_edge_list_ok(B, H, W)) return -1;
+  EdgeParams p{mask, kind, mask_channels, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
+  const TinyZero z{{zero_a, zero_b, zero_c}, {zero_a ? zero_a_bytes : 0, zero_b ? zero_b_bytes : 0, zero_c ? zero_c_bytes : 0}};
+  const size_t zbytes = z.bytes[0] + z.bytes[1] + z.bytes[2];
+  const unsigned grid = zbytes > 4096 ? 1u + (unsigned)((zbytes + 16383) / 16384 < 16 ? (zbytes + 16383) / 16384 : 16) : 1u;
+  hipLaunchKernelGGL(tiny_edge_list, dim3(grid), dim3(1024), 0, st, p, edges, capacity, counts, rank, z);
+  return (int)hipGetLastError();
+}
+
 int launch_edge_mask(const float *gt, int B, int H, int W, float thr, int stride, uint8_t *out, hipStream_t st) {
   EdgeParams p{gt, 2, 3, B, H, W, stride, thr, (int)(((size_t)H * W + CHUNK - 1) / CHUNK)};
   hipLaunchKernelGGL(edge_mask_write, dim3(B * p.nblk_img), dim3(256), 0, st, p, out);

@@ -146,6 +146,13 @@ def set_dense_threshold(edge_pixels_per_tile):
     return _lib.lib().ssg_set_dense_threshold(int(edge_pixels_per_tile))
 
 
+def set_tiny_step(on):
+    """Small (11,5) fused steps (B*H*W <= 16,384 pixels, capacity <= 4,096 rows: BASELINE's C1) in two launches -- one
+    workgroup per edge pixel (ssg_tiny.hip); True by default, False keeps every call on the general path.  Same results
+    to rounding.  Returns the previous setting."""
+    return bool(_lib.lib().ssg_set_tiny_step(int(bool(on))))
+
+
 def edge_mask_laplacian(gt, lap_threshold=20.0, mask_stride=0):
     """(B,3,H,W) float32 in [0,1] -> (B,H,W) uint8 {0,1}: generate_mask.py:22-31 on device."""
     _need_gpu(gt)

@@ -42,7 +42,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     # every prototype the Python binding uses is declared in the header
     assert set(_lib.PROTOTYPES) <= declared - profile_only
     lib = _lib.lib()
-    assert lib.ssg_abi_version() == 5
+    assert lib.ssg_abi_version() == 6
     assert lib.ssg_status_string(0) == b"ok"
     assert b"LDS" in lib.ssg_status_string(-2)
     assert lib.ssg_kernel_name(25, 9, 0).startswith(b"ssg_fwd_")

@@ -2020,7 +2020,8 @@ def test_loss_step_gradient_is_an_output(dev, det):
             grad = torch.full((B, C, H, W), fill, device=dev)
             fix = torch.empty(L.ssg_grad_fix_bytes(B, C, H, W), dtype=torch.uint8, device=dev) if det else None
             p = engine._ptr
-            _lib.check(fn(p(T(sr, dev)), p(T(gt, dev)), p(T(mask, dev)), 0, 1, B, C, H, W, ks, kw, 0.05, 1e-10, 1, 1e3,
+            srt, gtt, mt = T(sr, dev), T(gt, dev), T(mask, dev)   # (kept alive: temporaries would be handed the same block)
+            _lib.check(fn(p(srt), p(gtt), p(mt), 0, 1, B, C, H, W, ks, kw, 0.05, 1e-10, 1, 1e3,
                           1e3, 0, 20.0, cap, None, None, p(counts), p(loss), p(grad), p(ws), nb, p(fix),
                           torch.cuda.current_stream().cuda_stream))
             torch.cuda.synchronize()
