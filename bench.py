@@ -499,6 +499,17 @@ def extra_line(cfg_key, fused, dev, steps, warmup, maskgen=False):
     else:
         first_round = timed(mask)        # (a rehearsal, like the headline's pre-warm: a workload new to the process runs its
         ms = timed(mask)                 #  first block 1-3 % slow; reported as `first_round_ms`)
+        if cfg_key == "c1":
+            # the same step object on the general six-launch path (ssg_set_tiny_step(0)) and back, alternating: what the
+            # two-launch path of small (11,5) calls (ssg_tiny.hip) buys, whatever the box's clocks do meanwhile
+            runs = []
+            for on in (False, True, False, True):
+                prev = engine.set_tiny_step(on)
+                try:
+                    runs.append(timed(mask))
+                finally:
+                    engine.set_tiny_step(prev)
+            same_harness = {"general_path_ms": [runs[0], runs[2]], "two_launch_path_ms": [runs[1], runs[3]]}
     assert int(step.counts[0]) == n
     loss = step.loss.cpu().numpy()
     b_alg = alg_bytes_per_edge_px(cfg, n, B) - (8.0 * cfg["ks"] ** 2 if fused else 0.0)

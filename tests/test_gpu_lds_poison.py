@@ -106,3 +106,15 @@ def test_merged_forward_and_backward_under_lds_poison(dev, word):
             assert err <= tol * ref, (name, err, ref)
     finally:
         engine.set_dense_threshold(thr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("word", PATTERNS)
+def test_two_launch_small_step_under_lds_poison(dev, word):
+    """ssg_tiny.hip keeps tiles, rows, G, the staged gradient and six kinds of partial sums in LDS and runs rows in a loop
+    (1,640 rows on 1,024 workgroups): its oracle cases under LDS poison."""
+    import test_gpu_tiny as tt
+    with poisoned(word):
+        tt.test_tiny_step_vs_oracle(dev, 3, 48, 56, 0.08, 0.1, True)
+        tt.test_tiny_step_vs_oracle(dev, 1, 7, 9, 0.5, 0.2, True)
+        tt.test_tiny_step_more_rows_than_workgroups_and_capacity_cut(dev)
