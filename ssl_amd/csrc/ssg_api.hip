@@ -1196,7 +1196,9 @@ static int loss_backward(const float *sr, int B, int C, int H, int W, const int 
   const FinalizeArgs fin{p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0, set_size};
   // (the finalize rides in the flush's last workgroup when its partial sums are few -- 256 threads play its 1,024 lanes: C5's
   // 70 k partials took 30 us there against 10 + 11 as two launches)
-  if (!rc) rc = det_end(p, st, grad_is_output, (fin_done || nparts > 4096) ? nullptr : &fin, &fin_done);
+  // (sets of slots are read up to the device's row count only: what counts is their live prefix, bounded by the host's)
+  const int fin_reads = set_size > 0 ? (nparts / set_size) * ((n_rows + 3) / 4) : nparts;
+  if (!rc) rc = det_end(p, st, grad_is_output, (fin_done || fin_reads > 8192) ? nullptr : &fin, &fin_done);
   if (rc || fin_done) return rc;
   return launch_loss_finalize(p.partials, nparts, n_edges_dev, n_rows, ks * ks, w_l1, w_kl, loss_out, nan_on_overflow ? 1 : 0, st,
                               set_size);

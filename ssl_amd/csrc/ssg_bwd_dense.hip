@@ -1018,6 +1018,21 @@ __attribute__((amdgpu_waves_per_eu((RG == 8 || SPL) ? 2 : 1, (RG == 8 || SPL) ? 
   }
 }
 
+// (25,9): BOTH chunk classes of the 8 x 32 tiles in one launch (round 6).  The two instantiations used to be launched one
+// after the other over the tile list, a tile running in its own; C2 and C4 hold no TILE_HUGE tile, so the second launch was
+// ~5 us of workgroups that start only to leave, on the step's critical path.  Both bodies run at two waves per SIMD (236
+// and 238 registers), so one kernel that picks the body by the plan's class bit costs neither occupancy.
+template <int KS, int KW, int C, int TY, int RG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_bwd_dense_classes(DenseBwdParams p) {
+  static_assert(TY == 8 && RG == 8, "the 8 x 32 tiles of k_s <= 25");
+  const int tslot = blockIdx.x;
+  if (tslot >= dense_tile_count(p.n_dense)) return;
+  const int tx_n = (p.W + 31) / 32, ty_n = (p.H + TY - 1) / TY;
+  const int listed = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
+  if (__builtin_amdgcn_readfirstlane(listed) & TILE_HUGE) bwd_dense_body<KS, KW, C, TY, 4, RG, false, false, 2>(p);
+  else bwd_dense_body<KS, KW, C, TY, 2, RG, false, false, 2>(p);
+}
+
 // ------------------------------------------------------------------ host ----
 bool dense_bwd_supported(int ks, int kw, int C) { return C == 3 && ((ks == 25 && kw == 9) || (ks == 49 && kw == 13)); }
 
@@ -1064,6 +1079,16 @@ int launch_bwd_dense(const DenseBwdParams &p0, int ks, int kw, int C, hipStream_
     int rc = !tm ? 0 : launch_one<49, 13, 3, 4, 2, 4, true, true>(p, p.tm_slots < p.max_tiles ? p.tm_slots : p.max_tiles, st);
     if (!rc) rc = launch_one<49, 13, 3, 4, 2, 4, false>(p, p.max_tiles, st);
     return rc;
+  }
+  static const bool one_launch = env_int("SSG_DENSE_ONE_LAUNCH", 1) != 0;   // (profiling build: 0 = a launch per class, A/B)
+  if (one_launch) {
+    using G = DenseBwdGeo<25, 9, 3, 8, 8>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (const int rc = ensure_dynamic_lds(ssg_bwd_dense_classes<25, 9, 3, 8, 8>, (int)G::lds_bytes(), lds_set)) return rc;
+    hipLaunchKernelGGL((ssg_bwd_dense_classes<25, 9, 3, 8, 8>),
+                       dim3((unsigned)p.max_tiles, (unsigned)(p.qsplit > 0 ? p.qsplit : QSPLIT_AUTO_MAX), G::NHALF), dim3(64),
+                       G::lds_bytes(), st, p);
+    return (int)hipGetLastError();
   }
   int rc = launch_one<25, 9, 3, 8, 2, 8>(p, p.max_tiles, st);
   // (TILE_HUGE tiles are heavy ones -- more than 64 rows each, at the front of the list: see launch_fwd_dense_25)

@@ -161,7 +161,7 @@ __device__ __forceinline__ int dense_h_col(int ex, int L, int G, bool paired) {
 // trip (18 registers; with four chunks it would be 36 more than the kernel has).  Measured (same-box A/B, C2): dense
 // forward 0.396 -> 0.374 ms.
 template <int KS, int KW, int C, int NW, bool TM = false, bool RAW = false, int NCH = 0>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_fwd_dense(DenseParams p) {
+__device__ __forceinline__ void fwd_dense_body(const DenseParams &p) {
   static_assert(!(TM && RAW), "raw distances go to the caller's row-major rows");
   constexpr int NT = 64 * NW;
   constexpr int HP = KS / 2, HK = KW / 2, P = KS * KS, HALO = HP + HK, DT_Y = 16 - 2 * HK;
@@ -794,6 +794,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 }
 
+template <int KS, int KW, int C, int NW, bool TM = false, bool RAW = false, int NCH = 0>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_fwd_dense(DenseParams p) {
+  fwd_dense_body<KS, KW, C, NW, TM, RAW, NCH>(p);
+}
+
+// (25,9): BOTH chunk classes of the 8 x 32 tiles in one launch (round 6; see ssg_bwd_dense_classes): the workgroup reads its
+// tile's class bit from the plan and runs that instantiation's body.  Both run at two waves per SIMD, so the merged kernel
+// costs no occupancy; C2 / C4 hold no TILE_HUGE tile and lose a launch of workgroups that start only to leave.
+template <int KS, int KW, int C, int NW, bool RAW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssg_fwd_dense_classes(DenseParams p) {
+  const int tslot = blockIdx.x / p.nimg;
+  if (tslot >= dense_tile_count(p.n_dense)) return;
+  const int tx_n = (p.W + DT_X - 1) / DT_X, ty_n = (p.H + 7) / 8;
+  const int listed = dense_tile_at(p.n_dense, p.tiles, p.B * ty_n * tx_n, tslot);
+  if (__builtin_amdgcn_readfirstlane(listed) & TILE_HUGE) fwd_dense_body<KS, KW, C, NW, false, RAW, 4>(p);
+  else fwd_dense_body<KS, KW, C, NW, false, RAW, 2>(p);
+}
+
 
 // ------------------------------------------------------------------ strips (k_s 49, tile-major rows) ----
 // The tile kernel above computes E_q and its horizontal sums on 16 U-rows to serve DT_Y = 16 - (k_w - 1) centre rows:
@@ -1287,7 +1305,19 @@ static int launch_fwd_dense_t(DenseParams p, int n_tiles, hipStream_t st) {
 
 // (25,9): the two chunk classes of the 8 x 32 tiles, both over the whole tile list (a tile runs in its own)
 template <bool RAW>
-static int launch_fwd_dense_25(const DenseParams &p, hipStream_t st) {
+static int launch_fwd_dense_25(const DenseParams &p0, hipStream_t st) {
+  static const bool one_launch = env_int("SSG_DENSE_ONE_LAUNCH", 1) != 0;   // (profiling build: 0 = a launch per class, A/B)
+  if (one_launch) {
+    DenseParams p = p0;
+    if (p.max_tiles <= 0) return 0;
+    const size_t lds = dense_lds_bytes<25, 9, 3, 4>();
+    static std::atomic<unsigned long long> lds_set{0};
+    if (const int rc = ensure_dynamic_lds(ssg_fwd_dense_classes<25, 9, 3, 4, RAW>, (int)lds, lds_set)) return rc;
+    p.grid_tiles = p.max_tiles;
+    hipLaunchKernelGGL((ssg_fwd_dense_classes<25, 9, 3, 4, RAW>), dim3((unsigned)p.max_tiles * p.nimg), dim3(256), lds, st, p);
+    return (int)hipGetLastError();
+  }
+  const DenseParams &p = p0;
   int rc = launch_fwd_dense_t<25, 9, 3, 4, false, RAW, 2>(p, p.max_tiles, st);
   // TILE_HUGE tiles sit among the HEAVY ones, at the front of the list, and a heavy tile holds more than 64 of the call's
   // rows: slots from n_host / 65 on cannot be theirs (with a tight row capacity the launch -- empty at C2 / C4 -- shrinks
