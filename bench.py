@@ -274,7 +274,8 @@ def _stage_times_body(L, f_edges, f_fwd, f_bwd, only, iters, KS, KW, prev_overla
     f_bwd()
     torch.cuda.synchronize()
     fwd_group, bwd_group = ("fwd_dense", "fwd_direct"), ("grad_rows", "bwd_dense", "bwd_direct")
-    dense = f"<{KS},{KW},3>"
+    # ((25,9): both chunk classes of the 8 x 32 tiles in one launch since round 6 -- ssg_{fwd,bwd}_dense_classes<...>)
+    dense = ("_classes" if KS == 25 else "") + f"<{KS},{KW},3>"
     out[f"ssg_fwd_dense{dense}"] = only(f_fwd, "fwd_dense", fwd_group)
     out[f"ssg_fwd_tiled<{KS},{KW}> merged+single (2 launches)"] = only(f_fwd, "fwd_direct", fwd_group)
     # (the masked forward runs above left the row scales of the dense-tile rows cleared: a complete forward again, so
@@ -408,9 +409,13 @@ def pmc_entry(kernel_name):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
         key = kernel_name.replace(" ", "")
-        for k, v in t.get("kernels", {}).items():
-            if k == key or k.startswith(key.rstrip(">") + ","):    # ssg_bwd_dense<25,9,3> ~ ssg_bwd_dense<25,9,3,8,2,8>
-                return v
+        # (round 6: the (25,9) dense kernels run both chunk classes in one launch, ssg_{fwd,bwd}_dense_classes<...>)
+        keys = [key] + ([key.replace("_dense<", "_dense_classes<")] if "_dense<" in key else []) + \
+               ([key.replace("_dense_classes<", "_dense<")] if "_dense_classes<" in key else [])
+        for key in keys:
+            for k, v in t.get("kernels", {}).items():
+                if k == key or k.startswith(key.rstrip(">") + ","):    # ssg_bwd_dense<25,9,3> ~ ssg_bwd_dense<25,9,3,8,2,8>
+                    return v
     except (OSError, ValueError):
         pass
     return None

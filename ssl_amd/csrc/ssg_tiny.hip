@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256) void ssg_tiny_step(TinyParams p) {
       Gv = tid == HP * KS + HP ? 0.f : -(a * kfac) * (g - dot);   // (the centre offset multiplies A - B == 0: dropped, see ssg_bwd.hip)
       Gt[tid] = Gv;
     }
-    if (tid == 0) {   // (agent-scope stores: written through, see the hand-off below)
-      __hip_atomic_store(p.partials + 2 * (size_t)n, fred[0][1] + fred[1][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.partials + 2 * (size_t)n + 1, fred[0][2] + fred[1][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      p.partials[2 * (size_t)n] = fred[0][1] + fred[1][1];
+      p.partials[2 * (size_t)n + 1] = fred[0][2] + fred[1][2];
     }
     if (p.grad && !SSG_DBG(p, 2)) {
       if (wv < 2) {
@@ -202,34 +202,37 @@ __global__ __launch_bounds__(256) void ssg_tiny_step(TinyParams p) {
       for (int i = tid; i < C * P; i += 256) {
         const int c = i / P, r = i - c * P, ty = r / KS, tx = r - ty * KS;
         const float v = gst[c][r];
-        if (v != 0.f && !SSG_DBG(p, 4))
-          grad_add(p.grad, fix ? p.gfix : nullptr,
-                   (((size_t)e.b * C + c) * H + reflect_idx(e.y - HP + ty, H)) * W + reflect_idx(e.x - HP + tx, W), v, gsc);
+        if (v != 0.f && !SSG_DBG(p, 4)) {
+          const size_t gi = (((size_t)e.b * C + c) * H + reflect_idx(e.y - HP + ty, H)) * W + reflect_idx(e.x - HP + tx, W);
+          grad_add(p.grad, fix ? p.gfix : nullptr, gi, v, gsc);
+        }
       }
     }
     __syncthreads();   // (the tiles, the rows and the staging are the next row's)
   }
 
   // ---- the last workgroup through finishes the step ----
-  // Hand-off without an agent-scope RELEASE: on gfx950 that fence is an L2 write-back (buffer_wbl2) per workgroup -- 1,024
-  // of them made this kernel 74 us long.  Everything another workgroup reads afterwards was written with agent-scope
-  // operations (the gradient atomics, the criteria slots: performed at memory, not in this XCD's L2), so a workgroup only
-  // has to wait until its own have completed (s_waitcnt: the workgroup-scope fence) before it draws its ticket; the last
-  // one through invalidates its caches (agent-scope ACQUIRE: buffer_inv) and reads with plain loads.
-  // Only the workgroups that had a row draw a ticket (1,024 atomics on one address are 4 us of the launch; with no row at all
-  // workgroup 0 stands in).
+  // Only the workgroups that had a row take part (with no row at all workgroup 0 stands in): 1,024 tickets on one address
+  // were 6 us of the launch.  The hand-off is the grid-synchronisation idiom: every lane's writes are ordered in front of
+  // the workgroup barrier, then ONE lane draws the ticket with an agent-scope RELEASE -- on gfx950 an L2 write-back
+  // (buffer_wbl2 sc1) in front of the atomic; issued by every wave (a __threadfence() per lane: 1,024 workgroups x 4) it made
+  // the first version of this kernel 74 us long, 4 per working workgroup 37 us, one per working workgroup 26 us.  It cannot
+  // be dropped: with a relaxed ticket behind an s_waitcnt the last workgroup folded sums that lacked other XCDs' last
+  // additions, once in a few hundred steps of a 2 x 10 x 6 pixel call (tools/r6_fuzz_tiny.py).
   const int n_work = nrows < (int)gridDim.x ? (nrows > 0 ? nrows : 1) : (int)gridDim.x;
   if ((int)blockIdx.x >= n_work) return;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // (every wave's own atomics and stores acknowledged before the barrier: the workgroup-scope fence of __syncthreads() leaves
+  //  vmcnt alone on this target -- the waves of a workgroup share their L1 -- and the ticket below is drawn by ONE wave)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) s_last = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_work - 1;
+  if (tid == 0) s_last = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == n_work - 1;
   __syncthreads();
   if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __threadfence();   // (every wave of the last workgroup: its cached lines are invalidated before it reads the others' sums)
   {
     double a1 = 0.0, a2 = 0.0;
-    // (plain loads behind the acquiring fence above -- it invalidates this CU's and this XCD's cached lines; a load with agent
-    //  scope of its own would make 2 x nrows / 256 dependent round trips to memory of this loop)
+    // (plain loads behind the fence above -- it invalidates this CU's and this XCD's cached lines; a load with agent scope
+    //  of its own would make 2 x nrows / 256 dependent round trips to memory of this loop)
     const float2 *pp = (const float2 *)p.partials;
     for (int i = tid; i < nrows; i += 256) {
       const float2 v = pp[i];

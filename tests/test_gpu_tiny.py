@@ -214,3 +214,24 @@ def test_general_11_5_path_stays_covered(dev, golden):
     sr, gt, masks = _inputs(9000, 1, 160, 160, 0.02)                     # 25,600 pixels: beyond the builder's limit anyway
     r = _raw_step(dev, "ssg_loss_step", sr, gt, masks[:, None], 0, 1, 11, 5, 0.3, 2000, True)
     _check_against_oracle(r, sr, gt, masks, 11, 5, 0.3)
+
+
+def test_tiny_step_fold_sees_every_workgroups_sums(dev):
+    """Regression (round 6, found by tools/r6_fuzz_tiny.py): with a relaxed ticket behind a bare s_waitcnt the last workgroup
+    folded fixed-point sums that lacked other workgroups' last additions -- once in a few hundred steps of a tiny, fully
+    masked call, where sixty workgroups queue on a few hundred addresses.  Deterministic mode promises the same bits every
+    run: 400 steps of a 2 x 10 x 6 call (and of 1 x 6 x 6, every search tile folded twice) equal the first, and the general path."""
+    from ssl_amd import engine
+    for (B, H, W) in ((2, 10, 6), (1, 6, 6)):
+        sr, gt, m = _inputs(9100 + H, B, H, W, 0.6)
+        srt, gtt, mt = T(sr, dev), T(gt, dev), T(m[:, None], dev)
+        step = engine.LossStep(B, 3, H, W, 11, 5, 0.004, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True)
+        loss, grad = step(srt, gtt, mt)
+        l0, g0 = loss.clone(), grad.clone()
+        for _ in range(400):
+            loss, grad = step(srt, gtt, mt)
+            assert torch.equal(grad, g0) and torch.equal(loss, l0)
+        with tiny_off():
+            ref = engine.LossStep(B, 3, H, W, 11, 5, 0.004, 1e-10, True, 1e3, 1e3, device=dev, deterministic=True)
+            lr, gr = ref(srt, gtt, mt)
+            assert float((gr - g0).abs().max()) <= 2e-6 * float(gr.abs().max())
