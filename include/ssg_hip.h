@@ -183,7 +183,7 @@ int ssg_last_overlap_assignment(void);
  * reference's own CPU-runnable case (loss_util.py:185-229 on a 64 x 64 crop) -- with B*H*W <= 16,384 pixels and
  * capacity <= 4,096 rows run as TWO launches: one workgroup builds the edge list and clears the sums, then one workgroup
  * per edge pixel computes both SSG rows, the criteria and the row's gradient, and the last one through folds the step
- * (ssg_tiny.hip; C1: 59 -> about 20 us).  Same outputs, workspace and error behaviour as the general path; results equal
+ * (ssg_tiny.hip; C1: 59 -> 27 us).  Same outputs, workspace and error behaviour as the general path; results equal
  * to rounding (other summation orders), bit-reproducible in deterministic mode.  The workspace then holds the edge list and
  * the rank map but no tile order.  on = 0 keeps every call on the general path (default 1).  Process-wide; returns the
  * previous setting.  No reference counterpart. */
