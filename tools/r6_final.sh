@@ -16,8 +16,8 @@ cd /tmp
 # the default build's trace (direct kernels beside the dense ones) as *_overlap.csv
 # (c5f = the fused C5 step, no SSG output: tile-major scratch rows, ssg_fwd_strip / ssg_rows_tm / ssg_bwd_dense<..., TM>;
 #  its stats come from a run WITHOUT bench's per-kernel table, which launches the row-major kernels on their own)
-flags() { case $1 in c2) echo "--config c2";; c4) echo "--config c4 --no-kernel-table";; c5) echo "--config c5 --no-kernel-table";; c5f) echo "--config c5 --no-ssg-output --no-kernel-table";; esac; }
-for cfg in c2 c4 c5 c5f; do
+flags() { case $1 in c1) echo "--config c1 --steps 200";; c2) echo "--config c2";; c4) echo "--config c4 --no-kernel-table";; c5) echo "--config c5 --no-kernel-table";; c5f) echo "--config c5 --no-ssg-output --no-kernel-table";; esac; }
+for cfg in c1 c2 c4 c5 c5f; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$cfg" -o bench -- python "$R/bench.py" $(flags $cfg) --no-overlap --steps 10 --warmup 3 --no-cpu-baseline --no-module --no-extra > "$O/prof_$cfg.log" 2>&1
   f=$(find "$O/prof_$cfg" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/r6_bench_${cfg}_kernel_stats.csv"
   find "$O/prof_$cfg" -name "*kernel_trace.csv" -delete
