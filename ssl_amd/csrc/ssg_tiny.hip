@@ -20,7 +20,8 @@
 //       finish       the workgroup that draws the last ticket sums the criteria slots in fp64 in a fixed order
 //                    (-> loss_out) and turns the fixed-point sums into the gradient (ssg_bwd.hip's flush + finalize).
 // Same results as the six-launch path to rounding (different summation orders; parity against the oracle and the
-// reference's fixtures F1 / F3 in tests/test_gpu_tiny.py, bit-reproducible in deterministic mode).  Taken by
+// reference's fixture F1 in tests/test_gpu_parity.py / test_gpu_tiny.py, SSG rows bit-identical to the general path's in 9,000 fuzz
+// cases; bit-reproducible in deterministic mode).  Taken by
 // ssg_loss_fwd_bwd / ssg_loss_step when B H W <= 16,384 pixels and capacity <= 4,096 rows (ssg_api.hip); ssg_set_tiny_step(0)
 // turns it off.
 #include "ssg_common.hpp"
